@@ -1,0 +1,246 @@
+/*
+ * nextplaid_hip.h -- C ABI of the MI355X-native PLAID search path for next-plaid.
+ *
+ * This is the drop-in boundary: the entry points a `hip` cargo feature of the next-plaid crate
+ * would bind (extern "C") to serve MmapIndex::{load, search, search_batch} from a gfx950 GPU
+ * instead of the crate's CPU path.  Plain pointers and sizes only; no C++/torch types.
+ * Each entry cites the reference interface it replaces (paths under /root/reference/next-plaid/src).
+ *
+ * Conventions
+ *  - Every function returning int returns an np_status; 0 = ok.  Codes map onto the crate's
+ *    error enum (error.rs:9-66): 1 IndexLoad, 2 Search, 3 Shape, 4 Codec, 5 Io, 6 DeviceUnavailable
+ *    (the Rust wrapper falls back to its CPU path unless NEXT_PLAID_FORCE_GPU, mirroring
+ *    cuda.rs:105-144), 7 OutOfMemory, 8 InvalidArgument.  Nothing aborts or throws across the ABI.
+ *  - np_hip_last_error() is thread-local and valid until the next call on that thread.
+ *  - An np_index is immutable after open; all search entry points are re-entrant and may be
+ *    called concurrently on one shared handle from many threads (the crate shares &MmapIndex
+ *    across tokio workers, next-plaid-api/src/state.rs:413-416).  Each call checks a private
+ *    stream + workspace out of a small pool.
+ *  - The caller allocates every output buffer; no allocation crosses the boundary.
+ *  - Doc ids are GLOBAL i64 ids (position in the concatenation of doclens.*.json) even when the
+ *    handle holds one document shard.
+ */
+#ifndef NEXTPLAID_HIP_H
+#define NEXTPLAID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NP_ABI_VERSION 1
+
+typedef enum np_status {
+  NP_OK = 0,
+  NP_ERR_INDEX_LOAD = 1,         /* Error::IndexLoad  (error.rs:37) */
+  NP_ERR_SEARCH = 2,             /* Error::Search     (error.rs:17) */
+  NP_ERR_SHAPE = 3,              /* Error::Shape      (error.rs:29) */
+  NP_ERR_CODEC = 4,              /* Error::Codec      (error.rs:41) */
+  NP_ERR_IO = 5,                 /* Error::Io / Json  (error.rs:21,25) */
+  NP_ERR_DEVICE_UNAVAILABLE = 6, /* no usable gfx950 device / HIP runtime failure */
+  NP_ERR_OUT_OF_MEMORY = 7,
+  NP_ERR_INVALID_ARGUMENT = 8
+} np_status;
+
+typedef struct np_index np_index; /* opaque: device-resident index (or one document shard of it) */
+
+/* Options for opening an index.  Zero-initialise, then set what you need. */
+typedef struct np_open_opts {
+  int32_t device;       /* HIP device ordinal (one process per GPU: pass LOCAL_RANK) */
+  int32_t shard_rank;   /* this handle holds documents [N*rank/count, N*(rank+1)/count) */
+  int32_t shard_count;  /* 0 or 1 = whole index */
+  int32_t n_contexts;   /* concurrent search calls served without blocking (default 2) */
+  int32_t max_batch;    /* workspace is sized for this many queries per call (default 64);
+                           larger batches are processed in slices */
+  int32_t max_query_tokens; /* per-query token cap used to size workspaces (default 64;
+                           grows automatically, this is only the initial reservation) */
+  int64_t workspace_bytes;  /* soft cap for per-context scratch (0 = default 8 GiB) */
+} np_open_opts;
+
+/* Mirrors SearchParameters (search.rs:26-69).  batch_size is unused by search and omitted. */
+typedef struct np_search_params {
+  int32_t top_k;                  /* search.rs:34 */
+  int32_t n_full_scores;          /* search.rs:32 */
+  int32_t n_ivf_probe;            /* search.rs:36 */
+  int32_t centroid_batch_size;    /* search.rs:41: K > this (and > 0) selects the batched-probe
+                                     semantics of search.rs:140-254 */
+  float centroid_score_threshold; /* search.rs:47 */
+  int32_t has_threshold;          /* 0 = None */
+  int32_t precision;              /* 0 = fp32 everywhere (exact-f32 MFMA; parity mode)
+                                     1 = bf16 MFMA for the exact MaxSim stage only */
+} np_search_params;
+
+typedef struct np_info {            /* accessors of index.rs:1290-1312 */
+  int64_t num_documents;            /* whole index */
+  int64_t num_embeddings;           /* whole index (metadata.json) */
+  int64_t num_partitions;           /* K */
+  int32_t embedding_dim;
+  int32_t nbits;
+  double avg_doclen;
+  int64_t shard_doc_begin, shard_doc_end; /* documents held by this handle */
+  int64_t shard_embeddings;         /* tokens held by this handle */
+  int64_t device_bytes;             /* HBM held by the index (without workspaces) */
+  int32_t device;
+  int32_t abi_version;
+} np_info;
+
+/* Per-call stage timings (HIP events on the call's stream) and work counters.  Optional. */
+typedef struct np_stats {
+  float ms_total;        /* first launch -> results ready */
+  float ms_centroid;     /* S1  Q.C^T (MFMA) + group maxima */
+  float ms_probe;        /* S2  top-nprobe per token, threshold, cell list */
+  float ms_candidates;   /* S3  posting-list union (bitmap) + compaction */
+  float ms_approx;       /* S4  approximate scores (codes x QC gather) */
+  float ms_select;       /* S5  top n_full_scores/4 by approximate score */
+  float ms_exact;        /* S6  decompress + MaxSim (MFMA) */
+  float ms_topk;         /* S7  final top-k */
+  int64_t n_cells;       /* probed cells after threshold, summed over the batch */
+  int64_t n_ivf_ids;     /* posting-list entries read */
+  int64_t n_candidates;  /* unique candidate documents */
+  int64_t n_cand_tokens; /* sum of candidate doc lengths (codes read by S4) */
+  int64_t n_exact_docs;  /* documents exact-scored */
+  int64_t n_exact_tokens;/* tokens decompressed by S6 */
+  int32_t n_queries;
+  int32_t reserved;
+} np_stats;
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+
+/* Number of usable gfx950 devices (0 if none / no HIP runtime).  Replaces the role of
+ * cuda::get_global_context().is_some() (cuda.rs:105-144) for the search path. */
+int np_hip_device_count(void);
+
+/* Thread-local description of the last error on this thread ("" if none). */
+const char* np_hip_last_error(void);
+
+/* ---- index lifecycle ------------------------------------------------------------------------ */
+
+/* MmapIndex::load (index.rs:1026-1139): reads the crate's on-disk index directory unchanged
+ * (metadata.json, centroids.npy, bucket_weights.npy, ivf.npy, ivf_lengths.npy, doclens.N.json,
+ * N.codes.npy, N.residuals.npy; NPY v1/v2) and makes it resident in HBM.  The merged_*.npy caches
+ * are not needed: chunks are concatenated in the same order. */
+int np_hip_index_open(const char* index_dir, const np_open_opts* opts, np_index** out);
+
+/* Same index, built from host arrays in the on-disk dtypes instead of files (what
+ * MmapIndex holds after load: index.rs:995-1016).  doc ids in `ivf` are global; with sharding
+ * the arrays may cover only the shard's documents (doc_begin = first global id) or the whole
+ * index (doc_begin = 0, the shard range is cut out here).  bucket_cutoffs may be NULL. */
+typedef struct np_index_arrays {
+  int64_t num_documents_total;  /* N of the whole index */
+  int64_t doc_begin;            /* global id of doc_lengths[0] */
+  int64_t num_docs;             /* entries in doc_lengths */
+  int64_t num_centroids;        /* K */
+  int32_t dim, nbits;
+  const float* centroids;       /* [K, dim] */
+  const float* bucket_weights;  /* [2^nbits] */
+  const int64_t* ivf;           /* concatenated posting lists, global doc ids ascending per list */
+  const int32_t* ivf_lengths;   /* [K] */
+  const int64_t* doc_lengths;   /* [num_docs] */
+  const int64_t* codes;         /* [sum doc_lengths] */
+  const uint8_t* residuals;     /* [sum doc_lengths, dim*nbits/8] */
+} np_index_arrays;
+int np_hip_index_from_arrays(const np_index_arrays* arrays, const np_open_opts* opts, np_index** out);
+
+/* Seeded synthetic corpus generated directly in HBM (bench / large-scale tests; the generator
+ * spec is next-plaid_amd/next_plaid_amd/synth.py, bit-identical).  centroids / bucket_weights
+ * are host arrays.  Sharding as in np_open_opts. */
+typedef struct np_synth_spec {
+  int64_t num_docs;             /* whole corpus */
+  int64_t num_centroids;
+  int32_t dim, nbits;
+  int32_t doc_len_min, doc_len_max;
+  int32_t n_topics, rand256;
+  uint64_t seed;
+  const float* centroids;       /* [K, dim] */
+  const float* bucket_weights;  /* [2^nbits] */
+} np_synth_spec;
+int np_hip_index_synth(const np_synth_spec* spec, const np_open_opts* opts, np_index** out);
+
+/* Copies the shard held by a handle back to host arrays in the on-disk dtypes (ivf ids global).
+ * Pass NULL for any array not wanted.  Sizes come from np_hip_index_info / np_hip_index_ivf_size. */
+int np_hip_index_export(const np_index* index, int64_t* doc_lengths, int64_t* codes, uint8_t* residuals,
+                        int64_t* ivf, int32_t* ivf_lengths);
+int64_t np_hip_index_ivf_size(const np_index* index);
+
+void np_hip_index_close(np_index* index);               /* Drop for MmapIndex */
+int np_hip_index_info(const np_index* index, np_info* out); /* index.rs:1290-1312 */
+
+/* ---- search ------------------------------------------------------------------------------------ */
+
+/* MmapIndex::search_batch (index.rs:1279-1287 -> search.rs:643-675); MmapIndex::search
+ * (index.rs:1258-1265) is the B = 1 case.
+ *   queries        row-major f32, all queries' token rows concatenated: [q_tok_offsets[B], dim]
+ *   q_tok_offsets  B+1 prefix offsets (query i owns rows [off[i], off[i+1]))
+ *   subset         optional pre-filter doc ids (search.rs:350-382,434-437); subset_len < 0 = None,
+ *                  subset_len == 0 = empty subset (every result empty)
+ *   out_ids/out_scores  [B * top_k], query i at [i*top_k, i*top_k + out_counts[i]); scores descending
+ *   out_counts     [B]
+ * Host pointers; H2D/D2H copies are inside the call. */
+int np_hip_search_batch(const np_index* index, const float* queries, const int32_t* q_tok_offsets,
+                        int32_t B, int32_t dim, const np_search_params* params,
+                        const int64_t* subset, int64_t subset_len,
+                        int64_t* out_ids, float* out_scores, int32_t* out_counts, np_stats* stats);
+
+/* Same call with every buffer already resident in HBM on `index`'s device and the work enqueued on
+ * `stream` (a hipStream_t; NULL = the context's own stream).  Returns after enqueueing; the caller
+ * synchronises the stream.  `stats` (host) is filled only by np_hip_search_batch.  This is what a
+ * multi-GPU host and bench.py use (queries resident, results consumed on device by the merge). */
+int np_hip_search_batch_device(const np_index* index, const float* d_queries,
+                               const int32_t* d_q_tok_offsets, const int32_t* h_q_tok_offsets,
+                               int32_t B, int32_t dim, const np_search_params* params,
+                               const int64_t* d_subset, int64_t subset_len,
+                               int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts,
+                               void* stream);
+
+/* ---- document-sharded search (one process per GPU) -------------------------
+ * Phase A runs S1-S5 on the local shard and leaves, per query, the shard's best
+ * n_sel = min(n_full_scores, max(n_full_scores/4, top_k)) candidates as 64-bit rank keys in
+ * d_sel_keys[B * n_sel] (descending; key = orderable(approx score) << 32 | ~global_doc_id; 0 pads).
+ * The host all-gathers the keys over RCCL, takes each query's global n_sel-th key as the cut, and
+ * phase B exact-scores only the local candidates with key >= d_cut[b], returning the local top-k
+ * as (score, id, key) triples.  np_hip_merge_topk then merges the G shards' triples into the
+ * final top-k with the reference's tie rules (exact score desc, then approx rank).  With
+ * shard_count == 1 and d_cut == NULL the result equals np_hip_search_batch. */
+int np_hip_search_phase_a(const np_index* index, const float* d_queries, const int32_t* d_q_tok_offsets,
+                          const int32_t* h_q_tok_offsets, int32_t B, int32_t dim,
+                          const np_search_params* params, const int64_t* d_subset, int64_t subset_len,
+                          uint64_t* d_sel_keys, void* stream, void** call_state);
+int np_hip_search_phase_b(const np_index* index, void* call_state, const uint64_t* d_cut,
+                          int64_t* d_out_ids, float* d_out_scores, uint64_t* d_out_keys,
+                          int32_t* d_out_counts, void* stream);
+/* Ends a phase-A/phase-B call and returns its context to the pool (always call it). */
+void np_hip_search_end(const np_index* index, void* call_state);
+/* n_sel for given params (size of one query's slice of d_sel_keys). */
+int32_t np_hip_n_sel(const np_search_params* params);
+/* Global cut from G gathered key lists: d_all_keys[G][B][n_sel] -> d_cut[B]. */
+int np_hip_select_cut(const np_index* index, const uint64_t* d_all_keys, int32_t G, int32_t B,
+                      int32_t n_sel, uint64_t* d_cut, void* stream);
+/* Merge G shards' local top-k triples ([G][B][top_k], counts [G][B]) into out [B][top_k]. */
+int np_hip_merge_topk(const np_index* index, const int64_t* d_ids, const float* d_scores,
+                      const uint64_t* d_keys, const int32_t* d_counts, int32_t G, int32_t B,
+                      int32_t top_k, int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts,
+                      void* stream);
+
+/* ---- adjacent rows ----------------------------------------------------- */
+
+/* N2: MmapIndex::get_document_embeddings / decompress_documents (index.rs:1159-1245): decompressed,
+ * L2-normalised f32 embeddings of the given global doc ids, concatenated; out_lengths[i] = tokens of
+ * doc i (0 for ids outside this shard).  out_embeddings may be NULL to query lengths only. */
+int np_hip_decompress_documents(const np_index* index, const int64_t* doc_ids, int64_t n_docs,
+                                float* out_embeddings, int64_t out_capacity_rows, int64_t* out_lengths);
+
+/* Stage-level debug access for parity tests: runs S1-S5 for ONE query and copies out the probed
+ * cells (ascending), candidate doc ids (ascending, global), their approximate scores, and the
+ * selected docs in approx-rank order with their exact scores.  Capacities are in elements;
+ * counts are returned in n_*.  Any pointer may be NULL. */
+int np_hip_debug_trace(const np_index* index, const float* query, int32_t n_tokens, int32_t dim,
+                       const np_search_params* params, const int64_t* subset, int64_t subset_len,
+                       int64_t* cells, int64_t cap_cells, int64_t* n_cells,
+                       int64_t* cand, float* approx, int64_t cap_cand, int64_t* n_cand,
+                       int64_t* sel, float* sel_exact, int64_t cap_sel, int64_t* n_sel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEXTPLAID_HIP_H */

@@ -1,0 +1,392 @@
+"""Host-side mirror of the next-plaid crate's search API over the C ABI (include/nextplaid_hip.h).
+
+Names, argument meaning and error behaviour follow the reference:
+  MmapIndex.load / search / search_batch / accessors  -> next-plaid/src/index.rs:1026-1312
+  SearchParameters / QueryResult                       -> next-plaid/src/search.rs:26-80
+  error classes                                        -> next-plaid/src/error.rs:9-66
+There is NO CPU fallback here: a missing library or GPU raises (DeviceUnavailableError); the
+Rust wrapper is where a CPU fallback would live.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(os.path.dirname(_PKG), "csrc", "libnextplaid_hip.so")
+
+
+def library_path() -> str:
+    return os.environ.get("NEXTPLAID_HIP_LIB", _LIB)
+
+
+# ---- errors (error.rs) ------------------------------------------------------------------------
+
+class NextPlaidError(RuntimeError):
+    pass
+
+
+class IndexLoadError(NextPlaidError):
+    """Error::IndexLoad"""
+
+
+class SearchError(NextPlaidError):
+    """Error::Search"""
+
+
+class ShapeError(NextPlaidError):
+    """Error::Shape"""
+
+
+class CodecError(NextPlaidError):
+    """Error::Codec"""
+
+
+class IoError(NextPlaidError):
+    """Error::Io / Error::Json"""
+
+
+class DeviceUnavailableError(NextPlaidError):
+    """No usable gfx950 device or the HIP library is missing."""
+
+
+_ERR = {1: IndexLoadError, 2: SearchError, 3: ShapeError, 4: CodecError, 5: IoError,
+        6: DeviceUnavailableError, 7: MemoryError, 8: ValueError}
+
+
+# ---- C structs -----------------------------------------------------------------------------------
+
+class np_open_opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
+                ("n_contexts", C.c_int32), ("max_batch", C.c_int32), ("max_query_tokens", C.c_int32),
+                ("workspace_bytes", C.c_int64)]
+
+
+class np_search_params(C.Structure):
+    _fields_ = [("top_k", C.c_int32), ("n_full_scores", C.c_int32), ("n_ivf_probe", C.c_int32),
+                ("centroid_batch_size", C.c_int32), ("centroid_score_threshold", C.c_float),
+                ("has_threshold", C.c_int32), ("precision", C.c_int32)]
+
+
+class np_info(C.Structure):
+    _fields_ = [("num_documents", C.c_int64), ("num_embeddings", C.c_int64), ("num_partitions", C.c_int64),
+                ("embedding_dim", C.c_int32), ("nbits", C.c_int32), ("avg_doclen", C.c_double),
+                ("shard_doc_begin", C.c_int64), ("shard_doc_end", C.c_int64), ("shard_embeddings", C.c_int64),
+                ("device_bytes", C.c_int64), ("device", C.c_int32), ("abi_version", C.c_int32)]
+
+
+class np_stats(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_centroid", C.c_float), ("ms_probe", C.c_float),
+                ("ms_candidates", C.c_float), ("ms_approx", C.c_float), ("ms_select", C.c_float),
+                ("ms_exact", C.c_float), ("ms_topk", C.c_float),
+                ("n_cells", C.c_int64), ("n_ivf_ids", C.c_int64), ("n_candidates", C.c_int64),
+                ("n_cand_tokens", C.c_int64), ("n_exact_docs", C.c_int64), ("n_exact_tokens", C.c_int64),
+                ("n_queries", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class np_index_arrays(C.Structure):
+    _fields_ = [("num_documents_total", C.c_int64), ("doc_begin", C.c_int64), ("num_docs", C.c_int64),
+                ("num_centroids", C.c_int64), ("dim", C.c_int32), ("nbits", C.c_int32),
+                ("centroids", C.c_void_p), ("bucket_weights", C.c_void_p), ("ivf", C.c_void_p),
+                ("ivf_lengths", C.c_void_p), ("doc_lengths", C.c_void_p), ("codes", C.c_void_p),
+                ("residuals", C.c_void_p)]
+
+
+class np_synth_spec(C.Structure):
+    _fields_ = [("num_docs", C.c_int64), ("num_centroids", C.c_int64), ("dim", C.c_int32), ("nbits", C.c_int32),
+                ("doc_len_min", C.c_int32), ("doc_len_max", C.c_int32), ("n_topics", C.c_int32),
+                ("rand256", C.c_int32), ("seed", C.c_uint64), ("centroids", C.c_void_p),
+                ("bucket_weights", C.c_void_p)]
+
+
+EXPORTS = [
+    "np_hip_device_count", "np_hip_last_error", "np_hip_index_open", "np_hip_index_from_arrays",
+    "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_close",
+    "np_hip_index_info", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
+    "np_hip_search_phase_b", "np_hip_search_end", "np_hip_n_sel", "np_hip_select_cut", "np_hip_merge_topk",
+    "np_hip_decompress_documents", "np_hip_debug_trace",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libnextplaid_hip.so.  Raises DeviceUnavailableError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise DeviceUnavailableError(f"{path} not built (run python -c 'import __graft_entry__ as g; g.build()')")
+    try:
+        L = C.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise DeviceUnavailableError(f"cannot load {path}: {e}") from e
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.np_hip_device_count.restype = C.c_int
+    L.np_hip_last_error.restype = C.c_char_p
+    L.np_hip_index_open.argtypes = [C.c_char_p, C.POINTER(np_open_opts), C.POINTER(vp)]
+    L.np_hip_index_from_arrays.argtypes = [C.POINTER(np_index_arrays), C.POINTER(np_open_opts), C.POINTER(vp)]
+    L.np_hip_index_synth.argtypes = [C.POINTER(np_synth_spec), C.POINTER(np_open_opts), C.POINTER(vp)]
+    L.np_hip_index_export.argtypes = [vp] * 6
+    L.np_hip_index_ivf_size.argtypes = [vp]
+    L.np_hip_index_ivf_size.restype = i64
+    L.np_hip_index_close.argtypes = [vp]
+    L.np_hip_index_close.restype = None
+    L.np_hip_index_info.argtypes = [vp, C.POINTER(np_info)]
+    L.np_hip_search_batch.argtypes = [vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64, vp, vp, vp,
+                                      C.POINTER(np_stats)]
+    L.np_hip_search_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,
+                                             vp, vp, vp, vp]
+    L.np_hip_search_phase_a.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64, vp, vp,
+                                        C.POINTER(vp)]
+    L.np_hip_search_phase_b.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.np_hip_search_end.argtypes = [vp, vp]
+    L.np_hip_search_end.restype = None
+    L.np_hip_n_sel.argtypes = [C.POINTER(np_search_params)]
+    L.np_hip_n_sel.restype = i32
+    L.np_hip_select_cut.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.np_hip_merge_topk.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.np_hip_decompress_documents.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.np_hip_debug_trace.argtypes = [vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,
+                                     vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc:
+        msg = lib().np_hip_last_error().decode("utf-8", "replace")
+        raise _ERR.get(rc, NextPlaidError)(msg or f"np_status {rc}")
+
+
+def device_count() -> int:
+    try:
+        return int(lib().np_hip_device_count())
+    except DeviceUnavailableError:
+        return 0
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- crate mirror ------------------------------------------------------------------------------------
+
+@dataclass
+class SearchParameters:
+    """search.rs:26-69 (same field names and defaults) + `precision` (0 fp32 parity, 1 bf16 MaxSim)."""
+    batch_size: int = 2000
+    n_full_scores: int = 4096
+    top_k: int = 10
+    n_ivf_probe: int = 8
+    centroid_batch_size: int = 100_000
+    centroid_score_threshold: float | None = 0.4
+    precision: int = 0
+
+    def _c(self) -> np_search_params:
+        t = self.centroid_score_threshold
+        return np_search_params(self.top_k, self.n_full_scores, self.n_ivf_probe, self.centroid_batch_size,
+                                0.0 if t is None else float(t), 0 if t is None else 1, self.precision)
+
+
+@dataclass
+class QueryResult:
+    """search.rs:71-80"""
+    query_id: int
+    passage_ids: np.ndarray  # i64
+    scores: np.ndarray       # f32
+
+
+def _opts(device=0, shard_rank=0, shard_count=1, n_contexts=2, max_batch=64, max_query_tokens=64,
+          workspace_bytes=0):
+    return np_open_opts(device, shard_rank, shard_count, n_contexts, max_batch, max_query_tokens, workspace_bytes)
+
+
+class MmapIndex:
+    """Device-resident PLAID index; mirror of next_plaid::MmapIndex (index.rs:995-1312)."""
+
+    def __init__(self, handle, path=""):
+        self._h = handle
+        self.path = path
+        self._info = np_info()
+        _check(lib().np_hip_index_info(self._h, C.byref(self._info)))
+        self.last_stats: dict | None = None
+
+    # -- constructors ---------------------------------------------------------------------------------
+    @classmethod
+    def load(cls, index_path: str, **opts) -> "MmapIndex":
+        """MmapIndex::load (index.rs:1026).  opts: device, shard_rank, shard_count, n_contexts, max_batch."""
+        h = C.c_void_p()
+        o = _opts(**opts)
+        _check(lib().np_hip_index_open(os.fsencode(index_path), C.byref(o), C.byref(h)))
+        return cls(h, index_path)
+
+    @classmethod
+    def from_arrays(cls, centroids, bucket_weights, ivf, ivf_lengths, doc_lengths, codes, residuals, nbits,
+                    num_documents_total=None, doc_begin=0, **opts) -> "MmapIndex":
+        cen = np.ascontiguousarray(centroids, np.float32)
+        w = np.ascontiguousarray(bucket_weights, np.float32)
+        ivf = np.ascontiguousarray(ivf, np.int64)
+        il = np.ascontiguousarray(ivf_lengths, np.int32)
+        dl = np.ascontiguousarray(doc_lengths, np.int64)
+        cd = np.ascontiguousarray(codes, np.int64)
+        rs = np.ascontiguousarray(residuals, np.uint8)
+        if cen.ndim != 2:
+            raise ShapeError("centroids must be [K, dim]")
+        a = np_index_arrays(dl.size if num_documents_total is None else num_documents_total, doc_begin, dl.size,
+                            cen.shape[0], cen.shape[1], int(nbits), _ptr(cen), _ptr(w), _ptr(ivf), _ptr(il),
+                            _ptr(dl), _ptr(cd), _ptr(rs))
+        h = C.c_void_p()
+        o = _opts(**opts)
+        _check(lib().np_hip_index_from_arrays(C.byref(a), C.byref(o), C.byref(h)))
+        return cls(h, "<arrays>")
+
+    @classmethod
+    def synth(cls, spec, centroids=None, **opts) -> "MmapIndex":
+        """Seeded synthetic corpus generated in HBM (spec: next_plaid_amd.synth.SynthSpec)."""
+        from . import synth as S
+        cen = np.ascontiguousarray(S.centroids(spec) if centroids is None else centroids, np.float32)
+        _, w = S.bucket_tables(spec)
+        w = np.ascontiguousarray(w, np.float32)
+        s = np_synth_spec(spec.num_docs, spec.num_centroids, spec.dim, spec.nbits, spec.doc_len_min,
+                          spec.doc_len_max, spec.n_topics, spec.rand256, spec.seed, _ptr(cen), _ptr(w))
+        h = C.c_void_p()
+        o = _opts(**opts)
+        _check(lib().np_hip_index_synth(C.byref(s), C.byref(o), C.byref(h)))
+        return cls(h, "<synth>")
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            lib().np_hip_index_close(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- accessors (index.rs:1290-1312) ---------------------------------------------------------------
+    def num_documents(self):
+        return int(self._info.num_documents)
+
+    def num_embeddings(self):
+        return int(self._info.num_embeddings)
+
+    def num_partitions(self):
+        return int(self._info.num_partitions)
+
+    def avg_doclen(self):
+        return float(self._info.avg_doclen)
+
+    def embedding_dim(self):
+        return int(self._info.embedding_dim)
+
+    @property
+    def info(self) -> np_info:
+        return self._info
+
+    # -- search ------------------------------------------------------------------------------------------
+    def _pack(self, queries):
+        qs = [np.ascontiguousarray(q, np.float32) for q in queries]
+        d = self.embedding_dim()
+        for q in qs:
+            if q.ndim != 2 or q.shape[1] != d:
+                raise ShapeError(f"Shape error: query has shape {q.shape}, index dim is {d}")
+        off = np.zeros(len(qs) + 1, np.int32)
+        if qs:
+            off[1:] = np.cumsum([q.shape[0] for q in qs])
+        flat = np.concatenate(qs, 0) if qs else np.zeros((0, d), np.float32)
+        return np.ascontiguousarray(flat, np.float32), off
+
+    def search(self, query, params: SearchParameters, subset=None) -> QueryResult:
+        """MmapIndex::search (index.rs:1258-1265); query_id is 0 (search.rs:511-515)."""
+        r = self.search_batch([query], params, parallel=False, subset=subset)[0]
+        r.query_id = 0
+        return r
+
+    def search_batch(self, queries, params: SearchParameters, parallel: bool = True, subset=None):
+        """MmapIndex::search_batch (index.rs:1279-1287).  `parallel` only selects the reference's
+        error policy (search.rs:650-674): the GPU path always runs the batch as one pipeline pass."""
+        flat, off = self._pack(queries)
+        B = len(queries)
+        k = max(int(params.top_k), 0)
+        ids = np.zeros(max(B * k, 1), np.int64)
+        sc = np.zeros(max(B * k, 1), np.float32)
+        cnt = np.zeros(max(B, 1), np.int32)
+        p = params._c()
+        sub = None if subset is None else np.ascontiguousarray(subset, np.int64)
+        st = np_stats()
+        rc = lib().np_hip_search_batch(self._h, _ptr(flat), _ptr(off), B, self.embedding_dim(), C.byref(p),
+                                       _ptr(sub), -1 if sub is None else sub.size, _ptr(ids), _ptr(sc), _ptr(cnt),
+                                       C.byref(st))
+        if rc:
+            if parallel and rc == 2:  # search.rs:656-660: a failed query yields an empty result
+                return [QueryResult(i, np.zeros(0, np.int64), np.zeros(0, np.float32)) for i in range(B)]
+            _check(rc)
+        self.last_stats = st.as_dict()
+        return [QueryResult(i, ids[i * k: i * k + cnt[i]].copy(), sc[i * k: i * k + cnt[i]].copy())
+                for i in range(B)]
+
+    # -- adjacent rows ---------------------------------------------------------------------------------------
+    def get_document_embeddings(self, doc_id: int) -> np.ndarray:
+        """index.rs:1159-1179"""
+        embs, lens = self.decompress_documents([doc_id])
+        if doc_id < 0 or doc_id >= self.num_documents():
+            raise SearchError(f"Search failed: Invalid document ID: {doc_id}")
+        return embs
+
+    def decompress_documents(self, doc_ids):
+        """index.rs:1197-1245: (embeddings [sum len, dim], lengths)."""
+        ids = np.ascontiguousarray(doc_ids, np.int64)
+        lens = np.zeros(max(ids.size, 1), np.int64)
+        _check(lib().np_hip_decompress_documents(self._h, _ptr(ids), ids.size, None, 0, _ptr(lens)))
+        lens = lens[: ids.size]
+        total = int(lens.sum())
+        out = np.zeros((max(total, 1), self.embedding_dim()), np.float32)
+        _check(lib().np_hip_decompress_documents(self._h, _ptr(ids), ids.size, _ptr(out), total, _ptr(lens)))
+        return out[:total], lens
+
+    def debug_trace(self, query, params: SearchParameters, subset=None) -> dict:
+        q = np.ascontiguousarray(query, np.float32)
+        if q.ndim != 2 or q.shape[1] != self.embedding_dim():
+            raise ShapeError(f"Shape error: query has shape {q.shape}")
+        K = self.num_partitions()
+        n_loc = int(self._info.shard_doc_end - self._info.shard_doc_begin)
+        nsel = max(int(lib().np_hip_n_sel(C.byref(params._c()))), 1)
+        cells = np.zeros(max(K, 1), np.int64)
+        cand = np.zeros(max(n_loc, 1), np.int64)
+        approx = np.zeros(max(n_loc, 1), np.float32)
+        sel = np.zeros(nsel, np.int64)
+        sel_exact = np.zeros(nsel, np.float32)
+        nc, nd, ns = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        p = params._c()
+        sub = None if subset is None else np.ascontiguousarray(subset, np.int64)
+        _check(lib().np_hip_debug_trace(self._h, _ptr(q), q.shape[0], q.shape[1], C.byref(p), _ptr(sub),
+                                        -1 if sub is None else sub.size, _ptr(cells), cells.size, C.byref(nc),
+                                        _ptr(cand), _ptr(approx), cand.size, C.byref(nd),
+                                        _ptr(sel), _ptr(sel_exact), sel.size, C.byref(ns)))
+        return dict(cells=cells[: nc.value].copy(), cand=cand[: nd.value].copy(), approx=approx[: nd.value].copy(),
+                    sel=sel[: ns.value].copy(), sel_exact=sel_exact[: ns.value].copy())
+
+    def export(self) -> dict:
+        """Shard arrays back on the host in the on-disk dtypes (bench cpu_baseline, generator tests)."""
+        n_loc = int(self._info.shard_doc_end - self._info.shard_doc_begin)
+        T = int(self._info.shard_embeddings)
+        pd = self.embedding_dim() * int(self._info.nbits) // 8
+        K = self.num_partitions()
+        dl = np.zeros(max(n_loc, 1), np.int64)
+        cd = np.zeros(max(T, 1), np.int64)
+        rs = np.zeros((max(T, 1), pd), np.uint8)
+        ivf = np.zeros(max(int(lib().np_hip_index_ivf_size(self._h)), 1), np.int64)
+        il = np.zeros(max(K, 1), np.int32)
+        _check(lib().np_hip_index_export(self._h, _ptr(dl), _ptr(cd), _ptr(rs), _ptr(ivf), _ptr(il)))
+        return dict(doc_lengths=dl[:n_loc], codes=cd[:T], residuals=rs[:T], ivf=ivf[: int(il[:K].sum())],
+                    ivf_lengths=il[:K], nbits=int(self._info.nbits))
