@@ -1,0 +1,666 @@
+// np_index.hip -- makes a next-plaid index (or one document shard of it) resident in HBM.
+//
+// Replaces the in-memory half of MmapIndex::load (next-plaid/src/index.rs:1089-1139): ivf_offsets and
+// doc_offsets prefix sums, the codec tables (codec.rs:154-225), and -- instead of mmap'ing
+// merged_codes/merged_residuals -- device arrays laid out for the search kernels (np_internal.h).
+// Also: the seeded synthetic corpus generator (bench / scale tests) and export back to host.
+#include "np_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <string.h>
+
+namespace np {
+
+int DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return NP_OK;
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  size_t want = bytes + (bytes >> 3) + 256;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    p = nullptr;
+    set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    return NP_ERR_OUT_OF_MEMORY;
+  }
+  cap = want;
+  return NP_OK;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+void shard_range(int64_t n_total, int rank, int count, int64_t* b, int64_t* e) {
+  if (count <= 1) {
+    *b = 0;
+    *e = n_total;
+    return;
+  }
+  *b = (int64_t)((__int128)n_total * rank / count);
+  *e = (int64_t)((__int128)n_total * (rank + 1) / count);
+}
+
+int normalise_opts(const np_open_opts* in, np_open_opts* o) {
+  memset(o, 0, sizeof *o);
+  if (in) *o = *in;
+  if (o->shard_count <= 0) o->shard_count = 1;
+  if (o->shard_rank < 0 || o->shard_rank >= o->shard_count) {
+    set_error("Invalid configuration: shard_rank %d out of range for shard_count %d", o->shard_rank, o->shard_count);
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (o->n_contexts <= 0) o->n_contexts = 2;
+  if (o->n_contexts > 16) o->n_contexts = 16;
+  if (o->max_batch <= 0) o->max_batch = 64;
+  if (o->max_query_tokens <= 0) o->max_query_tokens = 64;
+  if (o->workspace_bytes <= 0) o->workspace_bytes = (int64_t)8 << 30;
+  return NP_OK;
+}
+
+static int check_device(int dev) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available");
+    return NP_ERR_DEVICE_UNAVAILABLE;
+  }
+  if (dev < 0 || dev >= n) {
+    set_error("device %d out of range (%d devices)", dev, n);
+    return NP_ERR_DEVICE_UNAVAILABLE;
+  }
+  return NP_OK;
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t n, size_t* acct) {
+  size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  hipError_t e = hipMalloc((void**)p, bytes);
+  if (e != hipSuccess) {
+    *p = nullptr;
+    set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return NP_ERR_OUT_OF_MEMORY;
+  }
+  if (acct) *acct += bytes;
+  return NP_OK;
+}
+
+void destroy_device_index(DeviceIndex* ix) {
+  if (!ix) return;
+  DeviceGuard g(ix->device);
+  for (Context* c : ix->contexts) destroy_context(c);
+  ix->contexts.clear();
+  (void)hipFree(ix->d_centroids);
+  (void)hipFree(ix->d_wlut);
+  (void)hipFree(ix->d_codes);
+  (void)hipFree(ix->d_residuals);
+  (void)hipFree(ix->d_doc_offsets);
+  (void)hipFree(ix->d_ivf);
+  (void)hipFree(ix->d_ivf_offsets);
+}
+
+static uint32_t bitrev(uint32_t v, int nbits) {
+  uint32_t r = 0;
+  for (int k = 0; k < nbits; ++k)
+    if (v & (1u << k)) r |= 1u << (nbits - 1 - k);
+  return r;
+}
+
+static int check_geometry(int64_t K, int dim, int nbits, int64_t n_total) {
+  if (nbits <= 0 || 8 % nbits != 0) {  // codec.rs:161-166
+    set_error("Codec error: nbits must be a divisor of 8, got %d", nbits);
+    return NP_ERR_CODEC;
+  }
+  if (K <= 0 || dim <= 0) {
+    set_error("Shape error: centroids must be [K > 0, dim > 0], got [%lld, %d]", (long long)K, dim);
+    return NP_ERR_SHAPE;
+  }
+  if ((dim * nbits) % 8 != 0) {
+    set_error("Shape error: dim*nbits must be a multiple of 8 (dim=%d nbits=%d)", dim, nbits);
+    return NP_ERR_SHAPE;
+  }
+  if (K >= ((int64_t)1 << 31) || n_total >= ((int64_t)1 << 32) - 1) {
+    set_error("Index load failed: K=%lld / N=%lld exceed the 32-bit device id space", (long long)K, (long long)n_total);
+    return NP_ERR_INDEX_LOAD;
+  }
+  return NP_OK;
+}
+
+static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bucket_weights) {
+  NP_TRY(dev_alloc(&ix->d_centroids, (size_t)ix->K * ix->dim, &ix->device_bytes));
+  NP_HIP(hipMemcpy(ix->d_centroids, centroids, (size_t)ix->K * ix->dim * sizeof(float), hipMemcpyHostToDevice));
+  const int nb = 1 << ix->nbits;
+  std::vector<float> wl(nb);
+  for (int s = 0; s < nb; ++s) wl[s] = bucket_weights[bitrev((uint32_t)s, ix->nbits)];
+  NP_TRY(dev_alloc(&ix->d_wlut, nb, &ix->device_bytes));
+  NP_HIP(hipMemcpy(ix->d_wlut, wl.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+  return NP_OK;
+}
+
+// ---- from host arrays / files ----------------------------------------------------------------------
+int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIndex** out) {
+  *out = nullptr;
+  np_open_opts o;
+  NP_TRY(normalise_opts(opts_in, &o));
+  NP_TRY(check_device(o.device));
+  NP_TRY(check_geometry(h.K, h.dim, h.nbits, h.num_documents_total));
+  int64_t sb, se;
+  shard_range(h.num_documents_total, o.shard_rank, o.shard_count, &sb, &se);
+  const int64_t hb = h.doc_begin, he = h.doc_begin + (int64_t)h.doc_lengths.size();
+  if (sb < hb || se > he) {
+    set_error("Index load failed: host arrays cover docs [%lld,%lld) but shard %d/%d needs [%lld,%lld)", (long long)hb,
+              (long long)he, o.shard_rank, o.shard_count, (long long)sb, (long long)se);
+    return NP_ERR_INDEX_LOAD;
+  }
+  DeviceGuard g(o.device);
+  if (!g.ok) {
+    set_error("hipSetDevice(%d) failed", o.device);
+    return NP_ERR_DEVICE_UNAVAILABLE;
+  }
+  np_index* nix = new np_index();
+  DeviceIndex* ix = nix;
+  struct Cleanup {
+    np_index* p;
+    ~Cleanup() {
+      if (p) {
+        destroy_device_index(p);
+        delete p;
+      }
+    }
+  } cleanup{nix};
+
+  ix->device = o.device;
+  ix->opts = o;
+  ix->N_total = h.num_documents_total;
+  ix->n_emb_total = h.num_embeddings_total;
+  ix->avg_doclen = h.avg_doclen;
+  ix->doc_begin = sb;
+  ix->n_docs = se - sb;
+  ix->K = h.K;
+  ix->KP = (h.K + 63) / 64 * 64;
+  ix->dim = h.dim;
+  ix->nbits = h.nbits;
+  ix->pd = h.dim * h.nbits / 8;
+  NP_TRY(upload_codec(ix, h.centroids, h.bucket_weights));
+
+  // doc offsets of the shard + its token range inside the host arrays
+  int64_t tb = 0;
+  for (int64_t d = hb; d < sb; ++d) tb += h.doc_lengths[d - hb];
+  std::vector<int64_t> off((size_t)ix->n_docs + 1);
+  off[0] = 0;
+  int64_t maxlen = 0;
+  for (int64_t d = 0; d < ix->n_docs; ++d) {
+    int64_t l = h.doc_lengths[sb - hb + d];
+    if (l < 0) {
+      set_error("Index load failed: negative doc length");
+      return NP_ERR_INDEX_LOAD;
+    }
+    maxlen = std::max(maxlen, l);
+    off[d + 1] = off[d] + l;
+  }
+  ix->T = off[ix->n_docs];
+  ix->max_doc_len = maxlen;
+  const int64_t te = tb + ix->T;
+  NP_TRY(dev_alloc(&ix->d_doc_offsets, off.size(), &ix->device_bytes));
+  NP_HIP(hipMemcpy(ix->d_doc_offsets, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+
+  // codes (i64 -> u32, range-checked) and residuals, chunk by chunk
+  NP_TRY(dev_alloc(&ix->d_codes, (size_t)ix->T, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_residuals, (size_t)ix->T * ix->pd, &ix->device_bytes));
+  {
+    const int64_t PIECE = (int64_t)8 << 20;
+    std::vector<uint32_t> tmp((size_t)std::min<int64_t>(PIECE, std::max<int64_t>(ix->T, 1)));
+    int64_t pos = 0;  // token position of the current chunk's first token in the host arrays
+    for (const HostChunk& c : h.chunks) {
+      int64_t a = std::max(pos, tb), b = std::min(pos + c.n_tokens, te);
+      for (int64_t s = a; s < b; s += PIECE) {
+        int64_t n = std::min(PIECE, b - s);
+        const char* src = (const char*)(c.codes) + (s - pos) * 8;
+        for (int64_t i = 0; i < n; ++i) {
+          int64_t v;
+          memcpy(&v, src + i * 8, 8);  // unaligned-safe, like mmap.rs:841-845
+          if (v < 0 || v >= ix->K) {
+            set_error("Index load failed: code %lld out of range [0,%lld)", (long long)v, (long long)ix->K);
+            return NP_ERR_INDEX_LOAD;
+          }
+          tmp[i] = (uint32_t)v;
+        }
+        NP_HIP(hipMemcpy(ix->d_codes + (s - tb), tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      }
+      if (b > a)
+        NP_HIP(hipMemcpy(ix->d_residuals + (a - tb) * ix->pd, c.residuals + (a - pos) * ix->pd,
+                         (size_t)(b - a) * ix->pd, hipMemcpyHostToDevice));
+      pos += c.n_tokens;
+    }
+    if (pos < te) {
+      set_error("Index load failed: chunks hold %lld tokens, doclens need %lld", (long long)pos, (long long)te);
+      return NP_ERR_INDEX_LOAD;
+    }
+  }
+
+  // IVF restricted to the shard, re-based to shard-local u32 ids
+  {
+    std::vector<int64_t> ioff((size_t)ix->K + 1, 0);
+    std::vector<uint32_t> ivf;
+    ivf.reserve((size_t)std::min<int64_t>(h.ivf_size, ix->T));
+    int64_t p = 0;
+    for (int64_t c = 0; c < ix->K; ++c) {
+      int64_t l = h.ivf_lengths[c];
+      if (l < 0 || p + l > h.ivf_size) {
+        set_error("Index load failed: ivf_lengths inconsistent with ivf.npy at centroid %lld", (long long)c);
+        return NP_ERR_INDEX_LOAD;
+      }
+      for (int64_t i = 0; i < l; ++i) {
+        int64_t id;
+        memcpy(&id, (const char*)h.ivf + (p + i) * 8, 8);
+        if (id < 0 || id >= h.num_documents_total) {
+          set_error("Index load failed: ivf doc id %lld out of range", (long long)id);
+          return NP_ERR_INDEX_LOAD;
+        }
+        if (id >= sb && id < se) ivf.push_back((uint32_t)(id - sb));
+      }
+      p += l;
+      ioff[c + 1] = (int64_t)ivf.size();
+    }
+    ix->ivf_size = (int64_t)ivf.size();
+    NP_TRY(dev_alloc(&ix->d_ivf, ivf.size(), &ix->device_bytes));
+    if (!ivf.empty()) NP_HIP(hipMemcpy(ix->d_ivf, ivf.data(), ivf.size() * 4, hipMemcpyHostToDevice));
+    NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
+    NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
+  }
+  cleanup.p = nullptr;
+  *out = ix;
+  return NP_OK;
+}
+
+// ---- synthetic corpus generated in HBM (spec: next_plaid_amd/synth.py) -----------------------------------
+__host__ __device__ static inline uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+enum { S_LEN = 1, S_TOPIC = 2, S_TOK = 3, S_RES = 4 };
+
+struct SynthP {
+  uint64_t b_len, b_topic, b_tok, b_res;
+  int64_t doc_begin, n_docs;
+  uint32_t K;
+  int32_t len_min, len_span, n_topics, rand256, pd, nw;
+};
+
+__global__ void synth_lens_kernel(SynthP p, int64_t* lens) {
+  int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= p.n_docs) return;
+  lens[d] = p.len_min + (int64_t)(mix64(p.b_len + (uint64_t)(p.doc_begin + d)) % (uint64_t)p.len_span);
+}
+
+// one wave per document
+__global__ void __launch_bounds__(256) synth_tokens_kernel(SynthP p, const int64_t* __restrict__ doc_off,
+                                                           uint32_t* __restrict__ codes, uint8_t* __restrict__ res,
+                                                           uint64_t* __restrict__ keys) {
+  const int lane = threadIdx.x & 63;
+  int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= p.n_docs) return;
+  const uint64_t gdoc = (uint64_t)(p.doc_begin + d);
+  const int64_t off = doc_off[d];
+  const int len = (int)(doc_off[d + 1] - off);
+  for (int t = lane; t < len; t += 64) {
+    uint64_t r = mix64(p.b_tok + (gdoc * 65536ull + (uint64_t)t));
+    uint32_t code;
+    if ((r & 0xFF) < (uint64_t)p.rand256) {
+      code = (uint32_t)(((r >> 8) & 0xFFFFFFFFull) % p.K);
+    } else {
+      uint64_t s = (r >> 40) % (uint64_t)p.n_topics;
+      uint64_t rt = mix64(p.b_topic + (gdoc * (uint64_t)p.n_topics + s));
+      code = (uint32_t)(((rt & 0xFFFFFFFFull) % p.K) >> ((rt >> 32) & 3));
+    }
+    codes[off + t] = code;
+    if (keys) keys[off + t] = ((uint64_t)code << 32) | (uint64_t)d;
+  }
+  const int nwords = len * p.nw;
+  for (int w = lane; w < nwords; w += 64) {
+    int t = w / p.nw, j = w - t * p.nw;
+    uint64_t v = mix64(p.b_res + ((gdoc * 65536ull + (uint64_t)t) * 16ull + (uint64_t)j));
+    uint8_t* dst = res + (off + t) * (int64_t)p.pd + j * 8;
+    int nb = min(8, p.pd - j * 8);
+    if (nb == 8 && (p.pd & 7) == 0) {
+      *(uint64_t*)dst = v;  // little endian
+    } else {
+      for (int b = 0; b < nb; ++b) dst[b] = (uint8_t)(v >> (8 * b));
+    }
+  }
+}
+
+__global__ void ivf_from_unique_kernel(const uint64_t* __restrict__ ukeys, int64_t n, uint32_t* __restrict__ ivf,
+                                       unsigned int* __restrict__ lens) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t k = ukeys[i];
+  ivf[i] = (uint32_t)(k & 0xFFFFFFFFull);
+  atomicAdd(&lens[(uint32_t)(k >> 32)], 1u);
+}
+
+static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, DeviceIndex** out) {
+  *out = nullptr;
+  np_open_opts o;
+  NP_TRY(normalise_opts(opts_in, &o));
+  NP_TRY(check_device(o.device));
+  if (!s || !s->centroids || !s->bucket_weights) {
+    set_error("Invalid configuration: synth spec needs centroids and bucket_weights");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  NP_TRY(check_geometry(s->num_centroids, s->dim, s->nbits, s->num_docs));
+  if (s->doc_len_min < 0 || s->doc_len_max < s->doc_len_min || s->doc_len_max > 65535 || s->n_topics <= 0 ||
+      s->dim * s->nbits / 8 > 128) {
+    set_error("Invalid configuration: synth doc_len/n_topics/packed width out of range");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g(o.device);
+  if (!g.ok) {
+    set_error("hipSetDevice(%d) failed", o.device);
+    return NP_ERR_DEVICE_UNAVAILABLE;
+  }
+  np_index* nix = new np_index();
+  DeviceIndex* ix = nix;
+  uint64_t* d_keys = nullptr;
+  uint64_t* d_keys2 = nullptr;
+  void* d_temp = nullptr;
+  int64_t* d_nsel = nullptr;
+  unsigned int* d_lens32 = nullptr;
+  struct Cleanup {
+    np_index* p;
+    uint64_t** a;
+    uint64_t** b;
+    void** c;
+    int64_t** d;
+    unsigned int** e;
+    ~Cleanup() {
+      (void)hipFree(*a);
+      (void)hipFree(*b);
+      (void)hipFree(*c);
+      (void)hipFree(*d);
+      (void)hipFree(*e);
+      if (p) {
+        destroy_device_index(p);
+        delete p;
+      }
+    }
+  } cleanup{nix, &d_keys, &d_keys2, &d_temp, &d_nsel, &d_lens32};
+
+  int64_t sb, se;
+  shard_range(s->num_docs, o.shard_rank, o.shard_count, &sb, &se);
+  ix->device = o.device;
+  ix->opts = o;
+  ix->N_total = s->num_docs;
+  ix->doc_begin = sb;
+  ix->n_docs = se - sb;
+  ix->K = s->num_centroids;
+  ix->KP = (ix->K + 63) / 64 * 64;
+  ix->dim = s->dim;
+  ix->nbits = s->nbits;
+  ix->pd = s->dim * s->nbits / 8;
+  ix->max_doc_len = s->doc_len_max;
+  NP_TRY(upload_codec(ix, s->centroids, s->bucket_weights));
+
+  SynthP p;
+  p.b_len = mix64(s->seed + S_LEN);
+  p.b_topic = mix64(s->seed + S_TOPIC);
+  p.b_tok = mix64(s->seed + S_TOK);
+  p.b_res = mix64(s->seed + S_RES);
+  p.doc_begin = sb;
+  p.n_docs = ix->n_docs;
+  p.K = (uint32_t)ix->K;
+  p.len_min = s->doc_len_min;
+  p.len_span = s->doc_len_max - s->doc_len_min + 1;
+  p.n_topics = s->n_topics;
+  p.rand256 = s->rand256;
+  p.pd = ix->pd;
+  p.nw = (ix->pd + 7) / 8;
+
+  // doc lengths -> offsets (inclusive scan shifted by one)
+  NP_TRY(dev_alloc(&ix->d_doc_offsets, (size_t)ix->n_docs + 1, &ix->device_bytes));
+  NP_HIP(hipMemset(ix->d_doc_offsets, 0, sizeof(int64_t)));
+  if (ix->n_docs > 0) {
+    int64_t* d_lens = nullptr;
+    NP_TRY(dev_alloc(&d_lens, (size_t)ix->n_docs, nullptr));
+    synth_lens_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(p, d_lens);
+    size_t tb = 0;
+    hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_lens, ix->d_doc_offsets + 1, (int)ix->n_docs);
+    hipError_t e = hipMalloc(&d_temp, std::max<size_t>(tb, 16));
+    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_lens, ix->d_doc_offsets + 1, (int)ix->n_docs);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_lens);
+    (void)hipFree(d_temp);
+    d_temp = nullptr;
+    if (e != hipSuccess) {
+      set_error("synth: doc offset scan failed: %s", hipGetErrorString(e));
+      return NP_ERR_DEVICE_UNAVAILABLE;
+    }
+  }
+  NP_HIP(hipMemcpy(&ix->T, ix->d_doc_offsets + ix->n_docs, sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (ix->T >= ((int64_t)1 << 31)) {
+    set_error("synth: shard holds %lld tokens; the in-HBM IVF build handles < 2^31 per shard (use more shards)",
+              (long long)ix->T);
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  ix->n_emb_total = 0;  // filled below for unsharded corpora; sharded: avg-based estimate
+  NP_TRY(dev_alloc(&ix->d_codes, (size_t)ix->T, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_residuals, (size_t)ix->T * ix->pd, &ix->device_bytes));
+  NP_TRY(dev_alloc(&d_keys, (size_t)ix->T, nullptr));
+  if (ix->n_docs > 0)
+    synth_tokens_kernel<<<(unsigned)((ix->n_docs + 3) / 4), 256>>>(p, ix->d_doc_offsets, ix->d_codes, ix->d_residuals,
+                                                                   d_keys);
+  NP_HIP(hipGetLastError());
+
+  // IVF: sort (code, doc) pairs, unique, split (index.rs:479-499)
+  NP_TRY(dev_alloc(&d_keys2, (size_t)ix->T, nullptr));
+  NP_TRY(dev_alloc(&d_nsel, 1, nullptr));
+  NP_TRY(dev_alloc(&d_lens32, (size_t)ix->K, nullptr));
+  NP_HIP(hipMemset(d_lens32, 0, (size_t)ix->K * 4));
+  NP_HIP(hipMemset(d_nsel, 0, 8));
+  int64_t n_unique = 0;
+  if (ix->T > 0) {
+    int kbits = 1;
+    while (((int64_t)1 << kbits) < ix->K) ++kbits;
+    size_t tb1 = 0, tb2 = 0;
+    hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, d_keys, d_keys2, (int)ix->T, 0, 32 + kbits);
+    hipcub::DeviceSelect::Unique(nullptr, tb2, d_keys2, d_keys, d_nsel, (int)ix->T);
+    size_t tb = std::max(tb1, tb2);
+    NP_HIP(hipMalloc(&d_temp, std::max<size_t>(tb, 16)));
+    NP_HIP(hipcub::DeviceRadixSort::SortKeys(d_temp, tb1, d_keys, d_keys2, (int)ix->T, 0, 32 + kbits));
+    NP_HIP(hipcub::DeviceSelect::Unique(d_temp, tb2, d_keys2, d_keys, d_nsel, (int)ix->T));
+    NP_HIP(hipDeviceSynchronize());
+    // d_nsel was declared int64 for alignment; hipcub wrote a 64-bit? it writes NumSelectedT = *d_nsel type
+    NP_HIP(hipMemcpy(&n_unique, d_nsel, sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
+  ix->ivf_size = n_unique;
+  NP_TRY(dev_alloc(&ix->d_ivf, (size_t)n_unique, &ix->device_bytes));
+  if (n_unique > 0)
+    ivf_from_unique_kernel<<<(unsigned)((n_unique + 255) / 256), 256>>>(d_keys, n_unique, ix->d_ivf, d_lens32);
+  std::vector<unsigned int> lens((size_t)ix->K);
+  NP_HIP(hipMemcpy(lens.data(), d_lens32, (size_t)ix->K * 4, hipMemcpyDeviceToHost));
+  std::vector<int64_t> ioff((size_t)ix->K + 1, 0);
+  for (int64_t c = 0; c < ix->K; ++c) ioff[c + 1] = ioff[c] + lens[c];
+  NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
+  NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
+  NP_HIP(hipDeviceSynchronize());
+
+  // whole-corpus token count: exact when unsharded or fixed-length, else extrapolated
+  if (o.shard_count == 1 || s->doc_len_min == s->doc_len_max)
+    ix->n_emb_total = (s->doc_len_min == s->doc_len_max) ? s->num_docs * (int64_t)s->doc_len_min : ix->T;
+  else
+    ix->n_emb_total = ix->n_docs > 0 ? (int64_t)((double)ix->T / (double)ix->n_docs * (double)s->num_docs) : 0;
+  ix->avg_doclen = s->num_docs > 0 ? (double)ix->n_emb_total / (double)s->num_docs : 0.0;
+  cleanup.p = nullptr;
+  *out = ix;
+  return NP_OK;
+}
+
+}  // namespace np
+
+using namespace np;
+
+// =================================== C ABI ====================================================
+extern "C" {
+
+int np_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int usable = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
+  }
+  return usable;
+}
+
+const char* np_hip_last_error(void) { return np::last_error(); }
+
+int np_hip_index_open(const char* index_dir, const np_open_opts* opts, np_index** out) {
+  clear_error();
+  if (!out) {
+    set_error("np_hip_index_open: out is NULL");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
+  HostIndex h;
+  NP_TRY(load_index_dir(index_dir, &h));
+  DeviceIndex* ix = nullptr;
+  NP_TRY(build_device_index(h, opts, &ix));
+  *out = static_cast<np_index*>(ix);
+  return NP_OK;
+}
+
+int np_hip_index_from_arrays(const np_index_arrays* a, const np_open_opts* opts, np_index** out) {
+  clear_error();
+  if (!out || !a) {
+    set_error("np_hip_index_from_arrays: NULL argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
+  if (!a->centroids || !a->ivf_lengths || (a->num_docs > 0 && !a->doc_lengths)) {
+    set_error("np_hip_index_from_arrays: centroids / ivf_lengths / doc_lengths are required");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (!a->bucket_weights) {  // codec.rs:428-431
+    set_error("Codec error: bucket_weights required for decompression");
+    return NP_ERR_CODEC;
+  }
+  HostIndex h;
+  h.num_documents_total = a->num_documents_total;
+  h.doc_begin = a->doc_begin;
+  h.K = a->num_centroids;
+  h.dim = a->dim;
+  h.nbits = a->nbits;
+  h.centroids = a->centroids;
+  h.bucket_weights = a->bucket_weights;
+  h.ivf = a->ivf;
+  h.ivf_lengths = a->ivf_lengths;
+  h.ivf_size = 0;
+  for (int64_t c = 0; c < a->num_centroids; ++c) h.ivf_size += a->ivf_lengths[c];
+  h.doc_lengths.assign(a->doc_lengths, a->doc_lengths + a->num_docs);
+  HostChunk c;
+  c.codes = a->codes;
+  c.residuals = a->residuals;
+  c.n_tokens = 0;
+  for (int64_t d = 0; d < a->num_docs; ++d) c.n_tokens += a->doc_lengths[d];
+  if (c.n_tokens > 0 && (!a->codes || !a->residuals)) {
+    set_error("np_hip_index_from_arrays: codes / residuals are required");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  h.chunks.push_back(c);
+  h.num_embeddings_total = c.n_tokens;
+  h.avg_doclen = a->num_docs > 0 ? (double)c.n_tokens / (double)a->num_docs : 0.0;
+  DeviceIndex* ix = nullptr;
+  NP_TRY(build_device_index(h, opts, &ix));
+  *out = static_cast<np_index*>(ix);
+  return NP_OK;
+}
+
+int np_hip_index_synth(const np_synth_spec* spec, const np_open_opts* opts, np_index** out) {
+  clear_error();
+  if (!out) {
+    set_error("np_hip_index_synth: out is NULL");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceIndex* ix = nullptr;
+  NP_TRY(synth_build(spec, opts, &ix));
+  *out = static_cast<np_index*>(ix);
+  return NP_OK;
+}
+
+int64_t np_hip_index_ivf_size(const np_index* index) { return index ? index->ivf_size : 0; }
+
+int np_hip_index_export(const np_index* ix, int64_t* doc_lengths, int64_t* codes, uint8_t* residuals, int64_t* ivf,
+                        int32_t* ivf_lengths) {
+  clear_error();
+  if (!ix) {
+    set_error("np_hip_index_export: NULL index");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g(ix->device);
+  if (doc_lengths) {
+    std::vector<int64_t> off((size_t)ix->n_docs + 1);
+    NP_HIP(hipMemcpy(off.data(), ix->d_doc_offsets, off.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t d = 0; d < ix->n_docs; ++d) doc_lengths[d] = off[d + 1] - off[d];
+  }
+  if (codes && ix->T > 0) {
+    const int64_t PIECE = (int64_t)8 << 20;
+    std::vector<uint32_t> tmp((size_t)std::min(PIECE, ix->T));
+    for (int64_t s = 0; s < ix->T; s += PIECE) {
+      int64_t n = std::min(PIECE, ix->T - s);
+      NP_HIP(hipMemcpy(tmp.data(), ix->d_codes + s, (size_t)n * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < n; ++i) codes[s + i] = (int64_t)tmp[i];
+    }
+  }
+  if (residuals && ix->T > 0)
+    NP_HIP(hipMemcpy(residuals, ix->d_residuals, (size_t)ix->T * ix->pd, hipMemcpyDeviceToHost));
+  if (ivf && ix->ivf_size > 0) {
+    std::vector<uint32_t> tmp((size_t)ix->ivf_size);
+    NP_HIP(hipMemcpy(tmp.data(), ix->d_ivf, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < ix->ivf_size; ++i) ivf[i] = (int64_t)tmp[i] + ix->doc_begin;
+  }
+  if (ivf_lengths) {
+    std::vector<int64_t> off((size_t)ix->K + 1);
+    NP_HIP(hipMemcpy(off.data(), ix->d_ivf_offsets, off.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < ix->K; ++c) ivf_lengths[c] = (int32_t)(off[c + 1] - off[c]);
+  }
+  return NP_OK;
+}
+
+void np_hip_index_close(np_index* index) {
+  if (!index) return;
+  destroy_device_index(index);
+  delete index;
+}
+
+int np_hip_index_info(const np_index* ix, np_info* out) {
+  clear_error();
+  if (!ix || !out) {
+    set_error("np_hip_index_info: NULL argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  memset(out, 0, sizeof *out);
+  out->num_documents = ix->N_total;
+  out->num_embeddings = ix->n_emb_total;
+  out->num_partitions = ix->K;
+  out->embedding_dim = ix->dim;
+  out->nbits = ix->nbits;
+  out->avg_doclen = ix->avg_doclen;
+  out->shard_doc_begin = ix->doc_begin;
+  out->shard_doc_end = ix->doc_begin + ix->n_docs;
+  out->shard_embeddings = ix->T;
+  out->device_bytes = (int64_t)ix->device_bytes;
+  out->device = ix->device;
+  out->abi_version = NP_ABI_VERSION;
+  return NP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// np_internal.h -- shared declarations of libnextplaid_hip.so (not part of the C ABI).
+//
+// Data layout in HBM.  One np_index = one document shard:
+//   centroids   f32 [K][dim]            replicated on every shard   (centroids.npy)
+//   wlut        f32 [2^nbits]           permuted bucket weights: wlut[s] = bucket_weights[bitrev_nbits(s)]
+//                                       (folds codec.rs:168-214's two LUTs into one)
+//   codes       u32 [T]                 centroid id per token       (N.codes.npy, i64 on disk)
+//   residuals   u8  [T][pd]             packed buckets, unchanged   (N.residuals.npy)
+//   doc_offsets i64 [n_docs+1]          prefix sum of doclens       (index.rs:1106-1110)
+//   ivf         u32 [ivf_size]          shard-local doc ids         (ivf.npy re-based)
+//   ivf_offsets i64 [K+1]                                           (index.rs:1089-1094)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <mutex>
+#include <condition_variable>
+#include <string>
+#include <vector>
+#include "../../include/nextplaid_hip.h"
+
+namespace np {
+
+// ---- errors --------------------------------------------------------------------------------
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* last_error();
+void clear_error();
+
+struct Status {
+  int code;
+  Status(int c = NP_OK) : code(c) {}
+  bool ok() const { return code == NP_OK; }
+};
+
+#define NP_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      np::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return (e__ == hipErrorOutOfMemory) ? NP_ERR_OUT_OF_MEMORY : NP_ERR_DEVICE_UNAVAILABLE; \
+    }                                                                                        \
+  } while (0)
+
+#define NP_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != NP_OK) return rc__; \
+  } while (0)
+
+// ---- host view of an index (on-disk dtypes), produced by the loader or handed in by the caller
+struct HostChunk {
+  const int64_t* codes = nullptr;     // [n_tokens]
+  const uint8_t* residuals = nullptr; // [n_tokens][pd]
+  int64_t n_tokens = 0;
+};
+
+struct HostIndex {
+  int64_t num_documents_total = 0, num_embeddings_total = 0;
+  double avg_doclen = 0.0;
+  int64_t doc_begin = 0;               // global id of doc_lengths[0]
+  int64_t K = 0;
+  int32_t dim = 0, nbits = 0;
+  const float* centroids = nullptr;
+  const float* bucket_weights = nullptr;
+  const int64_t* ivf = nullptr;        // global doc ids
+  int64_t ivf_size = 0;
+  const int32_t* ivf_lengths = nullptr;
+  std::vector<int64_t> doc_lengths;    // docs [doc_begin, doc_begin + size)
+  std::vector<HostChunk> chunks;       // token data of those docs, in order
+  // keeps mmaps / owned buffers alive
+  std::vector<std::pair<void*, size_t>> maps;
+  std::vector<std::vector<char>> owned;
+  ~HostIndex();
+};
+
+// np_loader.cpp: MmapIndex::load's file parsing (index.rs:1026-1139, mmap.rs:659-749)
+int load_index_dir(const char* dir, HostIndex* out);
+
+// ---- device buffers ------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);  // grows (never shrinks); contents are NOT preserved
+  void release();
+  template <class T> T* as() const { return (T*)p; }
+};
+
+struct Workspace;  // np_search.hip
+
+struct Context {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[10] = {};
+  Workspace* ws = nullptr;
+  bool busy = false;
+};
+
+struct DeviceIndex {
+  int device = 0;
+  int64_t N_total = 0, n_emb_total = 0;
+  double avg_doclen = 0.0;
+  int64_t doc_begin = 0, n_docs = 0;
+  int64_t K = 0, KP = 0;  // KP = K rounded up to 64
+  int32_t dim = 0, nbits = 0, pd = 0;
+  int64_t T = 0;
+  int64_t max_doc_len = 0;
+  float* d_centroids = nullptr;
+  float* d_wlut = nullptr;
+  uint32_t* d_codes = nullptr;
+  uint8_t* d_residuals = nullptr;
+  int64_t* d_doc_offsets = nullptr;
+  uint32_t* d_ivf = nullptr;
+  int64_t* d_ivf_offsets = nullptr;
+  int64_t ivf_size = 0;
+  size_t device_bytes = 0;
+  np_open_opts opts{};
+  // context pool
+  mutable std::mutex mu;
+  mutable std::condition_variable cv;
+  mutable std::vector<Context*> contexts;
+};
+
+// np_index.hip
+int build_device_index(const HostIndex& h, const np_open_opts* opts, DeviceIndex** out);
+void destroy_device_index(DeviceIndex* ix);
+int normalise_opts(const np_open_opts* in, np_open_opts* out);
+void shard_range(int64_t n_total, int rank, int count, int64_t* b, int64_t* e);
+
+// np_search.hip
+void destroy_context(Context* c);
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace np
+
+struct np_index : np::DeviceIndex {};

@@ -1,0 +1,1080 @@
+// np_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the PLAID search path.
+//
+// Stage map (reference: next-plaid/src/search.rs:327-516, codec.rs:423-470, maxsim.rs:270-294):
+//   prep_queries_kernel   pads/transposes the query batch                      (host glue)
+//   qc_gemm_kernel        S1  Q.C^T on exact-f32 MFMA 32x32x2, k-ordered FMA chain == search.rs:345;
+//                             writes QCT[b][c][q] (one 128-B line per centroid) + per-32-centroid maxima
+//   probe_kernel          S2  per-token top-nprobe (radix select on group maxima, then on the
+//                             surviving groups) + threshold (search.rs:388-425)
+//   mark/count/compact    S3  posting-list union as a per-query doc bitmap -> ascending unique ids
+//                             (index.rs:1142-1156: concat + sort_unstable + dedup)
+//   approx_kernel         S4  sum_q max_tok QC[q, code[tok]]   (search.rs:305-324)
+//   select_kernel         S5  stable top n_sel by approximate score (search.rs:460-469)
+//   exact_f32/bf16_kernel S6  residual unpack + centroid add + L2 normalise straight into MFMA A
+//                             fragments, Q.D^T on MFMA, row-max / sum (codec.rs:423-470, maxsim.rs:270-294)
+//   topk_kernel           S7  stable top-k by exact score (search.rs:496-515)
+//   select_cut / merge    document-sharded exchange (new)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace np {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define NP_NEG_INF (-__builtin_huge_valf())
+
+// Orderable key of search.rs:110-117's comparator: finite values keep f32::total_cmp order in
+// [0x00800000, 0xFF7FFFFF]; every non-finite value maps to 0 (all Equal, below any finite).
+__device__ __forceinline__ uint32_t okey(float x) {
+  uint32_t b = __float_as_uint(x);
+  uint32_t k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((b & 0x7F800000u) == 0x7F800000u) ? 0u : k;
+}
+__device__ __forceinline__ float unkey(uint32_t k) {  // inverse for k != 0
+  uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+  return __uint_as_float(b);
+}
+__device__ __forceinline__ bool finitef(float x) { return (__float_as_uint(x) & 0x7F800000u) != 0x7F800000u; }
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int mfma_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
+
+struct Counters {  // per-call work counters (np_stats)
+  unsigned long long n_cells, n_ivf_ids, n_candidates, n_cand_tokens, n_exact_docs, n_exact_tokens;
+};
+
+// ---------------------------------------------------------------------------------------------
+// prep: Qt[b][k][q] f32 (k-major, zero padded to LQP) and Qb[b][q][k] bf16
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restrict__ q, const int32_t* __restrict__ qoff,
+                                                           int dim, int LQP, float* __restrict__ Qt,
+                                                           __bf16* __restrict__ Qb) {
+  const int b = blockIdx.x;
+  const int t0 = qoff[b], Lq = qoff[b + 1] - t0;
+  const int n = dim * LQP;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    {  // k-major write, coalesced over q
+      int k = i / LQP, qq = i - k * LQP;
+      float v = (qq < Lq) ? q[(int64_t)(t0 + qq) * dim + k] : 0.0f;
+      Qt[(int64_t)b * n + i] = v;
+    }
+    {  // row-major bf16
+      int qq = i / dim, k = i - qq * dim;
+      float v = (qq < Lq) ? q[(int64_t)(t0 + qq) * dim + k] : 0.0f;
+      Qb[(int64_t)b * n + i] = (__bf16)v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S1  Q.C^T  (exact f32 MFMA).  One wave = 64 centroids (two 32-row A fragments held in
+// registers for the whole kernel) x every 32-token query tile of the batch.
+// D[c][q]: lane holds q = lane&31 and centroid rows mfma_row(r, lane>>5).
+// The k loop feeds k = 2s + (lane>>5) in ascending s, so each output is the k-ordered FMA chain.
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
+                                                      const float* __restrict__ Qt, int B, int LQP,
+                                                      float* __restrict__ QCT, uint32_t* __restrict__ gmax) {
+  const int lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
+  const int64_t c0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (c0 >= KP) return;
+  float a0[DIM / 2], a1[DIM / 2];
+  {
+    const int64_t r0 = c0 + li, r1 = c0 + 32 + li;
+#pragma unroll
+    for (int m = 0; m < DIM / 4; ++m) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (r0 < K) v0 = *reinterpret_cast<const float4*>(C + r0 * DIM + 4 * m);
+      if (r1 < K) v1 = *reinterpret_cast<const float4*>(C + r1 * DIM + 4 * m);
+      a0[2 * m] = kk ? v0.y : v0.x;
+      a0[2 * m + 1] = kk ? v0.w : v0.z;
+      a1[2 * m] = kk ? v1.y : v1.x;
+      a1[2 * m + 1] = kk ? v1.w : v1.z;
+    }
+  }
+  const int nqt = LQP >> 5;
+  const int ntiles = B * nqt;
+  const int64_t G = KP >> 5;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int b = tile / nqt, qt = tile - b * nqt;
+    const float* qb = Qt + (int64_t)b * DIM * LQP + qt * 32 + li + (int64_t)kk * LQP;  // [2s+kk][q]
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < DIM / 2; ++s) {  // fully unrolled: a0/a1 must stay in registers
+      const float bq = qb[(int64_t)(2 * s) * LQP];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bq, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bq, acc1, 0, 0, 0);
+    }
+    float* out = QCT + ((int64_t)b * KP + c0) * LQP + qt * 32 + li;
+    uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mfma_row(r, kk);
+      out[(int64_t)row * LQP] = acc0[r];
+      out[(int64_t)(row + 32) * LQP] = acc1[r];
+      const uint32_t e0 = (c0 + row < K) ? okey(acc0[r]) : 0u;
+      const uint32_t e1 = (c0 + 32 + row < K) ? okey(acc1[r]) : 0u;
+      k0 = max(k0, e0);
+      k1 = max(k1, e1);
+    }
+    k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
+    k1 = max(k1, (uint32_t)__shfl_xor((int)k1, 32));
+    if (kk == 0) {
+      uint32_t* g = gmax + ((int64_t)b * G + (c0 >> 5)) * LQP + qt * 32 + li;
+      g[0] = k0;
+      g[LQP] = k1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S2 helpers: block-level radix select for 32 query tokens at once.
+// Thread (r = tid>>5, q = tid&31); `enumerate(cb)` calls cb(key) for this thread's items of
+// token q.  On return s_prefix[q] = key of the want-th largest item, s_rem[q] = how many items
+// equal to that key belong to the top `want`.
+// ---------------------------------------------------------------------------------------------
+template <class Enum>
+__device__ __forceinline__ void radix_select32(Enum&& enumerate, uint32_t want, uint32_t* hist /*[256*32]*/,
+                                               uint32_t* part /*[8*32]*/, uint32_t* s_prefix, uint32_t* s_rem,
+                                               int tid) {
+  const int q = tid & 31, r = tid >> 5;
+  if (r == 0) {
+    s_prefix[q] = 0;
+    s_rem[q] = want;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int i = tid; i < 256 * 32; i += 256) hist[i] = 0;
+    __syncthreads();
+    const uint32_t pre = s_prefix[q];
+    enumerate([&](uint32_t key) {
+      if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&hist[((key >> shift) & 255u) * 32 + q], 1u);
+    });
+    __syncthreads();
+    uint32_t s = 0;
+    for (int i = 0; i < 32; ++i) s += hist[(r * 32 + i) * 32 + q];
+    part[r * 32 + q] = s;
+    __syncthreads();
+    if (r == 0) {
+      const uint32_t rem = s_rem[q];
+      uint32_t cum = 0;
+      int R = 7;
+      for (; R > 0; --R) {
+        const uint32_t pr = part[R * 32 + q];
+        if (cum + pr >= rem) break;
+        cum += pr;
+      }
+      int bin = R * 32 + 31;
+      for (; bin > R * 32; --bin) {
+        const uint32_t h = hist[bin * 32 + q];
+        if (cum + h >= rem) break;
+        cum += h;
+      }
+      s_prefix[q] = (pre << 8) | (uint32_t)bin;
+      s_rem[q] = rem - cum;
+    }
+    __syncthreads();
+  }
+}
+
+struct ProbeP {
+  const float* QCT;        // [B][KP][LQP]
+  const uint32_t* gmax;    // [B][KP/32][LQP]
+  const int32_t* qoff;     // [B+1]
+  int64_t K, KP;
+  int LQP;
+  int nprobe;              // params.n_ivf_probe
+  const int32_t* nprobe_dev;   // effective nprobe with a subset (search.rs:370-382), else NULL
+  const uint32_t* elig;    // eligible-centroid bitmap [KP/32] (search.rs:350-364), else NULL
+  const int32_t* n_elig;   // popcount of elig, else NULL
+  int has_thr;
+  float thr;
+  uint32_t* cellbits;      // [B][KP/32] zeroed
+  uint32_t* cells_tmp;     // [B][KP]
+  uint32_t* cells;         // [B][KP]
+  int32_t* n_cells;        // [B]
+  Counters* ctr;
+};
+
+__global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
+  __shared__ uint32_t hist[256 * 32];
+  __shared__ uint32_t part[8 * 32];
+  __shared__ uint32_t s_prefix[32], s_rem[32], s_taug[32], s_tie[32];
+  __shared__ uint32_t s_ntmp, s_nfinal;
+  const int b = blockIdx.x, tid = threadIdx.x, q = tid & 31, r = tid >> 5;
+  const int Lq = p.qoff[b + 1] - p.qoff[b];
+  const int64_t G = p.KP >> 5;
+  const int LQP = p.LQP;
+  const float* QCT = p.QCT + (int64_t)b * p.KP * LQP;
+  const uint32_t* gm = p.gmax + (int64_t)b * G * LQP;
+  uint32_t* bits = p.cellbits + (int64_t)b * G;
+  const int64_t pool = p.elig ? (int64_t)*p.n_elig : p.K;
+  int64_t eff = p.nprobe_dev ? (int64_t)*p.nprobe_dev : (int64_t)p.nprobe;
+  const uint32_t n_probe = (uint32_t)min(eff, pool);  // search.rs:405
+  const bool take_all = pool <= (int64_t)n_probe;
+  if (tid == 0) { s_ntmp = 0; s_nfinal = 0; }
+
+  for (int qc = 0; qc < (LQP >> 5); ++qc) {
+    const int qq = qc * 32 + q;
+    const bool qvalid = qq < Lq;
+    if (n_probe == 0) break;
+    if (take_all) {
+      // every pooled centroid is selected by every token (search.rs:406: len <= n_probe)
+      if (qc == 0)
+        for (int64_t w = tid; w < G; w += 256) {
+          uint32_t m = p.elig ? p.elig[w] : 0xFFFFFFFFu;
+          int64_t c0 = w * 32;
+          if (c0 + 32 > p.K) m &= (c0 >= p.K) ? 0u : ((1u << (p.K - c0)) - 1u);
+          if (m && Lq > 0) atomicOr(&bits[w], m);
+        }
+      continue;
+    }
+    // ---- phase 1: tau_g[q] = n_probe-th largest group maximum (no eligibility mask only)
+    const bool use_groups = (p.elig == nullptr) && (G > (int64_t)n_probe);
+    if (use_groups) {
+      radix_select32(
+          [&](auto&& cb) {
+            if (qvalid)
+              for (int64_t g = r; g < G; g += 8) cb(gm[g * LQP + qq]);
+          },
+          n_probe, hist, part, s_prefix, s_rem, tid);
+      if (r == 0) s_taug[q] = s_prefix[q];
+    } else if (r == 0) {
+      s_taug[q] = 0;
+    }
+    __syncthreads();
+    const uint32_t taug = s_taug[q];
+    // ---- phase 2: tau[q] = n_probe-th largest element inside the surviving groups
+    auto for_elems = [&](auto&& cb) {
+      if (!qvalid) return;
+      for (int64_t g = r; g < G; g += 8) {
+        if (gm[g * LQP + qq] < taug) continue;
+        const uint32_t em = p.elig ? p.elig[g] : 0xFFFFFFFFu;
+        if (!em) continue;
+        const float* row = QCT + (g * 32) * LQP + qq;
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+          const int64_t c = g * 32 + i;
+          if (c < p.K && ((em >> i) & 1u)) cb(okey(row[(int64_t)i * LQP]), c);
+        }
+      }
+    };
+    radix_select32([&](auto&& cb) { for_elems([&](uint32_t key, int64_t) { cb(key); }); }, n_probe, hist, part,
+                   s_prefix, s_rem, tid);
+    if (r == 0) s_tie[q] = 0;
+    __syncthreads();
+    // ---- phase 3: mark the selected cells (ties at the cut: unspecified in the reference)
+    {
+      const uint32_t tau = s_prefix[q], rem = s_rem[q];
+      for_elems([&](uint32_t key, int64_t c) {
+        bool take = key > tau;
+        if (!take && key == tau) take = atomicAdd(&s_tie[q], 1u) < rem;
+        if (take) atomicOr(&bits[c >> 5], 1u << (c & 31));
+      });
+    }
+    __syncthreads();
+  }
+  __threadfence();
+  __syncthreads();
+  // ---- compact the marked cells
+  uint32_t* tmp = p.cells_tmp + (int64_t)b * p.KP;
+  for (int64_t w = tid; w < G; w += 256) {
+    uint32_t m = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      tmp[atomicAdd(&s_ntmp, 1u)] = (uint32_t)(w * 32 + bit);
+    }
+  }
+  __syncthreads();
+  // ---- threshold (search.rs:417-425): keep c iff finite-first max_q QC[q,c] >= t_cs.
+  // max_by keeps the LAST of equal maxima, so an all-non-finite column yields QC[Lq-1, c].
+  const uint32_t ntmp = s_ntmp;
+  uint32_t* outc = p.cells + (int64_t)b * p.KP;
+  const int wave = tid >> 6, lane = tid & 63;
+  for (uint32_t i = wave; i < ntmp; i += 4) {
+    const uint32_t c = tmp[i];
+    bool pass = true;
+    if (p.has_thr) {
+      const float* row = QCT + (int64_t)c * LQP;
+      uint32_t km = 0;
+      for (int q0 = 0; q0 < Lq; q0 += 64) {
+        const int qx = q0 + lane;
+        const uint32_t k = (qx < Lq) ? okey(row[qx]) : 0u;
+        km = max(km, k);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, o));
+      float mx;
+      if (km != 0) mx = unkey(km);
+      else mx = (Lq > 0) ? row[Lq - 1] : NP_NEG_INF;
+      pass = mx >= p.thr;
+    }
+    if (pass && lane == 0) outc[atomicAdd(&s_nfinal, 1u)] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    p.n_cells[b] = (int32_t)s_nfinal;
+    atomicAdd(&p.ctr->n_cells, (unsigned long long)s_nfinal);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// subset pre-filter (search.rs:350-382, 434-437)
+// ---------------------------------------------------------------------------------------------
+// one wave per subset doc: doc bitmap (shard-local) + eligible-centroid bitmap
+__global__ void __launch_bounds__(256) subset_kernel(const int64_t* __restrict__ subset, int64_t n, int64_t doc_begin,
+                                                     int64_t n_docs, const int64_t* __restrict__ doc_off,
+                                                     const uint32_t* __restrict__ codes, uint32_t* __restrict__ docbits,
+                                                     uint32_t* __restrict__ elig) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const int64_t d = subset[i] - doc_begin;
+  if (d < 0 || d >= n_docs) return;
+  if (lane == 0) atomicOr(&docbits[d >> 5], 1u << (d & 31));
+  if (elig) {
+    const int64_t s = doc_off[d], e = doc_off[d + 1];
+    for (int64_t t = s + lane; t < e; t += 64) {
+      const uint32_t c = codes[t];
+      atomicOr(&elig[c >> 5], 1u << (c & 31));
+    }
+  }
+}
+
+// n_elig + effective nprobe = clamp(nprobe * N / |subset|, nprobe, n_elig)  (search.rs:370-382)
+__global__ void __launch_bounds__(256) subset_nprobe_kernel(const uint32_t* __restrict__ elig, int64_t words,
+                                                            int nprobe, int64_t n_total, int64_t subset_len,
+                                                            int32_t* __restrict__ n_elig, int32_t* __restrict__ eff) {
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int64_t w = threadIdx.x; w < words; w += 256) c += __popc(elig[w]);
+  atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ne = s_cnt;
+    *n_elig = ne;
+    long long e = nprobe;
+    if (ne > 0) {
+      unsigned long long scaled =
+          subset_len > 0 ? (unsigned long long)nprobe * (unsigned long long)n_total / (unsigned long long)subset_len
+                         : (unsigned long long)nprobe;
+      long long sc = scaled > 0x7FFFFFFFull ? 0x7FFFFFFFll : (long long)scaled;
+      if (sc < nprobe) sc = nprobe;
+      if (sc > ne) sc = ne;
+      e = sc;
+    }
+    *eff = (int32_t)e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S3  candidates: union of the probed posting lists as a per-query bitmap over shard docs
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mark_candidates_kernel(const uint32_t* __restrict__ cells,
+                                                              const int32_t* __restrict__ n_cells, int64_t KP,
+                                                              const int64_t* __restrict__ ivf_off,
+                                                              const uint32_t* __restrict__ ivf,
+                                                              const uint32_t* __restrict__ subset_bits, int64_t NW,
+                                                              uint32_t* __restrict__ docbits, Counters* ctr) {
+  const int b = blockIdx.y;
+  const int nc = n_cells[b];
+  uint32_t* bits = docbits + (int64_t)b * NW;
+  unsigned long long ids = 0;
+  for (int i = blockIdx.x; i < nc; i += gridDim.x) {
+    const uint32_t c = cells[(int64_t)b * KP + i];
+    const int64_t s = ivf_off[c], e = ivf_off[c + 1];
+    if (threadIdx.x == 0) ids += (unsigned long long)(e - s);
+    for (int64_t j = s + threadIdx.x; j < e; j += 256) {
+      const uint32_t d = ivf[j];
+      const uint32_t m = 1u << (d & 31);
+      if (subset_bits && !(subset_bits[d >> 5] & m)) continue;   // search.rs:434-437
+      if (!(bits[d >> 5] & m)) atomicOr(&bits[d >> 5], m);      // stale read only costs an extra atomic
+    }
+  }
+  if (threadIdx.x == 0 && ids) atomicAdd(&ctr->n_ivf_ids, ids);
+}
+
+#define NP_CHUNK_WORDS 1024  // bitmap words per compaction block (32768 docs)
+
+__global__ void __launch_bounds__(256) count_chunks_kernel(const uint32_t* __restrict__ docbits, int64_t NW,
+                                                           int nchunks, int32_t* __restrict__ chunk_counts) {
+  __shared__ int s_cnt;
+  const int b = blockIdx.y, ch = blockIdx.x;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const uint32_t* bits = docbits + (int64_t)b * NW;
+  int c = 0;
+  for (int k = 0; k < NP_CHUNK_WORDS / 256; ++k) {
+    const int64_t w = (int64_t)ch * NP_CHUNK_WORDS + k * 256 + threadIdx.x;
+    if (w < NW) c += __popc(bits[w]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_counts[(int64_t)b * nchunks + ch] = s_cnt;
+}
+
+// writes ascending doc ids; thread t owns words [4t, 4t+4) of the chunk so the order is preserved
+__global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict__ docbits, int64_t NW, int nchunks,
+                                                      const int32_t* __restrict__ chunk_counts,
+                                                      uint32_t* __restrict__ cand, int64_t cand_stride,
+                                                      int32_t* __restrict__ n_cand, Counters* ctr) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* cc = chunk_counts + (int64_t)b * nchunks;
+  {
+    int part = 0;
+    for (int j = tid; j < ch; j += 256) part += cc[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) s_wave[wave] = part;
+    __syncthreads();
+    if (tid == 0) s_base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  const int base = s_base;
+  __syncthreads();
+  const uint32_t* bits = docbits + (int64_t)b * NW;
+  const int64_t w0 = (int64_t)ch * NP_CHUNK_WORDS + tid * 4;
+  uint32_t w[4];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w[k] = (w0 + k < NW) ? bits[w0 + k] : 0u;
+    cnt += __popc(w[k]);
+  }
+  // exclusive scan of cnt over the block
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int k = 0; k < wave; ++k) woff += s_wave[k];
+  int pos = base + woff + incl - cnt;
+  uint32_t* out = cand + (int64_t)b * cand_stride;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t m = w[k];
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      out[pos++] = (uint32_t)((w0 + k) * 32 + bit);
+    }
+  }
+  if (ch == nchunks - 1 && tid == 255) {
+    const int total = base + woff + incl;
+    n_cand[b] = total;
+    atomicAdd(&ctr->n_candidates, (unsigned long long)total);
+  }
+}
+
+__global__ void cand_prefix_kernel(const int32_t* __restrict__ n_cand, int B, int64_t* __restrict__ prefix) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t s = 0;
+    for (int b = 0; b < B; ++b) {
+      prefix[b] = s;
+      s += n_cand[b];
+    }
+    prefix[B] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S4  approximate score: one wave per candidate document.  QL = lanes per token (32: two tokens
+// per step, 64: one).  Each lane owns one query token q and gathers QCT[code][q] -- one
+// contiguous 4*QL-byte line per document token.  max uses '>' semantics (NaN ignored, +inf kept),
+// the sum runs in q order and skips tokens whose max stayed -inf (search.rs:305-324).
+// ---------------------------------------------------------------------------------------------
+template <int QL>
+__global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
+                                                     const int32_t* __restrict__ qoff,
+                                                     const uint32_t* __restrict__ cand, int64_t cand_stride,
+                                                     const int64_t* __restrict__ prefix, int B,
+                                                     const int64_t* __restrict__ doc_off,
+                                                     const uint32_t* __restrict__ codes, float* __restrict__ approx,
+                                                     Counters* ctr) {
+  constexpr int TPS = 64 / QL;  // tokens per step
+  const int lane = threadIdx.x & 63;
+  const int ql = lane & (QL - 1), h = lane / QL;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t total = prefix[B];
+  unsigned long long toks = 0;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += nwaves) {
+    int lo = 0, hi = B;  // largest b with prefix[b] <= w
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (prefix[mid] <= w) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    const int64_t i = w - prefix[b];
+    const uint32_t doc = cand[(int64_t)b * cand_stride + i];
+    const int64_t off = doc_off[doc];
+    const int len = (int)(doc_off[doc + 1] - off);
+    const int Lq = qoff[b + 1] - qoff[b];
+    const float* T = QCT + (int64_t)b * KP * LQP;
+    toks += (unsigned long long)len;
+    float score = 0.f;
+    for (int q0 = 0; q0 < Lq; q0 += QL) {
+      const int q = q0 + ql;
+      float m = NP_NEG_INF;
+      for (int t0 = 0; t0 < len; t0 += 64) {
+        const int tl = t0 + lane;
+        const uint32_t creg = (tl < len) ? codes[off + tl] : 0u;
+        const int nt = min(64, len - t0);
+#pragma unroll 8
+        for (int s = 0; s < 64 / TPS; ++s) {
+          const int t = s * TPS + h;
+          if (s * TPS >= nt) break;
+          const uint32_t c = (uint32_t)__shfl((int)creg, t);
+          const float v = (t < nt && q < LQP) ? T[(int64_t)c * LQP + q] : NP_NEG_INF;
+          m = fmaxf(m, v);  // == `if v > m` for NaN v (kept out) and +inf (kept)
+        }
+      }
+      if (TPS == 2) m = fmaxf(m, __shfl_xor(m, 32));
+      const int nq = min(QL, Lq - q0);
+      for (int j = 0; j < nq; ++j) {
+        const float x = readlane_f(m, j);
+        if (x > NP_NEG_INF) score += x;
+      }
+    }
+    if (lane == 0) approx[(int64_t)b * cand_stride + i] = score;
+  }
+  if (lane == 0 && toks) atomicAdd(&ctr->n_cand_tokens, toks);
+}
+
+// ---------------------------------------------------------------------------------------------
+// block bitonic sort, descending, n = power of two, in LDS
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n, int tid, int nthreads) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < n; i += nthreads) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t a = s[i], c = s[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < c) : (a > c)) {
+            s[i] = c;
+            s[ixj] = a;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// S5  per query: the n_sel best candidates by (approx desc [finite first], doc id asc), sorted.
+// key64 = okey(approx) << 32 | (0xFFFFFFFF - global_doc_id)
+// ---------------------------------------------------------------------------------------------
+struct SelectP {
+  const float* approx;
+  const uint32_t* cand;
+  int64_t cand_stride;
+  const int32_t* n_cand;
+  int64_t doc_begin;
+  int n_sel;    // min(n_full_scores, max(n_full_scores/4, top_k))
+  int NSELP;    // pow2 >= n_sel
+  uint64_t* sel_keys;   // [B][n_sel]
+  uint32_t* sel_doc;    // [B][n_sel] shard-local doc
+  int32_t* nsel_out;    // [B]
+};
+
+__global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
+  extern __shared__ uint64_t s_sel[];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_prefix, s_rem, s_ngt, s_eqbase;
+  __shared__ uint32_t s_wtot[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n_cand[b];
+  const float* ap = p.approx + (int64_t)b * p.cand_stride;
+  const uint32_t* cd = p.cand + (int64_t)b * p.cand_stride;
+  const int nsel = min(p.n_sel, n);
+  for (int i = tid; i < p.NSELP; i += 1024) s_sel[i] = 0;
+  if (tid == 0) { s_ngt = 0; s_eqbase = 0; }
+  __syncthreads();
+  if (nsel > 0) {
+    if (n <= nsel) {
+      for (int i = tid; i < n; i += 1024)
+        s_sel[i] = ((uint64_t)okey(ap[i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + cd[i]));
+    } else {
+      if (tid == 0) { s_prefix = 0; s_rem = (uint32_t)nsel; }
+      __syncthreads();
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t pre = s_prefix;
+        for (int i = tid; i < n; i += 1024) {
+          const uint32_t key = okey(ap[i]);
+          if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t rem = s_rem, cum = 0;
+          int bin = 255;
+          for (; bin > 0; --bin) {
+            if (cum + hist[bin] >= rem) break;
+            cum += hist[bin];
+          }
+          s_prefix = (pre << 8) | (uint32_t)bin;
+          s_rem = rem - cum;
+        }
+        __syncthreads();
+      }
+      const uint32_t tau = s_prefix, rem = s_rem;
+      const uint32_t ngt_total = (uint32_t)nsel - rem;
+      for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const bool in = i < n;
+        const uint32_t key = in ? okey(ap[i]) : 0u;
+        const bool gt = in && key > tau, eq = in && key == tau;
+        // ordered rank among the ties (ascending candidate index == ascending doc id)
+        const unsigned long long bal = __ballot(eq);
+        const uint32_t wrank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = s_eqbase;
+        for (int k = 0; k < wave; ++k) before += s_wtot[k];
+        const uint32_t rank = before + wrank;
+        const uint64_t comp =
+            ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + (in ? cd[i] : 0u)));
+        if (gt) s_sel[atomicAdd(&s_ngt, 1u)] = comp;
+        if (eq && rank < rem) s_sel[ngt_total + rank] = comp;
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t t = 0;
+          for (int k = 0; k < 16; ++k) t += s_wtot[k];
+          s_eqbase += t;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  bitonic_sort_desc(s_sel, p.NSELP, tid, 1024);
+  for (int j = tid; j < p.n_sel; j += 1024) {
+    const uint64_t c = (j < nsel) ? s_sel[j] : 0ull;
+    p.sel_keys[(int64_t)b * p.n_sel + j] = c;
+    p.sel_doc[(int64_t)b * p.n_sel + j] =
+        (j < nsel) ? (uint32_t)((int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)) - p.doc_begin) : 0u;
+  }
+  if (tid == 0) p.nsel_out[b] = nsel;
+}
+
+// ---------------------------------------------------------------------------------------------
+// S6  exact MaxSim.  One wave walks a document in 32-token tiles.  Lane (tok = lane&31,
+// half = lane>>5) unpacks its half of the token's residual bytes, adds the centroid row, the two
+// halves exchange their sum of squares with one shuffle, and the normalised values ARE the MFMA
+// A fragment (no LDS staging of D).  S = D.Q^T accumulates on the matrix cores with tokens as
+// MFMA rows and query tokens as columns, so the row-max over document tokens is an in-lane max.
+//   decompress: out = centroid + wlut[segment]; row /= max(||row||, 1e-12)   codec.rs:443-467
+//   maxsim:     sum_q max_t S[q,t], non-finite entries ignored                maxsim.rs:281-291
+// ---------------------------------------------------------------------------------------------
+struct ExactP {
+  const float* Qt;          // [B][DIM][LQP] f32
+  const __bf16* Qb;         // [B][LQP][DIM]
+  const int32_t* qoff;
+  int LQP;
+  const float* centroids;
+  const float* wlut;
+  const uint32_t* codes;
+  const uint8_t* residuals;
+  const int64_t* doc_off;
+  const uint64_t* sel_keys; // [B][n_sel]
+  const uint32_t* sel_doc;
+  const int32_t* nsel;      // [B]
+  const uint64_t* cut;      // [B] or NULL
+  int n_sel;
+  float* exact;             // [B][n_sel]
+  Counters* ctr;
+};
+
+#define NP_EXACT_DPW 4   // documents per wave
+#define NP_MAX_QT 8      // query tiles of 32 tokens (LQP <= 256); kernels are instantiated for 1, 2 and 8
+
+template <int NBITS>
+__device__ __forceinline__ float seg_weight(const float* sW, uint32_t byte, int e) {
+  constexpr uint32_t MASK = (1u << NBITS) - 1u;
+  return sW[(byte >> (8 - NBITS * (e + 1))) & MASK];  // segment e: 0 = highest bits = first dim
+}
+
+template <int DIM, int NBITS, int NQT>
+__global__ void __launch_bounds__(256) exact_f32_kernel(ExactP p) {
+  constexpr int H = DIM / 2;              // dims per lane
+  constexpr int PD = DIM * NBITS / 8;     // bytes per token
+  constexpr int PH = PD / 2;              // bytes per lane
+  constexpr int PER = 8 / NBITS;          // dims per byte
+  static_assert(PH % 4 == 0 && H % 4 == 0, "unsupported DIM/NBITS");
+  extern __shared__ float smem[];
+  const int LQP = p.LQP;
+  float* sQ = smem;                       // [DIM][LQP]
+  float* sW = smem + DIM * LQP;           // [1<<NBITS]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < DIM * LQP; i += 256) sQ[i] = p.Qt[(int64_t)b * DIM * LQP + i];
+  if (tid < (1 << NBITS)) sW[tid] = p.wlut[tid];
+  __syncthreads();
+  const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
+  const int Lq = p.qoff[b + 1] - p.qoff[b];
+  const int nqt = (Lq + 31) >> 5;
+  const int nsel = p.nsel[b];
+  const uint64_t cut = p.cut ? p.cut[b] : 0ull;
+  unsigned long long toks = 0, ndocs = 0;
+  for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
+    const int j = (blockIdx.x * 4 + wave) * NP_EXACT_DPW + dd;
+    if (j >= nsel) break;
+    const int64_t oj = (int64_t)b * p.n_sel + j;
+    if (p.sel_keys[oj] < cut) {
+      if (lane == 0) p.exact[oj] = 0.f;
+      continue;
+    }
+    const uint32_t doc = p.sel_doc[oj];
+    const int64_t off = p.doc_off[doc];
+    const int len = (int)(p.doc_off[doc + 1] - off);
+    toks += (unsigned long long)len;
+    ++ndocs;
+    float m[NQT];
+#pragma unroll
+    for (int x = 0; x < NQT; ++x) m[x] = NP_NEG_INF;
+    for (int t0 = 0; t0 < len; t0 += 32) {
+      const int tt = t0 + li;
+      const bool valid = tt < len;
+      const int64_t tok = off + (valid ? tt : len - 1);
+      const uint32_t code = p.codes[tok];
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(p.residuals + tok * PD + kk * PH);
+      const float4* cp = reinterpret_cast<const float4*>(p.centroids + (int64_t)code * DIM + kk * H);
+      float v[H];
+      float ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < PH / 4; ++w) {
+        const uint32_t word = rp[w];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t byte = (word >> (8 * i)) & 0xFFu;
+#pragma unroll
+          for (int e = 0; e < PER; ++e) {
+            const int jdim = (w * 4 + i) * PER + e;
+            const float c = reinterpret_cast<const float*>(cp)[jdim];
+            const float x = c + seg_weight<NBITS>(sW, byte, e);
+            v[jdim] = x;
+            ss = fmaf(x, x, ss);
+          }
+        }
+      }
+      // 1/||row|| is applied to the MFMA output rows (S[t][q] = rn[t] * <raw_t, q>) instead of to
+      // the 64 fragment values; lane li holds rn of token t0+li, row r of this lane needs token
+      // t0 + mfma_row(r, kk).
+      const float tot = ss + __shfl_xor(ss, 32);
+      const float rn = valid ? 1.0f / fmaxf(sqrtf(tot), 1e-12f) : 0.f;
+      float rrow[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rrow[r] = __shfl(rn, mfma_row(r, kk));
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+        if (qt < nqt) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const float* qb = sQ + (kk * H) * LQP + qt * 32 + li;
+#pragma unroll
+          for (int s = 0; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s], qb[s * LQP], acc, 0, 0, 0);
+          float mm = m[qt];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = t0 + mfma_row(r, kk);
+            const float x = acc[r] * rrow[r];
+            if (trow < len && finitef(x)) mm = fmaxf(mm, x);
+          }
+          m[qt] = mm;
+        }
+      }
+    }
+    float total = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+      if (qt < nqt) {
+        const float mm = fmaxf(m[qt], __shfl_xor(m[qt], 32));
+        const int nq = min(32, Lq - qt * 32);
+        for (int qi = 0; qi < nq; ++qi) {
+          const float x = readlane_f(mm, qi);
+          if (x > NP_NEG_INF) total += x;
+        }
+      }
+    }
+    if (lane == 0) p.exact[oj] = total;
+  }
+  if (lane == 0 && ndocs) {
+    atomicAdd(&p.ctr->n_exact_docs, ndocs);
+    atomicAdd(&p.ctr->n_exact_tokens, toks);
+  }
+}
+
+// bf16 MFMA variant (precision = 1): A fragment s of lane (tok, kk) = dims [16s + 8kk, +8).
+template <int DIM, int NBITS, int NQT>
+__global__ void __launch_bounds__(256) exact_bf16_kernel(ExactP p) {
+  constexpr int NS = DIM / 16;            // MFMA k-steps
+  constexpr int PD = DIM * NBITS / 8;
+  constexpr int PER = 8 / NBITS;
+  static_assert(DIM % 16 == 0 && (NBITS == 2 || NBITS == 4), "unsupported DIM/NBITS");
+  __shared__ float sW[1 << NBITS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < (1 << NBITS)) sW[tid] = p.wlut[tid];
+  __syncthreads();
+  const int LQP = p.LQP;
+  const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
+  const int Lq = p.qoff[b + 1] - p.qoff[b];
+  const int nqt = (Lq + 31) >> 5;
+  const int nsel = p.nsel[b];
+  const uint64_t cut = p.cut ? p.cut[b] : 0ull;
+  const __bf16* Qb = p.Qb + (int64_t)b * LQP * DIM;
+  bf16x8 bq0[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) bq0[s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)li * DIM + 16 * s + 8 * kk);
+  unsigned long long toks = 0, ndocs = 0;
+  for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
+    const int j = (blockIdx.x * 4 + wave) * NP_EXACT_DPW + dd;
+    if (j >= nsel) break;
+    const int64_t oj = (int64_t)b * p.n_sel + j;
+    if (p.sel_keys[oj] < cut) {
+      if (lane == 0) p.exact[oj] = 0.f;
+      continue;
+    }
+    const uint32_t doc = p.sel_doc[oj];
+    const int64_t off = p.doc_off[doc];
+    const int len = (int)(p.doc_off[doc + 1] - off);
+    toks += (unsigned long long)len;
+    ++ndocs;
+    float m[NQT];
+#pragma unroll
+    for (int x = 0; x < NQT; ++x) m[x] = NP_NEG_INF;
+    for (int t0 = 0; t0 < len; t0 += 32) {
+      const int tt = t0 + li;
+      const bool valid = tt < len;
+      const int64_t tok = off + (valid ? tt : len - 1);
+      const uint32_t code = p.codes[tok];
+      const uint8_t* rp = p.residuals + tok * PD;
+      const float* cp = p.centroids + (int64_t)code * DIM;
+      bf16x8 a[NS];
+      float ss = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int d0 = 16 * s + 8 * kk;
+        const float4 c0 = *reinterpret_cast<const float4*>(cp + d0);
+        const float4 c1 = *reinterpret_cast<const float4*>(cp + d0 + 4);
+        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        uint32_t word;
+        if (NBITS == 4) word = *reinterpret_cast<const uint32_t*>(rp + d0 / 2);
+        else word = *reinterpret_cast<const uint16_t*>(rp + d0 / 4);
+#pragma unroll
+        for (int i = 0; i < 8 / PER; ++i) {
+          const uint32_t byte = (word >> (8 * i)) & 0xFFu;
+#pragma unroll
+          for (int e = 0; e < PER; ++e) {
+            const float x = cc[i * PER + e] + seg_weight<NBITS>(sW, byte, e);
+            a[s][i * PER + e] = (__bf16)x;   // un-normalised; rows are scaled after the MFMA
+            ss = fmaf(x, x, ss);
+          }
+        }
+      }
+      const float tot = ss + __shfl_xor(ss, 32);
+      const float rn = valid ? 1.0f / fmaxf(sqrtf(tot), 1e-12f) : 0.f;
+      float rrow[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rrow[r] = __shfl(rn, mfma_row(r, kk));
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+        if (qt < nqt) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            bf16x8 bq;
+            if (qt == 0) bq = bq0[s];
+            else bq = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)(qt * 32 + li) * DIM + 16 * s + 8 * kk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq, acc, 0, 0, 0);
+          }
+          float mm = m[qt];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = t0 + mfma_row(r, kk);
+            const float x = acc[r] * rrow[r];
+            if (trow < len && finitef(x)) mm = fmaxf(mm, x);
+          }
+          m[qt] = mm;
+        }
+      }
+    }
+    float total = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+      if (qt < nqt) {
+        const float mm = fmaxf(m[qt], __shfl_xor(m[qt], 32));
+        const int nq = min(32, Lq - qt * 32);
+        for (int qi = 0; qi < nq; ++qi) {
+          const float x = readlane_f(mm, qi);
+          if (x > NP_NEG_INF) total += x;
+        }
+      }
+    }
+    if (lane == 0) p.exact[oj] = total;
+  }
+  if (lane == 0 && ndocs) {
+    atomicAdd(&p.ctr->n_exact_docs, ndocs);
+    atomicAdd(&p.ctr->n_exact_tokens, toks);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S7  stable top-k by (exact desc [finite first], approx rank asc)   (search.rs:496-515)
+// ---------------------------------------------------------------------------------------------
+struct TopkP {
+  const float* exact;
+  const uint64_t* sel_keys;
+  const uint32_t* sel_doc;
+  const int32_t* nsel;
+  const uint64_t* cut;
+  int n_sel, NSELP, top_k;
+  int64_t doc_begin;
+  int64_t* out_ids;     // [B][top_k]
+  float* out_scores;
+  uint64_t* out_keys;   // may be NULL
+  int32_t* out_counts;
+};
+
+__global__ void __launch_bounds__(1024) topk_kernel(TopkP p) {
+  extern __shared__ uint64_t s_sel[];
+  __shared__ int s_valid;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nsel = p.nsel[b];
+  const uint64_t cut = p.cut ? p.cut[b] : 0ull;
+  if (tid == 0) s_valid = 0;
+  __syncthreads();
+  int nv = 0;
+  for (int j = tid; j < p.NSELP; j += 1024) {
+    uint64_t c = 0;
+    if (j < nsel && p.sel_keys[(int64_t)b * p.n_sel + j] >= cut) {
+      c = ((uint64_t)okey(p.exact[(int64_t)b * p.n_sel + j]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)j);
+      ++nv;
+    }
+    s_sel[j] = c;
+  }
+  if (nv) atomicAdd(&s_valid, nv);
+  bitonic_sort_desc(s_sel, p.NSELP, tid, 1024);
+  const int cnt = min(p.top_k, s_valid);
+  for (int i = tid; i < cnt; i += 1024) {
+    const int j = (int)(0xFFFFFFFFu - (uint32_t)(s_sel[i] & 0xFFFFFFFFull));
+    const int64_t oj = (int64_t)b * p.n_sel + j;
+    p.out_ids[(int64_t)b * p.top_k + i] = p.doc_begin + (int64_t)p.sel_doc[oj];
+    p.out_scores[(int64_t)b * p.top_k + i] = p.exact[oj];
+    if (p.out_keys) p.out_keys[(int64_t)b * p.top_k + i] = p.sel_keys[oj];
+  }
+  if (tid == 0) p.out_counts[b] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// document-sharded exchange
+// ---------------------------------------------------------------------------------------------
+// cut[b] = the n_sel-th largest key over the G shards' lists (1 if fewer exist: keep everything)
+__global__ void __launch_bounds__(1024) select_cut_kernel(const uint64_t* __restrict__ all_keys, int G, int B,
+                                                          int n_sel, int NP2, uint64_t* __restrict__ cut) {
+  extern __shared__ uint64_t s_sel[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = G * n_sel;
+  for (int i = tid; i < NP2; i += 1024) {
+    uint64_t v = 0;
+    if (i < n) {
+      const int g = i / n_sel, j = i - g * n_sel;
+      v = all_keys[((int64_t)g * B + b) * n_sel + j];
+    }
+    s_sel[i] = v;
+  }
+  bitonic_sort_desc(s_sel, NP2, tid, 1024);
+  if (tid == 0) {
+    const uint64_t c = (n_sel > 0) ? s_sel[n_sel - 1] : 0ull;
+    cut[b] = c ? c : 1ull;
+  }
+}
+
+// merge G x top_k triples by (exact desc [finite first], approx key desc); rank by counting
+__global__ void __launch_bounds__(256) merge_topk_kernel(const int64_t* __restrict__ ids, const float* __restrict__ scores,
+                                                         const uint64_t* __restrict__ keys,
+                                                         const int32_t* __restrict__ counts, int G, int B, int top_k,
+                                                         int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                         int32_t* __restrict__ out_counts) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = G * top_k;
+  int total = 0;
+  for (int g = 0; g < G; ++g) total += counts[g * B + b];
+  for (int i = tid; i < n; i += 256) {
+    const int g = i / top_k, j = i - g * top_k;
+    if (j >= counts[g * B + b]) continue;
+    const int64_t e = ((int64_t)g * B + b) * top_k + j;
+    const uint32_t ks = okey(scores[e]);
+    const uint64_t ka = keys[e];
+    int rank = 0;
+    for (int g2 = 0; g2 < G; ++g2) {
+      const int c2 = counts[g2 * B + b];
+      for (int j2 = 0; j2 < c2; ++j2) {
+        const int64_t e2 = ((int64_t)g2 * B + b) * top_k + j2;
+        const uint32_t ks2 = okey(scores[e2]);
+        if (ks2 > ks || (ks2 == ks && keys[e2] > ka)) ++rank;
+      }
+    }
+    if (rank < top_k) {
+      out_ids[(int64_t)b * top_k + rank] = ids[e];
+      out_scores[(int64_t)b * top_k + rank] = scores[e];
+    }
+  }
+  if (tid == 0) out_counts[b] = min(top_k, total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// N2  decompress_documents (index.rs:1159-1245, codec.rs:423-470): one wave per token, any dim.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) decompress_kernel(const int64_t* __restrict__ tok_src /*[n] shard token idx*/,
+                                                         int64_t n, int dim, int nbits, int pd,
+                                                         const float* __restrict__ centroids,
+                                                         const float* __restrict__ wlut,
+                                                         const uint32_t* __restrict__ codes,
+                                                         const uint8_t* __restrict__ residuals,
+                                                         float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const int64_t tok = tok_src[i];
+  const uint32_t code = codes[tok];
+  const int per = 8 / nbits;
+  const uint32_t mask = (1u << nbits) - 1u;
+  float ss = 0.f;
+  for (int j = lane; j < dim; j += 64) {
+    const uint32_t byte = residuals[tok * pd + j / per];
+    const int e = j % per;
+    const float x = centroids[(int64_t)code * dim + j] + wlut[(byte >> (8 - nbits * (e + 1))) & mask];
+    out[i * dim + j] = x;
+    ss += x * x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float norm = fmaxf(sqrtf(ss), 1e-12f);
+  for (int j = lane; j < dim; j += 64) out[i * dim + j] = out[i * dim + j] / norm;
+}
+
+}  // namespace np

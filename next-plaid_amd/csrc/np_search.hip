@@ -1,0 +1,860 @@
+// np_search.hip -- the search pipeline and its C ABI.
+//
+// Replaces search::search_one_mmap / search_many_mmap (next-plaid/src/search.rs:327-675) behind
+// MmapIndex::search / search_batch (index.rs:1258-1287).  A batch of B queries is ONE pass of
+// S1..S7 launches on one HIP stream (no host round trip between stages; every data-dependent
+// size lives in device memory and kernels early-exit on it).
+#include "np_internal.h"
+#include "np_kernels.h"
+
+#include <algorithm>
+#include <string.h>
+
+namespace np {
+
+struct Workspace {
+  DevBuf q, qoff, Qt, Qb, QCT, gmax, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, approx, n_cand,
+      prefix, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset, subset_bits,
+      elig, misc, cut;
+  void* h_pin = nullptr;
+  size_t h_pin_cap = 0;
+  hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
+  bool done_valid = false;
+  void release_all() {
+    DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &QCT, &gmax, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
+                     &chunk_counts, &cand, &approx, &n_cand, &prefix, &sel_keys, &sel_doc, &nsel, &exact, &out_ids,
+                     &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc, &cut};
+    for (DevBuf* b : all) b->release();
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = nullptr;
+    h_pin_cap = 0;
+    if (done) (void)hipEventDestroy(done);
+    done = nullptr;
+  }
+  int pin(size_t bytes) {
+    if (bytes <= h_pin_cap) return NP_OK;
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = nullptr;
+    h_pin_cap = 0;
+    hipError_t e = hipHostMalloc(&h_pin, bytes + 4096, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      return NP_ERR_OUT_OF_MEMORY;
+    }
+    h_pin_cap = bytes + 4096;
+    return NP_OK;
+  }
+};
+
+void destroy_context(Context* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->ws) {
+    c->ws->release_all();
+    delete c->ws;
+  }
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int acquire_context(const DeviceIndex* ix, Context** out) {
+  std::unique_lock<std::mutex> lk(ix->mu);
+  for (;;) {
+    for (Context* c : ix->contexts)
+      if (!c->busy) {
+        c->busy = true;
+        *out = c;
+        return NP_OK;
+      }
+    if ((int)ix->contexts.size() < ix->opts.n_contexts) {
+      Context* c = new Context();
+      c->ws = new Workspace();
+      hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+      for (auto& ev : c->ev)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ws->done, hipEventDisableTiming);
+      if (e != hipSuccess) {
+        set_error("context creation failed: %s", hipGetErrorString(e));
+        destroy_context(c);
+        return NP_ERR_DEVICE_UNAVAILABLE;
+      }
+      c->busy = true;
+      ix->contexts.push_back(c);
+      *out = c;
+      return NP_OK;
+    }
+    ix->cv.wait(lk);
+  }
+}
+
+static void release_context(const DeviceIndex* ix, Context* c) {
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    c->busy = false;
+  }
+  ix->cv.notify_one();
+}
+
+// ---- one pipeline pass over a slice of the batch --------------------------------------------------
+struct CallState {
+  Context* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  int B = 0, LQP = 0, n_sel = 0, NSELP = 1;
+  np_search_params prm{};
+  bool empty_subset = false;
+  bool timed = false;
+};
+
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+static int n_sel_of(const np_search_params* p) {
+  int64_t nd = std::max<int64_t>((int64_t)p->n_full_scores / 4, p->top_k);  // search.rs:468
+  return (int)std::min<int64_t>(nd, p->n_full_scores);                     // search.rs:461-469 take/take
+}
+
+static bool dim_supported(int dim, int nbits) {
+  return (dim == 32 || dim == 64 || dim == 96 || dim == 128) && (nbits == 2 || nbits == 4);
+}
+
+static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_search_params* p) {
+  if (!ix || !p) {
+    set_error("Search failed: NULL index or params");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B < 0) {
+    set_error("Search failed: negative batch size");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (dim != ix->dim) {  // ndarray .dot() would panic on this (search.rs:345)
+    set_error("Shape error: query dim %d does not match index dim %d", dim, ix->dim);
+    return NP_ERR_SHAPE;
+  }
+  if (!dim_supported(ix->dim, ix->nbits)) {
+    set_error("Shape error: the HIP search path supports dim in {32,64,96,128} and nbits in {2,4}; index has dim=%d nbits=%d",
+              ix->dim, ix->nbits);
+    return NP_ERR_SHAPE;
+  }
+  if (p->n_ivf_probe < 1 || p->top_k < 0 || p->n_full_scores < 0) {
+    set_error("Search failed: invalid parameters (n_ivf_probe=%d top_k=%d n_full_scores=%d)", p->n_ivf_probe, p->top_k,
+              p->n_full_scores);
+    return NP_ERR_SEARCH;
+  }
+  if (n_sel_of(p) > 8192) {
+    set_error("Search failed: max(n_full_scores/4, top_k) = %d exceeds the HIP path's 8192-document re-rank window",
+              n_sel_of(p));
+    return NP_ERR_SEARCH;
+  }
+  if (p->precision != 0 && p->precision != 1) {
+    set_error("Search failed: unknown precision %d", p->precision);
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  return NP_OK;
+}
+
+static int64_t per_query_bytes(const DeviceIndex* ix, int LQP) {
+  const int64_t NW = (ix->n_docs + 31) / 32;
+  return ix->KP * LQP * 4 + (ix->KP / 32) * LQP * 4 + ix->KP * 9 + NW * 4 + std::max<int64_t>(ix->n_docs, 1) * 8 +
+         (int64_t)ix->dim * LQP * 6 + 65536;
+}
+
+template <int DIM>
+static void launch_gemm(hipStream_t st, const DeviceIndex* ix, const float* Qt, int B, int LQP, float* QCT,
+                        uint32_t* gmax) {
+  const unsigned blocks = (unsigned)((ix->KP / 64 + 3) / 4);
+  qc_gemm_kernel<DIM><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax);
+}
+
+template <int DIM, int NBITS, int NQT>
+static int launch_exact(hipStream_t st, const ExactP& p, int B, int precision) {
+  const unsigned gx = (unsigned)((p.n_sel + 4 * NP_EXACT_DPW - 1) / (4 * NP_EXACT_DPW));
+  if (gx == 0 || B == 0) return NP_OK;
+  if (precision == 0) {
+    const size_t lds = ((size_t)DIM * p.LQP + (1 << NBITS)) * sizeof(float);
+    if (lds > 64 * 1024)
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_f32_kernel<DIM, NBITS, NQT>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    exact_f32_kernel<DIM, NBITS, NQT><<<dim3(gx, B), 256, lds, st>>>(p);
+  } else {
+    exact_bf16_kernel<DIM, NBITS, NQT><<<dim3(gx, B), 256, 0, st>>>(p);
+  }
+  return NP_OK;
+}
+
+template <int DIM, int NBITS>
+static int launch_exact_qt(hipStream_t st, const ExactP& p, int B, int precision) {
+  if (p.LQP <= 32) return launch_exact<DIM, NBITS, 1>(st, p, B, precision);
+  if (p.LQP <= 64) return launch_exact<DIM, NBITS, 2>(st, p, B, precision);
+  return launch_exact<DIM, NBITS, NP_MAX_QT>(st, p, B, precision);
+}
+
+template <int DIM>
+static int launch_exact_nb(hipStream_t st, const ExactP& p, int B, int precision, int nbits) {
+  if (nbits == 2) return launch_exact_qt<DIM, 2>(st, p, B, precision);
+  return launch_exact_qt<DIM, 4>(st, p, B, precision);
+}
+
+// S1..S5 for queries [0,B) whose rows live in d_q (absolute offsets d_qoff/h_qoff).
+static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
+                   const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len) {
+  Workspace& w = *cs->ctx->ws;
+  hipStream_t st = cs->stream;
+  const int B = cs->B;
+  const np_search_params& prm = cs->prm;
+  int maxLq = 1;
+  for (int b = 0; b < B; ++b) maxLq = std::max(maxLq, h_qoff[b + 1] - h_qoff[b]);
+  for (int b = 0; b < B; ++b)
+    if (h_qoff[b + 1] < h_qoff[b]) {
+      set_error("Shape error: q_tok_offsets must be non-decreasing");
+      return NP_ERR_SHAPE;
+    }
+  const int LQP = (maxLq + 31) / 32 * 32;
+  if (LQP > 32 * NP_MAX_QT) {
+    set_error("Shape error: queries longer than %d tokens are not supported by the HIP path (got %d)", 32 * NP_MAX_QT,
+              maxLq);
+    return NP_ERR_SHAPE;
+  }
+  cs->LQP = LQP;
+  cs->n_sel = n_sel_of(&prm);
+  cs->NSELP = next_pow2(std::max(cs->n_sel, 1));
+  cs->empty_subset = (subset_len == 0);
+  const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
+  const int64_t cand_stride = std::max<int64_t>(ix->n_docs, 1);
+  const int nchunks = (int)((NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS);
+  const int nsel1 = std::max(cs->n_sel, 1), topk1 = std::max(prm.top_k, 1);
+
+  NP_TRY(w.Qt.reserve((size_t)B * ix->dim * LQP * 4));
+  NP_TRY(w.Qb.reserve((size_t)B * ix->dim * LQP * 2));
+  NP_TRY(w.QCT.reserve((size_t)B * KP * LQP * 4));
+  NP_TRY(w.gmax.reserve((size_t)B * G * LQP * 4));
+  NP_TRY(w.cellbits.reserve((size_t)B * G * 4));
+  NP_TRY(w.cells_tmp.reserve((size_t)B * KP * 4));
+  NP_TRY(w.cells.reserve((size_t)B * KP * 4));
+  NP_TRY(w.n_cells.reserve((size_t)B * 4));
+  NP_TRY(w.docbits.reserve((size_t)B * std::max<int64_t>(NW, 1) * 4));
+  NP_TRY(w.chunk_counts.reserve((size_t)B * std::max(nchunks, 1) * 4));
+  NP_TRY(w.cand.reserve((size_t)B * cand_stride * 4));
+  NP_TRY(w.approx.reserve((size_t)B * cand_stride * 4));
+  NP_TRY(w.n_cand.reserve((size_t)B * 4));
+  NP_TRY(w.prefix.reserve((size_t)(B + 1) * 8));
+  NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
+  NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
+  NP_TRY(w.nsel.reserve((size_t)B * 4));
+  NP_TRY(w.exact.reserve((size_t)B * nsel1 * 4));
+  NP_TRY(w.out_ids.reserve((size_t)B * topk1 * 8));
+  NP_TRY(w.out_scores.reserve((size_t)B * topk1 * 4));
+  NP_TRY(w.out_keys.reserve((size_t)B * topk1 * 8));
+  NP_TRY(w.out_counts.reserve((size_t)B * 4));
+  NP_TRY(w.ctr.reserve(sizeof(Counters)));
+  NP_TRY(w.misc.reserve(64));
+
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[0], st));
+  NP_HIP(hipMemsetAsync(w.ctr.p, 0, sizeof(Counters), st));
+  NP_HIP(hipMemsetAsync(w.n_cells.p, 0, (size_t)B * 4, st));
+  NP_HIP(hipMemsetAsync(w.n_cand.p, 0, (size_t)B * 4, st));
+  NP_HIP(hipMemsetAsync(w.nsel.p, 0, (size_t)B * 4, st));
+  NP_HIP(hipMemsetAsync(w.cellbits.p, 0, (size_t)B * G * 4, st));
+  if (NW > 0) NP_HIP(hipMemsetAsync(w.docbits.p, 0, (size_t)B * NW * 4, st));
+  if (cs->n_sel > 0) NP_HIP(hipMemsetAsync(w.sel_keys.p, 0, (size_t)B * cs->n_sel * 8, st));
+  if (B == 0) return NP_OK;
+
+  // ---- S1
+  prep_queries_kernel<<<B, 256, 0, st>>>(d_q, d_qoff, ix->dim, LQP, w.Qt.as<float>(), w.Qb.as<__bf16>());
+  switch (ix->dim) {
+    case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+    case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+    case 96: launch_gemm<96>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+    default: launch_gemm<128>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+  }
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[1], st));
+
+  // ---- subset pre-filter (search.rs:350-382); the batched path only filters candidates (:542-545)
+  const bool have_subset = subset_len > 0;
+  const bool batched = prm.centroid_batch_size > 0 && ix->K > prm.centroid_batch_size;  // search.rs:337
+  const bool use_elig = have_subset && !batched;
+  if (have_subset) {
+    NP_TRY(w.subset_bits.reserve((size_t)std::max<int64_t>(NW, 1) * 4));
+    NP_TRY(w.elig.reserve((size_t)G * 4));
+    NP_HIP(hipMemsetAsync(w.subset_bits.p, 0, (size_t)std::max<int64_t>(NW, 1) * 4, st));
+    NP_HIP(hipMemsetAsync(w.elig.p, 0, (size_t)G * 4, st));
+    subset_kernel<<<(unsigned)((subset_len + 3) / 4), 256, 0, st>>>(
+        d_subset, subset_len, ix->doc_begin, ix->n_docs, ix->d_doc_offsets, ix->d_codes, w.subset_bits.as<uint32_t>(),
+        use_elig ? w.elig.as<uint32_t>() : nullptr);
+    if (use_elig)
+      subset_nprobe_kernel<<<1, 256, 0, st>>>(w.elig.as<uint32_t>(), G, prm.n_ivf_probe, ix->N_total, subset_len,
+                                              w.misc.as<int32_t>(), w.misc.as<int32_t>() + 1);
+  }
+
+  // ---- S2
+  if (!cs->empty_subset) {
+    ProbeP pp;
+    pp.QCT = w.QCT.as<float>();
+    pp.gmax = w.gmax.as<uint32_t>();
+    pp.qoff = d_qoff;
+    pp.K = ix->K;
+    pp.KP = KP;
+    pp.LQP = LQP;
+    pp.nprobe = prm.n_ivf_probe;
+    pp.nprobe_dev = use_elig ? w.misc.as<int32_t>() + 1 : nullptr;
+    pp.elig = use_elig ? w.elig.as<uint32_t>() : nullptr;
+    pp.n_elig = use_elig ? w.misc.as<int32_t>() : nullptr;
+    pp.has_thr = prm.has_threshold;
+    pp.thr = prm.centroid_score_threshold;
+    pp.cellbits = w.cellbits.as<uint32_t>();
+    pp.cells_tmp = w.cells_tmp.as<uint32_t>();
+    pp.cells = w.cells.as<uint32_t>();
+    pp.n_cells = w.n_cells.as<int32_t>();
+    pp.ctr = w.ctr.as<Counters>();
+    probe_kernel<<<B, 256, 0, st>>>(pp);
+  }
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));
+
+  // ---- S3
+  if (!cs->empty_subset && ix->n_docs > 0) {
+    mark_candidates_kernel<<<dim3(128, B), 256, 0, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
+                                                         ix->d_ivf_offsets, ix->d_ivf,
+                                                         have_subset ? w.subset_bits.as<uint32_t>() : nullptr, NW,
+                                                         w.docbits.as<uint32_t>(), w.ctr.as<Counters>());
+    count_chunks_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
+                                                          w.chunk_counts.as<int32_t>());
+    compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
+                                                     w.chunk_counts.as<int32_t>(), w.cand.as<uint32_t>(), cand_stride,
+                                                     w.n_cand.as<int32_t>(), w.ctr.as<Counters>());
+  }
+  cand_prefix_kernel<<<1, 64, 0, st>>>(w.n_cand.as<int32_t>(), B, w.prefix.as<int64_t>());
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
+
+  // ---- S4
+  if (!cs->empty_subset && ix->n_docs > 0) {
+    const unsigned grid = 2048;
+    if (LQP == 32)
+      approx_kernel<32><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand.as<uint32_t>(), cand_stride,
+                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_codes,
+                                              w.approx.as<float>(), w.ctr.as<Counters>());
+    else
+      approx_kernel<64><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand.as<uint32_t>(), cand_stride,
+                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_codes,
+                                              w.approx.as<float>(), w.ctr.as<Counters>());
+  }
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
+
+  // ---- S5
+  if (cs->n_sel > 0) {
+    SelectP sp;
+    sp.approx = w.approx.as<float>();
+    sp.cand = w.cand.as<uint32_t>();
+    sp.cand_stride = cand_stride;
+    sp.n_cand = w.n_cand.as<int32_t>();
+    sp.doc_begin = ix->doc_begin;
+    sp.n_sel = cs->n_sel;
+    sp.NSELP = cs->NSELP;
+    sp.sel_keys = w.sel_keys.as<uint64_t>();
+    sp.sel_doc = w.sel_doc.as<uint32_t>();
+    sp.nsel_out = w.nsel.as<int32_t>();
+    const size_t lds = (size_t)cs->NSELP * 8;
+    if (lds > 48 * 1024)
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    select_kernel<<<B, 1024, lds, st>>>(sp);
+  }
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[5], st));
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+// S6..S7.  d_cut may be NULL (keep every locally selected document).
+static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, const uint64_t* d_cut,
+                   int64_t* d_out_ids, float* d_out_scores, uint64_t* d_out_keys, int32_t* d_out_counts) {
+  Workspace& w = *cs->ctx->ws;
+  hipStream_t st = cs->stream;
+  const int B = cs->B;
+  if (B == 0) return NP_OK;
+  if (cs->n_sel > 0) {
+    ExactP ep;
+    ep.Qt = w.Qt.as<float>();
+    ep.Qb = w.Qb.as<__bf16>();
+    ep.qoff = d_qoff;
+    ep.LQP = cs->LQP;
+    ep.centroids = ix->d_centroids;
+    ep.wlut = ix->d_wlut;
+    ep.codes = ix->d_codes;
+    ep.residuals = ix->d_residuals;
+    ep.doc_off = ix->d_doc_offsets;
+    ep.sel_keys = w.sel_keys.as<uint64_t>();
+    ep.sel_doc = w.sel_doc.as<uint32_t>();
+    ep.nsel = w.nsel.as<int32_t>();
+    ep.cut = d_cut;
+    ep.n_sel = cs->n_sel;
+    ep.exact = w.exact.as<float>();
+    ep.ctr = w.ctr.as<Counters>();
+    switch (ix->dim) {
+      case 32: NP_TRY((launch_exact_nb<32>(st, ep, B, cs->prm.precision, ix->nbits))); break;
+      case 64: NP_TRY((launch_exact_nb<64>(st, ep, B, cs->prm.precision, ix->nbits))); break;
+      case 96: NP_TRY((launch_exact_nb<96>(st, ep, B, cs->prm.precision, ix->nbits))); break;
+      default: NP_TRY((launch_exact_nb<128>(st, ep, B, cs->prm.precision, ix->nbits))); break;
+    }
+  }
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[6], st));
+  {
+    TopkP tp;
+    tp.exact = w.exact.as<float>();
+    tp.sel_keys = w.sel_keys.as<uint64_t>();
+    tp.sel_doc = w.sel_doc.as<uint32_t>();
+    tp.nsel = w.nsel.as<int32_t>();
+    tp.cut = d_cut;
+    tp.n_sel = cs->n_sel;
+    tp.NSELP = cs->NSELP;
+    tp.top_k = cs->prm.top_k;
+    tp.doc_begin = ix->doc_begin;
+    tp.out_ids = d_out_ids;
+    tp.out_scores = d_out_scores;
+    tp.out_keys = d_out_keys;
+    tp.out_counts = d_out_counts;
+    const size_t lds = (size_t)cs->NSELP * 8;
+    if (lds > 48 * 1024)
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    topk_kernel<<<B, 1024, lds, st>>>(tp);
+  }
+  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[7], st));
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+static int begin_use(CallState* cs, void* user_stream) {
+  Context* c = cs->ctx;
+  cs->stream = user_stream ? (hipStream_t)user_stream : c->stream;
+  if (c->ws->done_valid && cs->stream != c->stream) NP_HIP(hipStreamWaitEvent(cs->stream, c->ws->done, 0));
+  if (c->ws->done_valid && cs->stream == c->stream) NP_HIP(hipStreamWaitEvent(cs->stream, c->ws->done, 0));
+  return NP_OK;
+}
+static int end_use(CallState* cs) {
+  Context* c = cs->ctx;
+  NP_HIP(hipEventRecord(c->ws->done, cs->stream));
+  c->ws->done_valid = true;
+  return NP_OK;
+}
+
+static int slice_size(const DeviceIndex* ix, const int32_t* h_qoff, int B) {
+  int maxLq = 1;
+  for (int b = 0; b < B; ++b) maxLq = std::max(maxLq, h_qoff[b + 1] - h_qoff[b]);
+  const int LQP = std::min((maxLq + 31) / 32 * 32, 32 * NP_MAX_QT);
+  int64_t s = ix->opts.workspace_bytes / std::max<int64_t>(per_query_bytes(ix, LQP), 1);
+  s = std::max<int64_t>(1, std::min<int64_t>(s, ix->opts.max_batch));
+  return (int)std::min<int64_t>(s, std::max(B, 1));
+}
+
+// Whole batch on device buffers, sliced.  No host synchronisation.
+static int run_device(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
+                      const int32_t* h_qoff, int B, const np_search_params* prm, const int64_t* d_subset,
+                      int64_t subset_len, int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts) {
+  const int S = slice_size(ix, h_qoff, B);
+  for (int s0 = 0; s0 < B; s0 += S) {
+    cs->B = std::min(S, B - s0);
+    cs->prm = *prm;
+    NP_TRY(phase_a(ix, cs, d_q, d_qoff + s0, h_qoff + s0, d_subset, subset_len));
+    NP_TRY(phase_b(ix, cs, d_qoff + s0, nullptr, d_out_ids + (int64_t)s0 * prm->top_k,
+                   d_out_scores + (int64_t)s0 * prm->top_k, nullptr, d_out_counts + s0));
+  }
+  return NP_OK;
+}
+
+}  // namespace np
+
+using namespace np;
+
+extern "C" {
+
+int32_t np_hip_n_sel(const np_search_params* p) { return p ? n_sel_of(p) : 0; }
+
+int np_hip_search_batch_device(const np_index* ix, const float* d_queries, const int32_t* d_q_tok_offsets,
+                               const int32_t* h_q_tok_offsets, int32_t B, int32_t dim, const np_search_params* params,
+                               const int64_t* d_subset, int64_t subset_len, int64_t* d_out_ids, float* d_out_scores,
+                               int32_t* d_out_counts, void* stream) {
+  clear_error();
+  NP_TRY(validate(ix, B, dim, params));
+  if (B == 0) return NP_OK;
+  if (!d_queries || !d_q_tok_offsets || !h_q_tok_offsets || !d_out_counts || (params->top_k > 0 && (!d_out_ids || !d_out_scores))) {
+    set_error("Search failed: NULL buffer");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g(ix->device);
+  CallState cs;
+  NP_TRY(acquire_context(ix, &cs.ctx));
+  int rc = begin_use(&cs, stream);
+  if (rc == NP_OK)
+    rc = run_device(ix, &cs, d_queries, d_q_tok_offsets, h_q_tok_offsets, B, params, d_subset, subset_len, d_out_ids,
+                    d_out_scores, d_out_counts);
+  int rc2 = end_use(&cs);
+  release_context(ix, cs.ctx);
+  return rc != NP_OK ? rc : rc2;
+}
+
+int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t* q_tok_offsets, int32_t B, int32_t dim,
+                        const np_search_params* params, const int64_t* subset, int64_t subset_len, int64_t* out_ids,
+                        float* out_scores, int32_t* out_counts, np_stats* stats) {
+  clear_error();
+  if (stats) memset(stats, 0, sizeof *stats);
+  NP_TRY(validate(ix, B, dim, params));
+  if (B == 0) return NP_OK;
+  if (!queries || !q_tok_offsets || !out_counts || (params->top_k > 0 && (!out_ids || !out_scores))) {
+    set_error("Search failed: NULL buffer");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (subset_len > 0 && !subset) {
+    set_error("Search failed: subset_len > 0 but subset is NULL");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (q_tok_offsets[0] != 0) {
+    set_error("Shape error: q_tok_offsets[0] must be 0");
+    return NP_ERR_SHAPE;
+  }
+  for (int b = 0; b < B; ++b)
+    if (q_tok_offsets[b + 1] < q_tok_offsets[b]) {
+      set_error("Shape error: q_tok_offsets must be non-decreasing");
+      return NP_ERR_SHAPE;
+    }
+  DeviceGuard g(ix->device);
+  CallState cs;
+  NP_TRY(acquire_context(ix, &cs.ctx));
+  struct Rel {
+    const np_index* ix;
+    Context* c;
+    ~Rel() { release_context(ix, c); }
+  } rel{ix, cs.ctx};
+  Workspace& w = *cs.ctx->ws;
+  NP_TRY(begin_use(&cs, nullptr));
+  hipStream_t st = cs.stream;
+  const int64_t ntok = q_tok_offsets[B];
+  const int topk = params->top_k;
+  NP_TRY(w.q.reserve((size_t)std::max<int64_t>(ntok, 1) * dim * 4));
+  NP_TRY(w.qoff.reserve((size_t)(B + 1) * 4));
+  if (subset_len > 0) NP_TRY(w.subset.reserve((size_t)subset_len * 8));
+  // results of the whole batch land in one pinned staging area
+  const size_t ob_ids = (size_t)B * std::max(topk, 1) * 8, ob_sc = (size_t)B * std::max(topk, 1) * 4,
+               ob_cnt = (size_t)B * 4;
+  NP_TRY(w.pin(ob_ids + ob_sc + ob_cnt + sizeof(Counters) + 64));
+  DevBuf& oi = w.out_ids;   // reserved per slice in phase_a; reserve for the whole batch here
+  NP_TRY(oi.reserve(ob_ids));
+  NP_TRY(w.out_scores.reserve(ob_sc));
+  NP_TRY(w.out_counts.reserve(ob_cnt));
+  if (ntok > 0) NP_HIP(hipMemcpyAsync(w.q.p, queries, (size_t)ntok * dim * 4, hipMemcpyHostToDevice, st));
+  NP_HIP(hipMemcpyAsync(w.qoff.p, q_tok_offsets, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
+  if (subset_len > 0) NP_HIP(hipMemcpyAsync(w.subset.p, subset, (size_t)subset_len * 8, hipMemcpyHostToDevice, st));
+
+  // slices: each slice's outputs go to its rows of the batch-wide output buffers
+  const int S = slice_size(ix, q_tok_offsets, B);
+  np_stats acc;
+  memset(&acc, 0, sizeof acc);
+  char* pin = (char*)w.h_pin;
+  int64_t* h_ids = (int64_t*)pin;
+  float* h_sc = (float*)(pin + ob_ids);
+  int32_t* h_cnt = (int32_t*)(pin + ob_ids + ob_sc);
+  Counters* h_ctr = (Counters*)(pin + ob_ids + ob_sc + ((ob_cnt + 63) / 64) * 64);
+  for (int s0 = 0; s0 < B; s0 += S) {
+    cs.B = std::min(S, B - s0);
+    cs.prm = *params;
+    cs.timed = stats != nullptr;
+    // batch-wide output buffers must survive phase_a's reserve() calls: they only grow, and were
+    // reserved above for the full batch, so phase_a's per-slice reserve is a no-op for them.
+    NP_TRY(phase_a(ix, &cs, w.q.as<float>(), w.qoff.as<int32_t>() + s0, q_tok_offsets + s0,
+                   subset_len > 0 ? w.subset.as<int64_t>() : nullptr, subset_len));
+    NP_TRY(phase_b(ix, &cs, w.qoff.as<int32_t>() + s0, nullptr, w.out_ids.as<int64_t>() + (int64_t)s0 * topk,
+                   w.out_scores.as<float>() + (int64_t)s0 * topk, nullptr, w.out_counts.as<int32_t>() + s0));
+    if (stats) {
+      NP_HIP(hipMemcpyAsync(h_ctr, w.ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+      NP_HIP(hipStreamSynchronize(st));
+      float ms[8] = {0};
+      for (int i = 0; i < 7; ++i) (void)hipEventElapsedTime(&ms[i], cs.ctx->ev[i], cs.ctx->ev[i + 1]);
+      acc.ms_centroid += ms[0];
+      acc.ms_probe += ms[1];
+      acc.ms_candidates += ms[2];
+      acc.ms_approx += ms[3];
+      acc.ms_select += ms[4];
+      acc.ms_exact += ms[5];
+      acc.ms_topk += ms[6];
+      float tot = 0;
+      (void)hipEventElapsedTime(&tot, cs.ctx->ev[0], cs.ctx->ev[7]);
+      acc.ms_total += tot;
+      acc.n_cells += (int64_t)h_ctr->n_cells;
+      acc.n_ivf_ids += (int64_t)h_ctr->n_ivf_ids;
+      acc.n_candidates += (int64_t)h_ctr->n_candidates;
+      acc.n_cand_tokens += (int64_t)h_ctr->n_cand_tokens;
+      acc.n_exact_docs += (int64_t)h_ctr->n_exact_docs;
+      acc.n_exact_tokens += (int64_t)h_ctr->n_exact_tokens;
+    }
+  }
+  if (topk > 0) {
+    NP_HIP(hipMemcpyAsync(h_ids, w.out_ids.p, (size_t)B * topk * 8, hipMemcpyDeviceToHost, st));
+    NP_HIP(hipMemcpyAsync(h_sc, w.out_scores.p, (size_t)B * topk * 4, hipMemcpyDeviceToHost, st));
+  }
+  NP_HIP(hipMemcpyAsync(h_cnt, w.out_counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  NP_TRY(end_use(&cs));
+  NP_HIP(hipStreamSynchronize(st));
+  if (topk > 0) {
+    memcpy(out_ids, h_ids, (size_t)B * topk * 8);
+    memcpy(out_scores, h_sc, (size_t)B * topk * 4);
+  }
+  memcpy(out_counts, h_cnt, (size_t)B * 4);
+  if (stats) {
+    acc.n_queries = B;
+    *stats = acc;
+  }
+  return NP_OK;
+}
+
+// ---- document-sharded two-phase call -------------------------------------------------------------------
+int np_hip_search_phase_a(const np_index* ix, const float* d_queries, const int32_t* d_q_tok_offsets,
+                          const int32_t* h_q_tok_offsets, int32_t B, int32_t dim, const np_search_params* params,
+                          const int64_t* d_subset, int64_t subset_len, uint64_t* d_sel_keys, void* stream,
+                          void** call_state) {
+  clear_error();
+  if (!call_state) {
+    set_error("Search failed: call_state is NULL");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  *call_state = nullptr;
+  NP_TRY(validate(ix, B, dim, params));
+  if (!d_queries || !d_q_tok_offsets || !h_q_tok_offsets || !d_sel_keys) {
+    set_error("Search failed: NULL buffer");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B > slice_size(ix, h_q_tok_offsets, B)) {
+    set_error("Search failed: a sharded call must fit one workspace slice (B=%d); raise workspace_bytes/max_batch", B);
+    return NP_ERR_SEARCH;
+  }
+  DeviceGuard g(ix->device);
+  CallState* cs = new CallState();
+  int rc = acquire_context(ix, &cs->ctx);
+  if (rc != NP_OK) {
+    delete cs;
+    return rc;
+  }
+  cs->B = B;
+  cs->prm = *params;
+  rc = begin_use(cs, stream);
+  if (rc == NP_OK) rc = phase_a(ix, cs, d_queries, d_q_tok_offsets, h_q_tok_offsets, d_subset, subset_len);
+  if (rc == NP_OK && cs->n_sel > 0 && B > 0) {
+    hipError_t e = hipMemcpyAsync(d_sel_keys, cs->ctx->ws->sel_keys.p, (size_t)B * cs->n_sel * 8,
+                                  hipMemcpyDeviceToDevice, cs->stream);
+    if (e != hipSuccess) {
+      set_error("hipMemcpyAsync failed: %s", hipGetErrorString(e));
+      rc = NP_ERR_DEVICE_UNAVAILABLE;
+    }
+  }
+  if (rc != NP_OK) {
+    (void)end_use(cs);
+    release_context(ix, cs->ctx);
+    delete cs;
+    return rc;
+  }
+  // phase B needs the offsets again; keep a device copy owned by the workspace
+  Workspace& w = *cs->ctx->ws;
+  rc = w.qoff.reserve((size_t)(B + 1) * 4);
+  if (rc == NP_OK) {
+    hipError_t e = hipMemcpyAsync(w.qoff.p, d_q_tok_offsets, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, cs->stream);
+    if (e != hipSuccess) rc = NP_ERR_DEVICE_UNAVAILABLE;
+  }
+  if (rc != NP_OK) {
+    (void)end_use(cs);
+    release_context(ix, cs->ctx);
+    delete cs;
+    return rc;
+  }
+  *call_state = cs;
+  return NP_OK;
+}
+
+int np_hip_search_phase_b(const np_index* ix, void* call_state, const uint64_t* d_cut, int64_t* d_out_ids,
+                          float* d_out_scores, uint64_t* d_out_keys, int32_t* d_out_counts, void* stream) {
+  clear_error();
+  CallState* cs = (CallState*)call_state;
+  if (!ix || !cs || !d_out_counts) {
+    set_error("Search failed: NULL argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g(ix->device);
+  if (stream && (hipStream_t)stream != cs->stream) {
+    set_error("Search failed: phase B must use phase A's stream");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  return phase_b(ix, cs, cs->ctx->ws->qoff.as<int32_t>(), d_cut, d_out_ids, d_out_scores, d_out_keys, d_out_counts);
+}
+
+void np_hip_search_end(const np_index* ix, void* call_state) {
+  CallState* cs = (CallState*)call_state;
+  if (!ix || !cs) return;
+  DeviceGuard g(ix->device);
+  (void)end_use(cs);
+  release_context(ix, cs->ctx);
+  delete cs;
+}
+
+int np_hip_select_cut(const np_index* ix, const uint64_t* d_all_keys, int32_t G, int32_t B, int32_t n_sel,
+                      uint64_t* d_cut, void* stream) {
+  clear_error();
+  if (!ix || !d_all_keys || !d_cut || G < 1 || B < 0 || n_sel < 0) {
+    set_error("select_cut: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return NP_OK;
+  DeviceGuard g(ix->device);
+  const int NP2 = next_pow2(std::max(G * n_sel, 1));
+  const size_t lds = (size_t)NP2 * 8;
+  if (lds > 128 * 1024) {
+    set_error("select_cut: G*n_sel = %d exceeds the 16384-key merge window", G * n_sel);
+    return NP_ERR_SEARCH;
+  }
+  if (lds > 48 * 1024)
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_cut_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  select_cut_kernel<<<B, 1024, lds, (hipStream_t)stream>>>(d_all_keys, G, B, n_sel, NP2, d_cut);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+int np_hip_merge_topk(const np_index* ix, const int64_t* d_ids, const float* d_scores, const uint64_t* d_keys,
+                      const int32_t* d_counts, int32_t G, int32_t B, int32_t top_k, int64_t* d_out_ids,
+                      float* d_out_scores, int32_t* d_out_counts, void* stream) {
+  clear_error();
+  if (!ix || !d_ids || !d_scores || !d_keys || !d_counts || !d_out_counts || G < 1 || B < 0 || top_k < 0) {
+    set_error("merge_topk: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return NP_OK;
+  DeviceGuard g(ix->device);
+  merge_topk_kernel<<<B, 256, 0, (hipStream_t)stream>>>(d_ids, d_scores, d_keys, d_counts, G, B, top_k, d_out_ids,
+                                                        d_out_scores, d_out_counts);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+// ---- N2: decompress_documents (index.rs:1197-1245) ---------------------------------------------------------
+int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int64_t n_docs, float* out_embeddings,
+                                int64_t out_capacity_rows, int64_t* out_lengths) {
+  clear_error();
+  if (!ix || (n_docs > 0 && (!doc_ids || !out_lengths)) || n_docs < 0) {
+    set_error("decompress_documents: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g(ix->device);
+  std::vector<int64_t> off((size_t)ix->n_docs + 1);
+  NP_HIP(hipMemcpy(off.data(), ix->d_doc_offsets, off.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<int64_t> toks;
+  for (int64_t i = 0; i < n_docs; ++i) {
+    const int64_t d = doc_ids[i] - ix->doc_begin;
+    if (d < 0 || d >= ix->n_docs) {  // index.rs:1202-1204: out-of-range ids contribute length 0
+      out_lengths[i] = 0;
+      continue;
+    }
+    out_lengths[i] = off[d + 1] - off[d];
+    if (out_embeddings)
+      for (int64_t t = off[d]; t < off[d + 1]; ++t) toks.push_back(t);
+  }
+  if (!out_embeddings || toks.empty()) return NP_OK;
+  if ((int64_t)toks.size() > out_capacity_rows) {
+    set_error("decompress_documents: output holds %lld rows, %zu needed", (long long)out_capacity_rows, toks.size());
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  int64_t* d_tok = nullptr;
+  float* d_out = nullptr;
+  NP_HIP(hipMalloc(&d_tok, toks.size() * 8));
+  hipError_t e = hipMalloc(&d_out, toks.size() * (size_t)ix->dim * 4);
+  if (e != hipSuccess) {
+    (void)hipFree(d_tok);
+    set_error("hipMalloc failed: %s", hipGetErrorString(e));
+    return NP_ERR_OUT_OF_MEMORY;
+  }
+  e = hipMemcpy(d_tok, toks.data(), toks.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    decompress_kernel<<<(unsigned)((toks.size() + 3) / 4), 256>>>(d_tok, (int64_t)toks.size(), ix->dim, ix->nbits,
+                                                                  ix->pd, ix->d_centroids, ix->d_wlut, ix->d_codes,
+                                                                  ix->d_residuals, d_out);
+    e = hipMemcpy(out_embeddings, d_out, toks.size() * (size_t)ix->dim * 4, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_tok);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) {
+    set_error("decompress_documents failed: %s", hipGetErrorString(e));
+    return NP_ERR_DEVICE_UNAVAILABLE;
+  }
+  return NP_OK;
+}
+
+// ---- stage-level trace of one query (parity tests) -----------------------------------------------------------
+int np_hip_debug_trace(const np_index* ix, const float* query, int32_t n_tokens, int32_t dim,
+                       const np_search_params* params, const int64_t* subset, int64_t subset_len, int64_t* cells,
+                       int64_t cap_cells, int64_t* n_cells, int64_t* cand, float* approx, int64_t cap_cand,
+                       int64_t* n_cand, int64_t* sel, float* sel_exact, int64_t cap_sel, int64_t* n_sel) {
+  clear_error();
+  NP_TRY(validate(ix, 1, dim, params));
+  if (!query || n_tokens < 0) {
+    set_error("debug_trace: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g(ix->device);
+  CallState cs;
+  NP_TRY(acquire_context(ix, &cs.ctx));
+  struct Rel {
+    const np_index* ix;
+    Context* c;
+    ~Rel() { release_context(ix, c); }
+  } rel{ix, cs.ctx};
+  Workspace& w = *cs.ctx->ws;
+  NP_TRY(begin_use(&cs, nullptr));
+  hipStream_t st = cs.stream;
+  int32_t h_off[2] = {0, n_tokens};
+  NP_TRY(w.q.reserve((size_t)std::max(n_tokens, 1) * dim * 4));
+  NP_TRY(w.qoff.reserve(8));
+  if (subset_len > 0) NP_TRY(w.subset.reserve((size_t)subset_len * 8));
+  if (n_tokens > 0) NP_HIP(hipMemcpyAsync(w.q.p, query, (size_t)n_tokens * dim * 4, hipMemcpyHostToDevice, st));
+  NP_HIP(hipMemcpyAsync(w.qoff.p, h_off, 8, hipMemcpyHostToDevice, st));
+  if (subset_len > 0) NP_HIP(hipMemcpyAsync(w.subset.p, subset, (size_t)subset_len * 8, hipMemcpyHostToDevice, st));
+  cs.B = 1;
+  cs.prm = *params;
+  NP_TRY(phase_a(ix, &cs, w.q.as<float>(), w.qoff.as<int32_t>(), h_off, subset_len > 0 ? w.subset.as<int64_t>() : nullptr,
+                 subset_len));
+  NP_TRY(phase_b(ix, &cs, w.qoff.as<int32_t>(), nullptr, w.out_ids.as<int64_t>(), w.out_scores.as<float>(),
+                 w.out_keys.as<uint64_t>(), w.out_counts.as<int32_t>()));
+  NP_TRY(end_use(&cs));
+  NP_HIP(hipStreamSynchronize(st));
+  int32_t nc = 0, nd = 0, ns = 0;
+  NP_HIP(hipMemcpy(&nc, w.n_cells.p, 4, hipMemcpyDeviceToHost));
+  NP_HIP(hipMemcpy(&nd, w.n_cand.p, 4, hipMemcpyDeviceToHost));
+  NP_HIP(hipMemcpy(&ns, w.nsel.p, 4, hipMemcpyDeviceToHost));
+  if (n_cells) *n_cells = nc;
+  if (n_cand) *n_cand = nd;
+  if (n_sel) *n_sel = ns;
+  if (cells && nc > 0) {
+    std::vector<uint32_t> t((size_t)nc);
+    NP_HIP(hipMemcpy(t.data(), w.cells.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+    std::sort(t.begin(), t.end());
+    for (int64_t i = 0; i < std::min<int64_t>(nc, cap_cells); ++i) cells[i] = t[(size_t)i];
+  }
+  if (nd > 0 && (cand || approx)) {
+    const int64_t m = std::min<int64_t>(nd, cap_cand);
+    if (cand) {
+      std::vector<uint32_t> t((size_t)m);
+      NP_HIP(hipMemcpy(t.data(), w.cand.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; ++i) cand[i] = (int64_t)t[(size_t)i] + ix->doc_begin;
+    }
+    if (approx) NP_HIP(hipMemcpy(approx, w.approx.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  }
+  if (ns > 0 && (sel || sel_exact)) {
+    const int64_t m = std::min<int64_t>(ns, cap_sel);
+    if (sel) {
+      std::vector<uint32_t> t((size_t)m);
+      NP_HIP(hipMemcpy(t.data(), w.sel_doc.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; ++i) sel[i] = (int64_t)t[(size_t)i] + ix->doc_begin;
+    }
+    if (sel_exact) NP_HIP(hipMemcpy(sel_exact, w.exact.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  }
+  return NP_OK;
+}
+
+}  // extern "C"

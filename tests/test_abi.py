@@ -1,0 +1,110 @@
+"""The C-ABI library: loads, exports every symbol include/nextplaid_hip.h declares, reads the crate's
+on-disk format, and FAILS LOUDLY (no CPU fallback) when no GPU is present.  CPU only: no compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, synth
+
+import next_plaid_amd as npa
+from next_plaid_amd import api
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "nextplaid_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(np_hip_\w+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    L = api.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, f"not exported: {missing}"
+    assert sorted(api.EXPORTS) == declared, "api.EXPORTS must list exactly the header's entry points"
+
+
+def test_struct_sizes_match_header():
+    # natural alignment, no packing surprises between ctypes and the C structs
+    assert C.sizeof(api.np_open_opts) == 32
+    assert C.sizeof(api.np_search_params) == 28
+    assert C.sizeof(api.np_stats) == 8 * 4 + 6 * 8 + 8
+    assert C.sizeof(api.np_info) == 3 * 8 + 2 * 4 + 8 + 3 * 8 + 8 + 2 * 4
+
+
+def test_no_oracle_in_product_path():
+    # the product package must never import / link the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "next-plaid_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "plaid_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_load_missing_dir_is_index_load_error():
+    with pytest.raises(npa.IndexLoadError):
+        npa.MmapIndex.load("/nonexistent/index")
+
+
+def _write(tmp_path, **kw):
+    spec = synth.SynthSpec(num_docs=120, num_centroids=32, dim=64, nbits=4, doc_len_min=0, doc_len_max=12, seed=3)
+    a = synth.generate_arrays(spec)
+    synth.write_index(str(tmp_path), a, chunk_docs=50, **kw)
+    return a
+
+
+def test_loader_parses_reference_layout_then_needs_gpu(tmp_path, gpu_available):
+    _write(tmp_path)
+    assert sorted(os.listdir(tmp_path))[:3] == ["0.codes.npy", "0.metadata.json", "0.residuals.npy"]
+    if gpu_available:
+        ix = npa.MmapIndex.load(str(tmp_path))
+        assert ix.num_documents() == 120
+    else:
+        # files parse (no IndexLoad/Shape error), then the missing device is reported, not papered over
+        with pytest.raises(npa.DeviceUnavailableError):
+            npa.MmapIndex.load(str(tmp_path))
+
+
+def test_loader_error_codes(tmp_path):
+    a = _write(tmp_path)
+    os.remove(tmp_path / "bucket_weights.npy")            # codec.rs:428-431
+    with pytest.raises(npa.CodecError):
+        npa.MmapIndex.load(str(tmp_path))
+    np.save(tmp_path / "bucket_weights.npy", a["bucket_weights"])
+    np.save(tmp_path / "1.residuals.npy", a["residuals"][:10, :7])   # wrong packed width
+    with pytest.raises(npa.ShapeError):
+        npa.MmapIndex.load(str(tmp_path))
+    (tmp_path / "centroids.npy").write_bytes(b"not an npy file at all")
+    with pytest.raises(npa.IndexLoadError):
+        npa.MmapIndex.load(str(tmp_path))
+
+
+def test_loader_accepts_fastplaid_i64_ivf_lengths(tmp_path, gpu_available):
+    a = _write(tmp_path)
+    np.save(tmp_path / "ivf_lengths.npy", a["ivf_lengths"].astype("<i8"))   # mmap.rs:1780-1789
+    exc = None if gpu_available else npa.DeviceUnavailableError
+    if exc:
+        with pytest.raises(exc):
+            npa.MmapIndex.load(str(tmp_path))
+    else:
+        npa.MmapIndex.load(str(tmp_path))
+
+
+def test_search_without_gpu_raises(gpu_available):
+    if gpu_available:
+        pytest.skip("GPU present")
+    spec = synth.SynthSpec(num_docs=20, num_centroids=8, dim=64, doc_len_min=4, doc_len_max=4)
+    a = synth.generate_arrays(spec)
+    with pytest.raises(npa.DeviceUnavailableError):
+        npa.MmapIndex.from_arrays(a["centroids"], a["bucket_weights"], a["ivf"], a["ivf_lengths"], a["doc_lengths"],
+                                  a["codes"], a["residuals"], a["nbits"])
+    assert npa.device_count() == 0
+
+
+def test_params_mirror_reference_defaults():
+    p = npa.SearchParameters()          # search.rs:58-69
+    assert (p.batch_size, p.n_full_scores, p.top_k, p.n_ivf_probe, p.centroid_batch_size,
+            p.centroid_score_threshold) == (2000, 4096, 10, 8, 100_000, 0.4)
+    c = p._c()
+    assert c.has_threshold == 1 and abs(c.centroid_score_threshold - 0.4) < 1e-7
+    assert api.lib().np_hip_n_sel(C.byref(c)) == 1024          # max(4096/4, 10)
+    assert api.lib().np_hip_n_sel(C.byref(npa.SearchParameters(n_full_scores=8, top_k=10)._c())) == 8
