@@ -1,0 +1,174 @@
+"""Document-sharded search: one process per GPU, RCCL all-gather of per-shard rank keys / top-k.
+
+The reference has no multi-GPU path; this is the north_star's "index shards by
+document across the GPUs of one node with a final RCCL all-gather of per-shard top-k over xGMI",
+done so that the merged result is IDENTICAL to the unsharded search (search.rs:460-515):
+
+  phase A  every shard runs S1-S5 locally and emits its best n_sel candidates as 64-bit rank keys
+           (approx score, then ascending global doc id -- the reference's stable-sort order)
+  gather 1 all-gather keys  [B, n_sel] x u64 per rank   (8 MB at B=64, n_sel=1024, G=8: latency-bound)
+  cut      every rank takes the global n_sel-th key per query (np_hip_select_cut)
+  phase B  exact MaxSim only for local candidates with key >= cut  -> local top-k triples
+  gather 2 all-gather (id, score, key, count) packed in one i64 buffer [B, 3k+1]
+  merge    top-k by (exact score desc, approx rank) == the reference's final stable sort
+
+Two small collectives per batch; no payload-sized traffic ever crosses xGMI.  With torch.distributed
+backend "nccl" this IS RCCL on ROCm; the same code runs over "gloo" on CPU tensors in the tests with
+an oracle-backed shard backend (tests/test_dist_cpu.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+
+class HipShardBackend:
+    """One shard's device work through the C ABI, on torch tensors resident on the shard's GPU."""
+
+    def __init__(self, index: "api.MmapIndex", device=None, stream=None):
+        import torch
+        self.torch = torch
+        self.index = index
+        self.device = torch.device("cuda", index.info.device) if device is None else device
+        # a NON-default stream: the C ABI treats a NULL stream as "use the context's own stream",
+        # which would not be ordered with torch work on the legacy default stream
+        self.stream = torch.cuda.Stream(self.device) if stream is None else stream
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def n_sel(self, params):
+        return int(api.lib().np_hip_n_sel(C.byref(params._c())))
+
+    def _stream(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def phase_a(self, d_q, d_qoff, h_qoff, params):
+        t = self.torch
+        B = len(h_qoff) - 1
+        ns = max(self.n_sel(params), 1)
+        keys = t.zeros((B, ns), dtype=t.int64, device=self.device)
+        st = C.c_void_p()
+        p = params._c()
+        hq = np.ascontiguousarray(h_qoff, np.int32)
+        api._check(api.lib().np_hip_search_phase_a(
+            self.index._h, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_qoff.data_ptr()), hq.ctypes.data_as(C.c_void_p),
+            B, self.index.embedding_dim(), C.byref(p), None, -1, C.c_void_p(keys.data_ptr()), self._stream(),
+            C.byref(st)))
+        return keys[:, : self.n_sel(params)], (st, B, params)
+
+    def select_cut(self, all_keys):
+        t = self.torch
+        G, B, ns = all_keys.shape
+        cut = t.zeros(B, dtype=t.int64, device=self.device)
+        all_keys = all_keys.contiguous()
+        api._check(api.lib().np_hip_select_cut(self.index._h, C.c_void_p(all_keys.data_ptr()), G, B, ns,
+                                               C.c_void_p(cut.data_ptr()), self._stream()))
+        return cut
+
+    def phase_b(self, state, cut):
+        t = self.torch
+        st, B, params = state
+        k = max(params.top_k, 1)
+        packed = t.zeros((B, 3 * k + 1), dtype=t.int64, device=self.device)   # ids | keys | scores(bits) | count
+        ids = t.zeros((B, k), dtype=t.int64, device=self.device)
+        sc = t.zeros((B, k), dtype=t.float32, device=self.device)
+        keys = t.zeros((B, k), dtype=t.int64, device=self.device)
+        cnt = t.zeros(B, dtype=t.int32, device=self.device)
+        api._check(api.lib().np_hip_search_phase_b(
+            self.index._h, st, None if cut is None else C.c_void_p(cut.data_ptr()), C.c_void_p(ids.data_ptr()),
+            C.c_void_p(sc.data_ptr()), C.c_void_p(keys.data_ptr()), C.c_void_p(cnt.data_ptr()), self._stream()))
+        packed[:, :k] = ids
+        packed[:, k:2 * k] = keys
+        packed[:, 2 * k:3 * k] = sc.view(t.int32).to(t.int64)
+        packed[:, 3 * k] = cnt.to(t.int64)
+        return packed
+
+    def end(self, state):
+        api.lib().np_hip_search_end(self.index._h, state[0])
+
+    def merge(self, all_packed, top_k):
+        t = self.torch
+        G, B, _ = all_packed.shape
+        k = max(top_k, 1)
+        ids = all_packed[:, :, :k].contiguous()
+        keys = all_packed[:, :, k:2 * k].contiguous()
+        sc = all_packed[:, :, 2 * k:3 * k].to(t.int32).view(t.float32).contiguous()
+        cnt = all_packed[:, :, 3 * k].to(t.int32).contiguous()
+        o_ids = t.zeros((B, k), dtype=t.int64, device=self.device)
+        o_sc = t.zeros((B, k), dtype=t.float32, device=self.device)
+        o_cnt = t.zeros(B, dtype=t.int32, device=self.device)
+        api._check(api.lib().np_hip_merge_topk(
+            self.index._h, C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(keys.data_ptr()),
+            C.c_void_p(cnt.data_ptr()), G, B, top_k, C.c_void_p(o_ids.data_ptr()), C.c_void_p(o_sc.data_ptr()),
+            C.c_void_p(o_cnt.data_ptr()), self._stream()))
+        return o_ids, o_sc, o_cnt
+
+
+class ShardedSearcher:
+    """Runs the two-collective protocol over `backends` (the shards this process holds, normally
+    one) and, if `group`/torch.distributed is initialised, over all ranks.  Rank r holds the
+    shards r*len(backends) ... of world_size*len(backends) in rank order."""
+
+    def __init__(self, backends, use_dist: bool | None = None, group=None):
+        import torch
+        self.torch = torch
+        self.backends = list(backends)
+        self.group = group
+        if use_dist is None:
+            use_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.use_dist = use_dist
+
+    def _all_gather(self, local):  # local: [L, ...] stacked over this process's shards -> [G, ...]
+        if not self.use_dist:
+            return local
+        import torch.distributed as dist
+        ws = dist.get_world_size(self.group)
+        out = [self.torch.empty_like(local) for _ in range(ws)]
+        dist.all_gather(out, local.contiguous(), group=self.group)
+        return self.torch.cat(out, 0)
+
+    def search_batch_device(self, d_q, d_qoff, h_qoff, params):
+        """Queries already resident on every shard's device (the host broadcasts them).
+        d_q / d_qoff: one tensor per local backend (or a single tensor when there is one)."""
+        with self.backends[0].stream_ctx():
+            return self._search(d_q, d_qoff, h_qoff, params)
+
+    def _search(self, d_q, d_qoff, h_qoff, params):
+        t = self.torch
+        single = not isinstance(d_q, (list, tuple))
+        dqs = [d_q] if single else list(d_q)
+        dos = [d_qoff] if single else list(d_qoff)
+        keys, states = [], []
+        for be, q, o in zip(self.backends, dqs, dos):
+            k, st = be.phase_a(q, o, h_qoff, params)
+            keys.append(k)
+            states.append(st)
+        packed = []
+        try:
+            all_keys = self._all_gather(t.stack([k.to(keys[0].device) for k in keys], 0))
+            for be, st in zip(self.backends, states):
+                cut = be.select_cut(all_keys.to(be.device))
+                packed.append(be.phase_b(st, cut))
+        finally:
+            for be, st in zip(self.backends, states):
+                be.end(st)
+        all_packed = self._all_gather(t.stack([p.to(packed[0].device) for p in packed], 0))
+        return self.backends[0].merge(all_packed.to(self.backends[0].device), params.top_k)
+
+    def search_batch(self, queries, params):
+        """Host-side convenience: numpy queries in, list of QueryResult out (rank-identical)."""
+        t = self.torch
+        qs = [np.ascontiguousarray(q, np.float32) for q in queries]
+        off = np.zeros(len(qs) + 1, np.int32)
+        off[1:] = np.cumsum([q.shape[0] for q in qs])
+        flat = np.concatenate(qs, 0)
+        with self.backends[0].stream_ctx():
+            dq = [t.from_numpy(flat).to(be.device) for be in self.backends]
+            do = [t.from_numpy(off).to(be.device) for be in self.backends]
+            ids, sc, cnt = self._search(dq, do, off, params)
+            ids, sc, cnt = ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        return [api.QueryResult(i, ids[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(len(qs))]

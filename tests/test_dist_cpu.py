@@ -1,0 +1,67 @@
+"""world_size-2 gloo test of the document-sharded protocol (next_plaid_amd/dist.py) on CPU: the
+two all-gathers, the global cut and the merge reproduce the UNSHARDED oracle result exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import O, oracle_index, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+SPEC = dict(num_docs=1200, num_centroids=128, dim=64, nbits=4, doc_len_min=0, doc_len_max=30, seed=123)
+
+
+def _worker(rank, world, port, top_k, nfs, thr):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from shard_oracle_backend import OracleShardBackend
+        from next_plaid_amd.dist import ShardedSearcher
+        import next_plaid_amd as npa
+        spec = synth.SynthSpec(**SPEC)
+        a = synth.generate_arrays(spec)
+        n = spec.num_docs
+        b0, b1 = n * rank // world, n * (rank + 1) // world
+        be = OracleShardBackend(a, b0, b1)
+        qs, _ = synth.make_queries(spec, 5, n_tokens=12, cen=a["centroids"])
+        off = np.zeros(len(qs) + 1, np.int32)
+        off[1:] = np.cumsum([q.shape[0] for q in qs])
+        flat = torch.from_numpy(np.concatenate(qs, 0))
+        p = npa.SearchParameters(n_full_scores=nfs, top_k=top_k, n_ivf_probe=4, centroid_score_threshold=thr)
+        ids, sc, cnt = ShardedSearcher([be]).search_batch_device(flat, torch.from_numpy(off), off, p)
+        full = oracle_index(a)
+        po = O.SearchParameters(n_full_scores=nfs, top_k=top_k, n_ivf_probe=4, centroid_score_threshold=thr)
+        for i, q in enumerate(qs):
+            r = full.search(q, po)
+            assert cnt[i] == len(r.passage_ids), (rank, i, int(cnt[i]), len(r.passage_ids))
+            assert np.array_equal(ids[i, : cnt[i]].numpy(), r.passage_ids), (rank, i)
+            assert np.array_equal(sc[i, : cnt[i]].numpy(), r.scores), (rank, i)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("top_k,nfs,thr", [(5, 64, None), (10, 16, 0.3)])
+def test_sharded_protocol_world2_gloo(top_k, nfs, thr):
+    mp.spawn(_worker, args=(2, _free_port(), top_k, nfs, thr), nprocs=2, join=True)
+
+
+def test_shard_range_partition():
+    # contiguous doc ranges [N*r/G, N*(r+1)/G) cover [0,N) without overlap (np_open_opts.shard_*)
+    for n in (0, 1, 7, 1000003):
+        for g in (1, 2, 3, 8):
+            edges = [n * r // g for r in range(g + 1)]
+            assert edges[0] == 0 and edges[-1] == n and all(b >= a for a, b in zip(edges, edges[1:]))

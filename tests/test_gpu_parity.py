@@ -1,0 +1,249 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Needs a real MI355X.
+
+Bar (prompt section 3): bit-exact for integer / index work -- probed cells, candidate ids,
+approximate scores (fp32, same k-ordered FMA chain and q-ordered sum as the oracle) and the selected
+documents -- and fp tolerance for the exact MaxSim scores: RTOL_F32 = 2e-5 relative in fp32 mode
+(summation order only), RTOL_BF16 = 1e-3 in bf16 mode (north_star's bound).
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, O, RTOL_BF16, RTOL_F32, assert_ranking_close, hip_index, make_arrays, oracle_index,
+                     synth, to_oracle_params)
+
+import next_plaid_amd as npa
+
+pytestmark = pytest.mark.gpu
+
+import importlib.util
+
+_s = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+MG = importlib.util.module_from_spec(_s)
+_s.loader.exec_module(MG)
+
+
+def P(**kw):
+    return npa.SearchParameters(**kw)
+
+
+def check_trace(hx, ox, q, p, subset=None, what="", exact_rtol=RTOL_F32, bitexact_probe=True):
+    """Stage-by-stage comparison for one query; returns the oracle result."""
+    tr = hx.debug_trace(q, p, subset)
+    r = ox.search(q, to_oracle_params(p), subset, trace=True)
+    t = r.trace
+    if bitexact_probe:
+        assert np.array_equal(tr["cells"], t.cells), f"{what}: S2 cells differ: hip {tr['cells'][:20]} oracle {t.cells[:20]}"
+        assert np.array_equal(tr["cand"], t.cand), f"{what}: S3 candidates differ ({tr['cand'].size} vs {t.cand.size})"
+        bad = np.nonzero(tr["approx"].view(np.uint32) != t.approx.view(np.uint32))[0]
+        assert bad.size == 0, f"{what}: S4 approx not bit-exact at {bad[:5]}: {tr['approx'][bad[:5]]} vs {t.approx[bad[:5]]}"
+        assert np.array_equal(tr["sel"], t.sel), f"{what}: S5 selection/order differs"
+        tol = exact_rtol * np.maximum(np.abs(t.sel_exact), 1.0)
+        assert np.all(np.abs(tr["sel_exact"] - t.sel_exact) <= tol), \
+            f"{what}: S6 exact scores differ, max rel {np.max(np.abs(tr['sel_exact'] - t.sel_exact) / np.maximum(np.abs(t.sel_exact), 1))}"
+    return r
+
+
+@pytest.fixture(scope="module")
+def mid():
+    spec, a = make_arrays(num_docs=20000, num_centroids=4096, dim=128, nbits=4, doc_len_min=40, doc_len_max=120, seed=77)
+    qs, src = synth.make_queries(spec, 64, n_tokens=32, cen=a["centroids"])
+    return spec, a, oracle_index(a), hip_index(a), qs, src
+
+
+def test_device_present():
+    assert npa.device_count() >= 1
+
+
+def test_stages_mid(mid):
+    spec, a, ox, hx, qs, src = mid
+    for thr in (0.4, None):
+        p = P(n_full_scores=512, top_k=10, n_ivf_probe=8, centroid_score_threshold=thr)
+        for qi in range(4):
+            check_trace(hx, ox, qs[qi], p, what=f"thr={thr} q{qi}")
+
+
+def test_batch_mid_fp32_and_bf16(mid):
+    spec, a, ox, hx, qs, src = mid
+    for prec, rtol in ((0, RTOL_F32), (1, RTOL_BF16)):
+        p = P(n_full_scores=1024, top_k=10, n_ivf_probe=16, precision=prec)
+        res = hx.search_batch(qs, p)
+        ref = ox.search_batch(qs, to_oracle_params(p))
+        assert len(res) == 64
+        for i, (r, o) in enumerate(zip(res, ref)):
+            assert r.query_id == i
+            assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, rtol, f"prec={prec} q{i}")
+            assert r.passage_ids[0] == src[i]
+        st = hx.last_stats
+        assert st["n_queries"] == 64 and st["n_candidates"] > 0 and st["n_exact_docs"] > 0 and st["ms_total"] > 0
+
+
+def test_search_equals_batch_of_one(mid):
+    spec, a, ox, hx, qs, src = mid
+    p = P(n_full_scores=256, top_k=7, n_ivf_probe=4)
+    r1 = hx.search(qs[3], p)
+    rb = hx.search_batch(qs[:8], p)[3]
+    assert r1.query_id == 0 and np.array_equal(r1.passage_ids, rb.passage_ids) and np.array_equal(r1.scores, rb.scores)
+
+
+@pytest.mark.parametrize("case", [c[0] for c in MG.CASES if not c[0].startswith("batched")])
+def test_golden_search(case):
+    spec = synth.SynthSpec(**MG.GOLDEN_SPEC)
+    a = synth.generate_arrays(spec)
+    hx = hip_index(a)
+    gold = np.load(os.path.join(GOLDEN, "search_2000.npz"))
+    name, kw, sub = next(c for c in MG.CASES if c[0] == case)
+    p = P(**kw)
+    subset = None if sub is None else np.arange(0, spec.num_docs, 2, dtype=np.int64)
+    for qi, q in enumerate(gold["queries"]):
+        tr = hx.debug_trace(q, p, subset)
+        assert np.array_equal(tr["cells"], gold[f"{name}_q{qi}_cells"]), f"{name} q{qi} cells"
+        assert np.array_equal(tr["cand"], gold[f"{name}_q{qi}_cand"]), f"{name} q{qi} cand"
+        r = hx.search(q, p, subset)
+        assert_ranking_close(r.passage_ids, r.scores, gold[f"{name}_q{qi}_ids"], gold[f"{name}_q{qi}_scores"],
+                             RTOL_F32, f"{name} q{qi}")
+
+
+@pytest.mark.parametrize("dim,nbits,K", [(64, 4, 100), (64, 2, 70), (96, 4, 257), (96, 2, 64), (32, 4, 33),
+                                         (128, 2, 1000)])
+def test_shapes_ragged_edges(dim, nbits, K):
+    # ragged docs incl. EMPTY ones, K not a multiple of 32/64, short and long queries, top_k > candidates
+    spec, a = make_arrays(num_docs=700, num_centroids=K, dim=dim, nbits=nbits, doc_len_min=0, doc_len_max=70, seed=dim + nbits)
+    assert (a["doc_lengths"] == 0).any()
+    ox, hx = oracle_index(a), hip_index(a)
+    for ntok in (1, 5, 32, 48, 100):
+        qs, _ = synth.make_queries(spec, 3, n_tokens=ntok, cen=a["centroids"])
+        for thr, nprobe, nfs, topk in ((None, 3, 64, 5), (0.35, 8, 256, 300), (None, 64, 40, 10)):
+            p = P(n_full_scores=nfs, top_k=topk, n_ivf_probe=nprobe, centroid_score_threshold=thr)
+            for qi, q in enumerate(qs):
+                check_trace(hx, ox, q, p, what=f"d{dim} b{nbits} K{K} Lq{ntok} thr{thr} np{nprobe} q{qi}")
+            res = hx.search_batch(qs, p)
+            ref = ox.search_batch(qs, to_oracle_params(p))
+            for r, o in zip(res, ref):
+                assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32)
+
+
+def test_mixed_length_batch_and_slicing():
+    spec, a = make_arrays(num_docs=3000, num_centroids=512, dim=128, nbits=4, doc_len_min=10, doc_len_max=60, seed=8)
+    ox = oracle_index(a)
+    hx = hip_index(a, max_batch=5)          # forces 13 queries through 3 slices
+    g = np.random.default_rng(1)
+    qs = []
+    for i in range(13):
+        q, _ = synth.make_queries(spec, 1, n_tokens=int(g.integers(1, 70)), cen=a["centroids"], first_query=i)
+        qs.append(q[0])
+    p = P(n_full_scores=128, top_k=6, n_ivf_probe=6)
+    res = hx.search_batch(qs, p)
+    ref = ox.search_batch(qs, to_oracle_params(p))
+    for i, (r, o) in enumerate(zip(res, ref)):
+        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32, f"q{i}")
+
+
+def test_nan_inf_query_tokens():
+    spec, a = make_arrays(num_docs=1500, num_centroids=256, dim=128, nbits=4, doc_len_min=10, doc_len_max=40, seed=21)
+    ox, hx = oracle_index(a), hip_index(a)
+    qs, _ = synth.make_queries(spec, 2, n_tokens=8, cen=a["centroids"])
+    q = qs[0].copy()
+    q[2, :] = np.nan            # a NaN token: contributes 0, never selects cells ahead of finite scores
+    q[5, 7] = np.inf
+    for thr in (None, 0.4):
+        p = P(n_full_scores=128, top_k=5, n_ivf_probe=4, centroid_score_threshold=thr)
+        r = hx.search(q, p)
+        o = ox.search(q, to_oracle_params(p))
+        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32, f"nan thr={thr}")
+        assert np.all(np.isfinite(r.scores))
+
+
+def test_subset_filter_and_empty_subset():
+    # filtering_integration.rs:69-117, :320-349 through the HIP path
+    spec, a = make_arrays(num_docs=2000, num_centroids=256, dim=128, nbits=4, doc_len_min=10, doc_len_max=40, seed=31)
+    ox, hx = oracle_index(a), hip_index(a)
+    qs, _ = synth.make_queries(spec, 4, n_tokens=16, cen=a["centroids"])
+    p = P(n_full_scores=256, top_k=5, n_ivf_probe=4, centroid_score_threshold=None)
+    for subset in (np.arange(0, 2000, 2), np.array([5, 17, 1999, 4000, -3]), np.arange(100)):
+        subset = subset.astype(np.int64)
+        for qi, q in enumerate(qs):
+            check_trace(hx, ox, q, p, subset, what=f"subset n={subset.size} q{qi}")
+            r = hx.search(q, p, subset)
+            assert all(pid in set(subset.tolist()) for pid in r.passage_ids)
+    r = hx.search(qs[0], p, np.zeros(0, np.int64))
+    assert r.passage_ids.size == 0 and r.scores.size == 0
+
+
+def test_decompress_documents_matches_codec():
+    # N2 row: index.rs:1159-1245 / codec.rs:423-470
+    spec, a = make_arrays(num_docs=300, num_centroids=128, dim=96, nbits=2, doc_len_min=0, doc_len_max=30, seed=13)
+    ox, hx = oracle_index(a), hip_index(a)
+    ids = [0, 7, 299, 12, 5000]
+    embs, lens = hx.decompress_documents(ids)
+    assert list(lens[:4]) == [int(a["doc_lengths"][i]) for i in ids[:4]] and lens[4] == 0
+    ref = np.concatenate([ox.get_document_embeddings(i) for i in ids[:4]])
+    assert embs.shape == ref.shape and np.allclose(embs, ref, rtol=0, atol=3e-7)
+
+
+def test_on_disk_index_equals_arrays(tmp_path):
+    spec, a = make_arrays(num_docs=900, num_centroids=128, dim=128, nbits=4, doc_len_min=5, doc_len_max=50, seed=17)
+    synth.write_index(str(tmp_path), a, chunk_docs=250)
+    hd, ha = npa.MmapIndex.load(str(tmp_path)), hip_index(a)
+    assert hd.num_documents() == 900 and hd.num_partitions() == 128 and hd.embedding_dim() == 128
+    assert hd.num_embeddings() == int(a["doc_lengths"].sum()) and abs(hd.avg_doclen() - a["doc_lengths"].mean()) < 1e-9
+    e1, e2 = hd.export(), ha.export()
+    for k in ("doc_lengths", "codes", "residuals", "ivf", "ivf_lengths"):
+        assert np.array_equal(e1[k], e2[k]) and np.array_equal(e1[k], np.asarray(a[k])), k
+    qs, _ = synth.make_queries(spec, 3, n_tokens=32, cen=a["centroids"])
+    p = P(n_full_scores=128, top_k=10, n_ivf_probe=8)
+    for r1, r2 in zip(hd.search_batch(qs, p), ha.search_batch(qs, p)):
+        assert np.array_equal(r1.passage_ids, r2.passage_ids) and np.array_equal(r1.scores, r2.scores)
+
+
+def test_synth_device_generator_matches_numpy_spec():
+    spec = synth.SynthSpec(num_docs=5000, num_centroids=1024, dim=128, nbits=4, doc_len_min=20, doc_len_max=90, seed=99)
+    a = synth.generate_arrays(spec)
+    hx = npa.MmapIndex.synth(spec, centroids=a["centroids"])
+    e = hx.export()
+    for k in ("doc_lengths", "codes", "residuals", "ivf", "ivf_lengths"):
+        assert np.array_equal(e[k], np.asarray(a[k])), k
+    # a shard of it
+    hs = npa.MmapIndex.synth(spec, centroids=a["centroids"], shard_rank=1, shard_count=3)
+    b0, b1 = hs.info.shard_doc_begin, hs.info.shard_doc_end
+    assert (b0, b1) == (5000 * 1 // 3, 5000 * 2 // 3)
+    es = hs.export()
+    assert np.array_equal(es["doc_lengths"], a["doc_lengths"][b0:b1])
+    off = np.concatenate([[0], np.cumsum(a["doc_lengths"])])
+    assert np.array_equal(es["codes"], a["codes"][off[b0]:off[b1]])
+    assert np.all((es["ivf"] >= b0) & (es["ivf"] < b1))
+
+
+def test_errors_through_the_abi(mid):
+    spec, a, ox, hx, qs, src = mid
+    with pytest.raises(npa.ShapeError):
+        hx.search(np.zeros((4, 64), np.float32), P())
+    with pytest.raises(npa.SearchError):
+        hx.search(qs[0], P(n_ivf_probe=0))
+    spec2, a2 = make_arrays(num_docs=50, num_centroids=16, dim=48, nbits=4, doc_len_min=4, doc_len_max=4, seed=1)
+    h48 = hip_index(a2)      # loads fine; dim 48 has no HIP kernel -> Shape error, never a silent fallback
+    with pytest.raises(npa.ShapeError):
+        h48.search(np.zeros((4, 48), np.float32), P())
+
+
+def test_concurrent_calls_share_one_index(mid):
+    spec, a, ox, hx, qs, src = mid
+    p = P(n_full_scores=256, top_k=5, n_ivf_probe=8)
+    ref = hx.search_batch(qs[:16], p)
+    out, errs = {}, []
+
+    def work(t):
+        try:
+            out[t] = hx.search_batch(qs[:16], p)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    for t in range(6):
+        for r, o in zip(out[t], ref):
+            assert np.array_equal(r.passage_ids, o.passage_ids) and np.array_equal(r.scores, o.scores)
