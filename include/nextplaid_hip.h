@@ -101,6 +101,7 @@ typedef struct np_stats {
   int64_t n_cand_tokens; /* sum of candidate doc lengths (codes read by S4) */
   int64_t n_exact_docs;  /* documents exact-scored */
   int64_t n_exact_tokens;/* tokens decompressed by S6 */
+  int64_t n_cand_codes;  /* distinct (doc, code) pairs actually gathered by S4 (<= n_cand_tokens) */
   int32_t n_queries;
   int32_t reserved;
 } np_stats;

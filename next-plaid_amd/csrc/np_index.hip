@@ -95,6 +95,8 @@ void destroy_device_index(DeviceIndex* ix) {
   (void)hipFree(ix->d_centroids);
   (void)hipFree(ix->d_wlut);
   (void)hipFree(ix->d_codes);
+  (void)hipFree(ix->d_ucodes);
+  (void)hipFree(ix->d_ulen);
   (void)hipFree(ix->d_residuals);
   (void)hipFree(ix->d_doc_offsets);
   (void)hipFree(ix->d_ivf);
@@ -136,6 +138,67 @@ static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bu
   for (int s = 0; s < nb; ++s) wl[s] = bucket_weights[bitrev((uint32_t)s, ix->nbits)];
   NP_TRY(dev_alloc(&ix->d_wlut, nb, &ix->device_bytes));
   NP_HIP(hipMemcpy(ix->d_wlut, wl.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+  return NP_OK;
+}
+
+
+// ---- derived: per-document distinct codes (one block per document, bitonic sort in LDS) ------------------
+#define NP_UNIQ_MAX 4096
+__global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __restrict__ doc_off,
+                                                           const uint32_t* __restrict__ codes,
+                                                           uint32_t* __restrict__ ucodes, int32_t* __restrict__ ulen) {
+  __shared__ uint32_t s[NP_UNIQ_MAX];
+  __shared__ int s_wave[4];
+  const int64_t d = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t off = doc_off[d];
+  const int len = (int)(doc_off[d + 1] - off);
+  if (len > NP_UNIQ_MAX) {  // very long document: keep the full list (still correct, just not shorter)
+    for (int i = tid; i < len; i += 256) ucodes[off + i] = codes[off + i];
+    if (tid == 0) ulen[d] = len;
+    return;
+  }
+  int n = 1;
+  while (n < len) n <<= 1;
+  for (int i = tid; i < n; i += 256) s[i] = (i < len) ? codes[off + i] : 0xFFFFFFFFu;
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < n; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t a = s[i], c = s[ixj];
+          const bool asc = (i & k) == 0;
+          if (asc ? (a > c) : (a < c)) { s[i] = c; s[ixj] = a; }
+        }
+      }
+    }
+  __syncthreads();
+  int base = 0;
+  for (int i0 = 0; i0 < len; i0 += 256) {
+    const int i = i0 + tid;
+    const bool head = i < len && (i == 0 || s[i] != s[i - 1]);
+    const unsigned long long bal = __ballot(head);
+    if (lane == 0) s_wave[wave] = (int)__popcll(bal);
+    __syncthreads();
+    int before = base;
+    for (int k = 0; k < wave; ++k) before += s_wave[k];
+    if (head) ucodes[off + before + (int)__popcll(bal & ((1ull << lane) - 1ull))] = s[i];
+    base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (tid == 0) ulen[d] = base;
+}
+
+static int build_unique_codes(DeviceIndex* ix) {
+  NP_TRY(dev_alloc(&ix->d_ucodes, (size_t)ix->T, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_ulen, (size_t)ix->n_docs, &ix->device_bytes));
+  for (int64_t d0 = 0; d0 < ix->n_docs; d0 += (int64_t)1 << 30) {
+    const int64_t n = std::min<int64_t>((int64_t)1 << 30, ix->n_docs - d0);
+    unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->d_codes, ix->d_ucodes, ix->d_ulen + d0);
+  }
+  NP_HIP(hipGetLastError());
+  NP_HIP(hipDeviceSynchronize());
   return NP_OK;
 }
 
@@ -270,6 +333,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
     NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
   }
+  NP_TRY(build_unique_codes(ix));
   cleanup.p = nullptr;
   *out = ix;
   return NP_OK;
@@ -495,6 +559,7 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
   else
     ix->n_emb_total = ix->n_docs > 0 ? (int64_t)((double)ix->T / (double)ix->n_docs * (double)s->num_docs) : 0;
   ix->avg_doclen = s->num_docs > 0 ? (double)ix->n_emb_total / (double)s->num_docs : 0.0;
+  NP_TRY(build_unique_codes(ix));
   cleanup.p = nullptr;
   *out = ix;
   return NP_OK;

@@ -43,7 +43,7 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 __device__ __forceinline__ int mfma_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
 
 struct Counters {  // per-call work counters (np_stats)
-  unsigned long long n_cells, n_ivf_ids, n_candidates, n_cand_tokens, n_exact_docs, n_exact_tokens;
+  unsigned long long n_cells, n_ivf_ids, n_candidates, n_cand_tokens, n_exact_docs, n_exact_tokens, n_cand_codes;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -79,9 +79,14 @@ template <int DIM>
 __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
                                                       const float* __restrict__ Qt, int B, int LQP,
                                                       float* __restrict__ QCT, uint32_t* __restrict__ gmax) {
-  const int lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
-  const int64_t c0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-  if (c0 >= KP) return;
+  // The block's 4 waves walk the same sequence of 32-token query tiles; each tile ([DIM][32] f32,
+  // k-major) is staged once through LDS (double buffered, one barrier per tile) and read back as
+  // conflict-free ds_read_b32 B operands, so the MFMA stream never waits on an L2 round trip.
+  constexpr int NV = DIM / 32;  // float4 per thread per tile
+  __shared__ float sQ[2][DIM * 32];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, kk = lane >> 5;
+  const int64_t c0 = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * 64;
+  const bool active = c0 < KP;
   float a0[DIM / 2], a1[DIM / 2];
   {
     const int64_t r0 = c0 + li, r1 = c0 + 32 + li;
@@ -99,37 +104,61 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
   const int nqt = LQP >> 5;
   const int ntiles = B * nqt;
   const int64_t G = KP >> 5;
+  float4 stage[NV];
+  auto load_tile = [&](int tile) {
+    const int b = tile / nqt, qt = tile - b * nqt;
+    const float* src = Qt + (int64_t)b * DIM * LQP + qt * 32;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i4 = j * 256 + tid;            // float4 index inside the [DIM][32] tile
+      stage[j] = *reinterpret_cast<const float4*>(src + (int64_t)(i4 >> 3) * LQP + (i4 & 7) * 4);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) *reinterpret_cast<float4*>(&sQ[buf][(j * 256 + tid) * 4]) = stage[j];
+  };
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
     const int b = tile / nqt, qt = tile - b * nqt;
-    const float* qb = Qt + (int64_t)b * DIM * LQP + qt * 32 + li + (int64_t)kk * LQP;  // [2s+kk][q]
-    f32x16 acc0, acc1;
+    if (tile + 1 < ntiles) load_tile(tile + 1);   // in flight under this tile's MFMAs
+    if (active) {
+      const float* qb = &sQ[tile & 1][kk * 32 + li];   // [2s+kk][q]
+      f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < DIM / 2; ++s) {  // fully unrolled: a0/a1 must stay in registers
-      const float bq = qb[(int64_t)(2 * s) * LQP];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bq, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bq, acc1, 0, 0, 0);
-    }
-    float* out = QCT + ((int64_t)b * KP + c0) * LQP + qt * 32 + li;
-    uint32_t k0 = 0, k1 = 0;
+      for (int s = 0; s < DIM / 2; ++s) {  // fully unrolled: a0/a1 must stay in registers
+        const float bq = qb[s * 64];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bq, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bq, acc1, 0, 0, 0);
+      }
+      float* out = QCT + ((int64_t)b * KP + c0) * LQP + qt * 32 + li;
+      uint32_t k0 = 0, k1 = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mfma_row(r, kk);
-      out[(int64_t)row * LQP] = acc0[r];
-      out[(int64_t)(row + 32) * LQP] = acc1[r];
-      const uint32_t e0 = (c0 + row < K) ? okey(acc0[r]) : 0u;
-      const uint32_t e1 = (c0 + 32 + row < K) ? okey(acc1[r]) : 0u;
-      k0 = max(k0, e0);
-      k1 = max(k1, e1);
+      for (int r = 0; r < 16; ++r) {
+        const int row = mfma_row(r, kk);
+        out[(int64_t)row * LQP] = acc0[r];
+        out[(int64_t)(row + 32) * LQP] = acc1[r];
+        const uint32_t e0 = (c0 + row < K) ? okey(acc0[r]) : 0u;
+        const uint32_t e1 = (c0 + 32 + row < K) ? okey(acc1[r]) : 0u;
+        k0 = max(k0, e0);
+        k1 = max(k1, e1);
+      }
+      k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
+      k1 = max(k1, (uint32_t)__shfl_xor((int)k1, 32));
+      if (kk == 0) {
+        uint32_t* g = gmax + ((int64_t)b * G + (c0 >> 5)) * LQP + qt * 32 + li;
+        g[0] = k0;
+        g[LQP] = k1;
+      }
     }
-    k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
-    k1 = max(k1, (uint32_t)__shfl_xor((int)k1, 32));
-    if (kk == 0) {
-      uint32_t* g = gmax + ((int64_t)b * G + (c0 >> 5)) * LQP + qt * 32 + li;
-      g[0] = k0;
-      g[LQP] = k1;
-    }
+    if (tile + 1 < ntiles) store_tile((tile + 1) & 1);
+    __syncthreads();
   }
 }
 
@@ -186,7 +215,7 @@ __device__ __forceinline__ void radix_select32(Enum&& enumerate, uint32_t want, 
 
 struct ProbeP {
   const float* QCT;        // [B][KP][LQP]
-  const uint32_t* gmax;    // [B][KP/32][LQP]
+  const uint32_t* gmax;    // [B][KP/32][LQP]  (masked by `elig` when a subset is given)
   const int32_t* qoff;     // [B+1]
   int64_t K, KP;
   int LQP;
@@ -203,12 +232,36 @@ struct ProbeP {
   Counters* ctr;
 };
 
+#define NP_PROBE_CAPG 64   // surviving 32-centroid groups per token whose keys fit one wave's registers
+
+// Per-token tail of the probe: among the elements of the surviving groups find the n_probe best and
+// mark them.  One WAVE per token; element keys (+1, 0 = absent) live in 32 registers per lane and the
+// n_probe-th largest is found by a 32-step bitwise search with ballot/popcount counting.
+__device__ __forceinline__ void wave_select_mark(int nslots, uint32_t n_probe, const uint32_t (&keys)[32],
+                                                 uint32_t& tau, uint32_t& rem) {
+  uint32_t prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t trial = prefix | (1u << bit);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) cnt += (uint32_t)__popcll(__ballot(j < nslots && keys[j] >= trial));
+    if (cnt >= n_probe) prefix = trial;
+  }
+  uint32_t gt = 0;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) gt += (uint32_t)__popcll(__ballot(j < nslots && keys[j] > prefix));
+  tau = prefix;
+  rem = n_probe > gt ? n_probe - gt : 0u;
+}
+
 __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
   __shared__ uint32_t hist[256 * 32];
   __shared__ uint32_t part[8 * 32];
-  __shared__ uint32_t s_prefix[32], s_rem[32], s_taug[32], s_tie[32];
+  __shared__ uint32_t s_prefix[32], s_rem[32], s_taug[32], s_gcnt[32];
+  __shared__ uint32_t s_glist[32 * NP_PROBE_CAPG];
   __shared__ uint32_t s_ntmp, s_nfinal;
   const int b = blockIdx.x, tid = threadIdx.x, q = tid & 31, r = tid >> 5;
+  const int wave = tid >> 6, lane = tid & 63;
   const int Lq = p.qoff[b + 1] - p.qoff[b];
   const int64_t G = p.KP >> 5;
   const int LQP = p.LQP;
@@ -216,70 +269,142 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
   const uint32_t* gm = p.gmax + (int64_t)b * G * LQP;
   uint32_t* bits = p.cellbits + (int64_t)b * G;
   const int64_t pool = p.elig ? (int64_t)*p.n_elig : p.K;
-  int64_t eff = p.nprobe_dev ? (int64_t)*p.nprobe_dev : (int64_t)p.nprobe;
+  const int64_t eff = p.nprobe_dev ? (int64_t)*p.nprobe_dev : (int64_t)p.nprobe;
   const uint32_t n_probe = (uint32_t)min(eff, pool);  // search.rs:405
   const bool take_all = pool <= (int64_t)n_probe;
   if (tid == 0) { s_ntmp = 0; s_nfinal = 0; }
 
-  for (int qc = 0; qc < (LQP >> 5); ++qc) {
-    const int qq = qc * 32 + q;
-    const bool qvalid = qq < Lq;
-    if (n_probe == 0) break;
-    if (take_all) {
-      // every pooled centroid is selected by every token (search.rs:406: len <= n_probe)
-      if (qc == 0)
-        for (int64_t w = tid; w < G; w += 256) {
-          uint32_t m = p.elig ? p.elig[w] : 0xFFFFFFFFu;
-          int64_t c0 = w * 32;
-          if (c0 + 32 > p.K) m &= (c0 >= p.K) ? 0u : ((1u << (p.K - c0)) - 1u);
-          if (m && Lq > 0) atomicOr(&bits[w], m);
-        }
-      continue;
+  if (n_probe > 0 && take_all && Lq > 0) {
+    // every pooled centroid is selected by every token (search.rs:406: len <= n_probe)
+    for (int64_t w = tid; w < G; w += 256) {
+      uint32_t m = p.elig ? p.elig[w] : 0xFFFFFFFFu;
+      const int64_t c0 = w * 32;
+      if (c0 + 32 > p.K) m &= (c0 >= p.K) ? 0u : ((1u << (p.K - c0)) - 1u);
+      if (m) atomicOr(&bits[w], m);
     }
-    // ---- phase 1: tau_g[q] = n_probe-th largest group maximum (no eligibility mask only)
-    const bool use_groups = (p.elig == nullptr) && (G > (int64_t)n_probe);
-    if (use_groups) {
-      radix_select32(
-          [&](auto&& cb) {
-            if (qvalid)
-              for (int64_t g = r; g < G; g += 8) cb(gm[g * LQP + qq]);
-          },
-          n_probe, hist, part, s_prefix, s_rem, tid);
-      if (r == 0) s_taug[q] = s_prefix[q];
-    } else if (r == 0) {
-      s_taug[q] = 0;
-    }
-    __syncthreads();
-    const uint32_t taug = s_taug[q];
-    // ---- phase 2: tau[q] = n_probe-th largest element inside the surviving groups
-    auto for_elems = [&](auto&& cb) {
-      if (!qvalid) return;
-      for (int64_t g = r; g < G; g += 8) {
-        if (gm[g * LQP + qq] < taug) continue;
-        const uint32_t em = p.elig ? p.elig[g] : 0xFFFFFFFFu;
-        if (!em) continue;
-        const float* row = QCT + (g * 32) * LQP + qq;
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-          const int64_t c = g * 32 + i;
-          if (c < p.K && ((em >> i) & 1u)) cb(okey(row[(int64_t)i * LQP]), c);
+  } else if (n_probe > 0) {
+    for (int qc = 0; qc < (LQP >> 5); ++qc) {
+      if (qc * 32 >= Lq) break;
+      const int qq = qc * 32 + q;
+      const bool qvalid = qq < Lq;
+      // ---- phase 1 (block, 32 tokens at once): tau_g[q] = n_probe-th largest group maximum
+      const bool use_groups = G > (int64_t)n_probe;
+      if (use_groups) {
+        radix_select32(
+            [&](auto&& cb) {
+              if (qvalid)
+                for (int64_t g = r; g < G; g += 8) cb(gm[g * LQP + qq]);
+            },
+            n_probe, hist, part, s_prefix, s_rem, tid);
+        if (r == 0) s_taug[q] = s_prefix[q];
+      } else if (r == 0) {
+        s_taug[q] = 0;
+      }
+      if (r == 0) s_gcnt[q] = 0;
+      __syncthreads();
+      // ---- surviving groups -> per-token lists (order irrelevant)
+      if (qvalid) {
+        const uint32_t taug = s_taug[q];
+#pragma unroll 8
+        for (int64_t g = r; g < G; g += 8) {
+          if (gm[g * LQP + qq] >= taug) {
+            const uint32_t pos = atomicAdd(&s_gcnt[q], 1u);
+            if (pos < NP_PROBE_CAPG) s_glist[q * NP_PROBE_CAPG + pos] = (uint32_t)g;
+          }
         }
       }
-    };
-    radix_select32([&](auto&& cb) { for_elems([&](uint32_t key, int64_t) { cb(key); }); }, n_probe, hist, part,
-                   s_prefix, s_rem, tid);
-    if (r == 0) s_tie[q] = 0;
-    __syncthreads();
-    // ---- phase 3: mark the selected cells (ties at the cut: unspecified in the reference)
-    {
-      const uint32_t tau = s_prefix[q], rem = s_rem[q];
-      for_elems([&](uint32_t key, int64_t c) {
-        bool take = key > tau;
-        if (!take && key == tau) take = atomicAdd(&s_tie[q], 1u) < rem;
-        if (take) atomicOr(&bits[c >> 5], 1u << (c & 31));
-      });
+      __syncthreads();
+      // ---- phases 2+3: one wave per token
+      for (int t = wave; t < 32; t += 4) {
+        const int tq = qc * 32 + t;
+        if (tq >= Lq) break;
+        const uint32_t ng = s_gcnt[t];
+        const float* col = QCT + tq;
+        if (ng <= NP_PROBE_CAPG) {
+          // element slot e = j*64 + lane -> (group list[e>>5], member e&31); key' = okey+1, 0 = absent
+          const int nslots = (int)((ng * 32 + 63) / 64);
+          uint32_t keys[32];
+          uint32_t cids[32];
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            keys[j] = 0;
+            cids[j] = 0;
+            const uint32_t e = (uint32_t)j * 64 + lane;
+            if (j < nslots && e < ng * 32) {
+              const int64_t c = (int64_t)s_glist[t * NP_PROBE_CAPG + (e >> 5)] * 32 + (e & 31);
+              const bool ok = c < p.K && (!p.elig || ((p.elig[c >> 5] >> (c & 31)) & 1u));
+              if (ok) {
+                keys[j] = okey(col[c * LQP]) + 1u;
+                cids[j] = (uint32_t)c;
+              }
+            }
+          }
+          uint32_t tau, rem;
+          wave_select_mark(nslots, n_probe, keys, tau, rem);
+          uint32_t taken = 0;  // ties at the cut (unspecified in the reference): first `rem` in slot order
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            if (j < nslots) {
+              const bool gt = keys[j] > tau && keys[j] != 0;
+              const bool eq = keys[j] == tau && tau != 0;
+              const unsigned long long bal = __ballot(eq);
+              const uint32_t before = taken + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+              if (gt || (eq && before < rem)) atomicOr(&bits[cids[j] >> 5], 1u << (cids[j] & 31));
+              taken += (uint32_t)__popcll(bal);
+            }
+          }
+        } else {
+          // degenerate tie-heavy input: too many surviving groups for registers.  Same selection with
+          // the keys re-read from memory in every counting step (slow, exact).
+          const uint32_t taug = s_taug[t];
+          auto count_ge = [&](uint32_t trial, bool strict) {
+            uint32_t cnt = 0;
+            for (int64_t g0 = 0; g0 < G; g0 += 64) {
+              const int64_t g = g0 + lane;
+              uint32_t mine = 0;
+              if (g < G && gm[g * LQP + tq] >= taug) {
+                const uint32_t em = p.elig ? p.elig[g] : 0xFFFFFFFFu;
+                for (int i = 0; i < 32; ++i) {
+                  const int64_t c = g * 32 + i;
+                  if (c < p.K && ((em >> i) & 1u)) {
+                    const uint32_t k1 = okey(col[c * LQP]) + 1u;
+                    mine += strict ? (k1 > trial) : (k1 >= trial);
+                  }
+                }
+              }
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+              cnt += mine;
+            }
+            return cnt;
+          };
+          uint32_t prefix = 0;
+          for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);
+            if (count_ge(trial, false) >= n_probe) prefix = trial;
+          }
+          const uint32_t gt = count_ge(prefix, true);
+          const uint32_t rem = n_probe > gt ? n_probe - gt : 0u;
+          uint32_t taken = 0;
+          for (int64_t g0 = 0; g0 < G; g0 += 64) {
+            const int64_t g = g0 + lane;
+            const bool gv = g < G && gm[g * LQP + tq] >= taug;
+            const uint32_t em = gv ? (p.elig ? p.elig[g] : 0xFFFFFFFFu) : 0u;
+            for (int i = 0; i < 32; ++i) {
+              const int64_t c = g * 32 + i;
+              const bool ok = gv && c < p.K && ((em >> i) & 1u);
+              const uint32_t k1 = ok ? okey(col[c * LQP]) + 1u : 0u;
+              const bool eq = ok && k1 == prefix && prefix != 0;
+              const unsigned long long bal = __ballot(eq);
+              const uint32_t before = taken + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+              if (ok && (k1 > prefix || (eq && before < rem))) atomicOr(&bits[c >> 5], 1u << (c & 31));
+              taken += (uint32_t)__popcll(bal);
+            }
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   __threadfence();
   __syncthreads();
@@ -298,7 +423,6 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
   // max_by keeps the LAST of equal maxima, so an all-non-finite column yields QC[Lq-1, c].
   const uint32_t ntmp = s_ntmp;
   uint32_t* outc = p.cells + (int64_t)b * p.KP;
-  const int wave = tid >> 6, lane = tid & 63;
   for (uint32_t i = wave; i < ntmp; i += 4) {
     const uint32_t c = tmp[i];
     bool pass = true;
@@ -323,6 +447,28 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
   if (tid == 0) {
     p.n_cells[b] = (int32_t)s_nfinal;
     atomicAdd(&p.ctr->n_cells, (unsigned long long)s_nfinal);
+  }
+}
+
+// Group maxima restricted to eligible centroids (subset path): gmax[b][g][q] = max over eligible
+// members of okey(QCT[b][g*32+i][q]).  One wave per (b, g); lanes = query tokens.
+__global__ void __launch_bounds__(256) masked_gmax_kernel(const float* __restrict__ QCT, int64_t KP, int64_t K, int LQP,
+                                                          const uint32_t* __restrict__ elig,
+                                                          uint32_t* __restrict__ gmax) {
+  const int64_t G = KP >> 5;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  if (g >= G) return;
+  const uint32_t em = elig[g];
+  for (int q0 = 0; q0 < LQP; q0 += 64) {
+    const int q = q0 + lane;
+    if (q >= LQP) break;
+    uint32_t km = 0;
+    for (int i = 0; i < 32; ++i) {
+      const int64_t c = g * 32 + i;
+      if (c < K && ((em >> i) & 1u)) km = max(km, okey(QCT[((int64_t)b * KP + c) * LQP + q]));
+    }
+    gmax[((int64_t)b * G + g) * LQP + q] = km;
   }
 }
 
@@ -507,14 +653,18 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
                                                      const uint32_t* __restrict__ cand, int64_t cand_stride,
                                                      const int64_t* __restrict__ prefix, int B,
                                                      const int64_t* __restrict__ doc_off,
-                                                     const uint32_t* __restrict__ codes, float* __restrict__ approx,
+                                                     const uint32_t* __restrict__ codes,
+                                                     const int32_t* __restrict__ ulen, float* __restrict__ approx,
                                                      Counters* ctr) {
+  // `codes` holds, at each document's offset, its codes sorted and de-duplicated (ulen[doc] of
+  // them): max over tokens == max over distinct codes, so the value is unchanged and the gather
+  // shrinks by the document's code multiplicity.
   constexpr int TPS = 64 / QL;  // tokens per step
   const int lane = threadIdx.x & 63;
   const int ql = lane & (QL - 1), h = lane / QL;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int64_t total = prefix[B];
-  unsigned long long toks = 0;
+  unsigned long long toks = 0, ucodes = 0;
   for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += nwaves) {
     int lo = 0, hi = B;  // largest b with prefix[b] <= w
     while (hi - lo > 1) {
@@ -525,10 +675,11 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
     const int64_t i = w - prefix[b];
     const uint32_t doc = cand[(int64_t)b * cand_stride + i];
     const int64_t off = doc_off[doc];
-    const int len = (int)(doc_off[doc + 1] - off);
+    const int len = ulen[doc];
     const int Lq = qoff[b + 1] - qoff[b];
     const float* T = QCT + (int64_t)b * KP * LQP;
-    toks += (unsigned long long)len;
+    toks += (unsigned long long)(doc_off[doc + 1] - off);
+    ucodes += (unsigned long long)len;
     float score = 0.f;
     for (int q0 = 0; q0 < Lq; q0 += QL) {
       const int q = q0 + ql;
@@ -555,7 +706,10 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
     }
     if (lane == 0) approx[(int64_t)b * cand_stride + i] = score;
   }
-  if (lane == 0 && toks) atomicAdd(&ctr->n_cand_tokens, toks);
+  if (lane == 0 && toks) {
+    atomicAdd(&ctr->n_cand_tokens, toks);
+    atomicAdd(&ctr->n_cand_codes, ucodes);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -285,9 +285,13 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     subset_kernel<<<(unsigned)((subset_len + 3) / 4), 256, 0, st>>>(
         d_subset, subset_len, ix->doc_begin, ix->n_docs, ix->d_doc_offsets, ix->d_codes, w.subset_bits.as<uint32_t>(),
         use_elig ? w.elig.as<uint32_t>() : nullptr);
-    if (use_elig)
+    if (use_elig) {
       subset_nprobe_kernel<<<1, 256, 0, st>>>(w.elig.as<uint32_t>(), G, prm.n_ivf_probe, ix->N_total, subset_len,
                                               w.misc.as<int32_t>(), w.misc.as<int32_t>() + 1);
+      // the probe prunes by group maxima: restrict them to the eligible centroids
+      masked_gmax_kernel<<<dim3((unsigned)((G + 3) / 4), B), 256, 0, st>>>(w.QCT.as<float>(), KP, ix->K, LQP,
+                                                                           w.elig.as<uint32_t>(), w.gmax.as<uint32_t>());
+    }
   }
 
   // ---- S2
@@ -334,11 +338,11 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     const unsigned grid = 2048;
     if (LQP == 32)
       approx_kernel<32><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand.as<uint32_t>(), cand_stride,
-                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_codes,
+                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
                                               w.approx.as<float>(), w.ctr.as<Counters>());
     else
       approx_kernel<64><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand.as<uint32_t>(), cand_stride,
-                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_codes,
+                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
                                               w.approx.as<float>(), w.ctr.as<Counters>());
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
@@ -587,6 +591,7 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
       acc.n_cand_tokens += (int64_t)h_ctr->n_cand_tokens;
       acc.n_exact_docs += (int64_t)h_ctr->n_exact_docs;
       acc.n_exact_tokens += (int64_t)h_ctr->n_exact_tokens;
+      acc.n_cand_codes += (int64_t)h_ctr->n_cand_codes;
     }
   }
   if (topk > 0) {

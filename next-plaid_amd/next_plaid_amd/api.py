@@ -84,7 +84,7 @@ class np_stats(C.Structure):
                 ("ms_exact", C.c_float), ("ms_topk", C.c_float),
                 ("n_cells", C.c_int64), ("n_ivf_ids", C.c_int64), ("n_candidates", C.c_int64),
                 ("n_cand_tokens", C.c_int64), ("n_exact_docs", C.c_int64), ("n_exact_tokens", C.c_int64),
-                ("n_queries", C.c_int32), ("reserved", C.c_int32)]
+                ("n_cand_codes", C.c_int64), ("n_queries", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

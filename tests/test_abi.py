@@ -27,7 +27,7 @@ def test_struct_sizes_match_header():
     # natural alignment, no packing surprises between ctypes and the C structs
     assert C.sizeof(api.np_open_opts) == 32
     assert C.sizeof(api.np_search_params) == 28
-    assert C.sizeof(api.np_stats) == 8 * 4 + 6 * 8 + 8
+    assert C.sizeof(api.np_stats) == 8 * 4 + 7 * 8 + 8
     assert C.sizeof(api.np_info) == 3 * 8 + 2 * 4 + 8 + 3 * 8 + 8 + 2 * 4
 
 
