@@ -683,18 +683,26 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
     float score = 0.f;
     for (int q0 = 0; q0 < Lq; q0 += QL) {
       const int q = q0 + ql;
+      const bool qok = q < LQP;
+      const float* Tq = T + (qok ? q : LQP - 1);
       float m = NP_NEG_INF;
       for (int t0 = 0; t0 < len; t0 += 64) {
         const int tl = t0 + lane;
         const uint32_t creg = (tl < len) ? codes[off + tl] : 0u;
         const int nt = min(64, len - t0);
-#pragma unroll 8
-        for (int s = 0; s < 64 / TPS; ++s) {
-          const int t = s * TPS + h;
-          if (s * TPS >= nt) break;
-          const uint32_t c = (uint32_t)__shfl((int)creg, t);
-          const float v = (t < nt && q < LQP) ? T[(int64_t)c * LQP + q] : NP_NEG_INF;
-          m = fmaxf(m, v);  // == `if v > m` for NaN v (kept out) and +inf (kept)
+        // 8 independent gathers in flight per lane (no early exit inside the unrolled group)
+        for (int s0 = 0; s0 < 64 / TPS; s0 += 8) {
+          if (s0 * TPS >= nt) break;
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int t = (s0 + u) * TPS + h;
+            const uint32_t c = (uint32_t)__shfl((int)creg, t);
+            const float x = Tq[(int64_t)c * LQP];   // unconditional (c = 0 past the end): no branch per load
+            v[u] = (t < nt && qok) ? x : NP_NEG_INF;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);  // == `if v > m` for NaN v (kept out) and +inf (kept)
         }
       }
       if (TPS == 2) m = fmaxf(m, __shfl_xor(m, 32));
