@@ -1,0 +1,156 @@
+// next_plaid.hpp -- C++ host-side mirror of the next-plaid crate's search API over the C ABI.
+//
+// The reference host code is Rust (next-plaid/src/index.rs, search.rs, error.rs); this image has no
+// Rust toolchain, so the host side above include/nextplaid_hip.h is written in C++ with the SAME
+// names, argument meaning and error behaviour.  The Rust shim a maintainer would add is shown in
+// INTEGRATION.md; it is a line-for-line analogue of this header.
+//
+//   next_plaid::MmapIndex::load(path)                      index.rs:1026
+//   index.search(query, n_tokens, params, subset)          index.rs:1258  -> QueryResult, query_id = 0
+//   index.search_batch(queries, params, parallel, subset)  index.rs:1279  -> query_id = batch position
+//   SearchParameters (defaults search.rs:58-69), QueryResult (search.rs:71-80), Error (error.rs:9-66)
+//
+// Header-only; link with -lnextplaid_hip.  No CPU fallback lives here: DeviceUnavailable is an Error.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/nextplaid_hip.h"
+
+namespace next_plaid {
+
+struct Error : std::runtime_error {  // error.rs:9-66
+  enum Kind { IndexLoad = 1, Search = 2, Shape = 3, Codec = 4, Io = 5, DeviceUnavailable = 6, OutOfMemory = 7, Config = 8 };
+  Kind kind;
+  Error(int code, const char* msg) : std::runtime_error(msg && *msg ? msg : "next-plaid error"), kind((Kind)code) {}
+};
+
+inline void check(int rc) {
+  if (rc != NP_OK) throw Error(rc, np_hip_last_error());
+}
+
+struct SearchParameters {  // search.rs:26-69
+  size_t batch_size = 2000;
+  size_t n_full_scores = 4096;
+  size_t top_k = 10;
+  size_t n_ivf_probe = 8;
+  size_t centroid_batch_size = 100000;
+  std::optional<float> centroid_score_threshold = 0.4f;
+  int precision = 0;  // 0 = fp32 parity mode, 1 = bf16 MaxSim
+  np_search_params c() const {
+    np_search_params p{};
+    p.top_k = (int32_t)top_k;
+    p.n_full_scores = (int32_t)n_full_scores;
+    p.n_ivf_probe = (int32_t)n_ivf_probe;
+    p.centroid_batch_size = (int32_t)centroid_batch_size;
+    p.centroid_score_threshold = centroid_score_threshold.value_or(0.f);
+    p.has_threshold = centroid_score_threshold.has_value() ? 1 : 0;
+    p.precision = precision;
+    return p;
+  }
+};
+
+struct QueryResult {  // search.rs:71-80
+  size_t query_id = 0;
+  std::vector<int64_t> passage_ids;
+  std::vector<float> scores;
+};
+using SearchResult = QueryResult;  // search.rs:678
+
+// A row-major [n_tokens, dim] f32 query (ndarray::Array2<f32> in the crate).
+struct Query {
+  const float* data;
+  size_t n_tokens;
+};
+
+class MmapIndex {
+ public:
+  // MmapIndex::load (index.rs:1026).  `opts` selects the device / document shard.
+  static MmapIndex load(const std::string& index_path, const np_open_opts* opts = nullptr) {
+    np_index* h = nullptr;
+    check(np_hip_index_open(index_path.c_str(), opts, &h));
+    return MmapIndex(h, index_path);
+  }
+  MmapIndex(MmapIndex&& o) noexcept : path(std::move(o.path)), h_(o.h_), info_(o.info_) { o.h_ = nullptr; }
+  MmapIndex& operator=(MmapIndex&& o) noexcept {
+    if (this != &o) {
+      close();
+      h_ = o.h_;
+      o.h_ = nullptr;
+      path = std::move(o.path);
+      info_ = o.info_;
+    }
+    return *this;
+  }
+  MmapIndex(const MmapIndex&) = delete;
+  MmapIndex& operator=(const MmapIndex&) = delete;
+  ~MmapIndex() { close(); }
+
+  // index.rs:1258-1265
+  QueryResult search(const float* query, size_t n_tokens, const SearchParameters& params,
+                     const std::vector<int64_t>* subset = nullptr) const {
+    Query q{query, n_tokens};
+    auto r = search_batch(&q, 1, params, /*parallel=*/false, subset);
+    r[0].query_id = 0;
+    return std::move(r[0]);
+  }
+
+  // index.rs:1279-1287 -> search.rs:643-675.  `parallel` keeps the reference's error policy: with
+  // parallel = true a failing search yields empty results instead of an error (search.rs:656-660).
+  std::vector<QueryResult> search_batch(const Query* queries, size_t n, const SearchParameters& params, bool parallel,
+                                        const std::vector<int64_t>* subset = nullptr) const {
+    const size_t dim = embedding_dim();
+    std::vector<int32_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int32_t)queries[i].n_tokens;
+    std::vector<float> flat((size_t)off[n] * dim);
+    for (size_t i = 0; i < n; ++i)
+      std::copy(queries[i].data, queries[i].data + queries[i].n_tokens * dim, flat.begin() + (size_t)off[i] * dim);
+    const size_t k = params.top_k;
+    std::vector<int64_t> ids(std::max<size_t>(n * k, 1));
+    std::vector<float> sc(std::max<size_t>(n * k, 1));
+    std::vector<int32_t> cnt(std::max<size_t>(n, 1));
+    np_search_params p = params.c();
+    int rc = np_hip_search_batch(h_, flat.data(), off.data(), (int32_t)n, (int32_t)dim, &p,
+                                 subset ? subset->data() : nullptr, subset ? (int64_t)subset->size() : -1, ids.data(),
+                                 sc.data(), cnt.data(), &last_stats);
+    std::vector<QueryResult> out(n);
+    for (size_t i = 0; i < n; ++i) out[i].query_id = i;
+    if (rc != NP_OK) {
+      if (parallel && rc == NP_ERR_SEARCH) return out;
+      check(rc);
+    }
+    for (size_t i = 0; i < n; ++i) {
+      out[i].passage_ids.assign(ids.begin() + i * k, ids.begin() + i * k + cnt[i]);
+      out[i].scores.assign(sc.begin() + i * k, sc.begin() + i * k + cnt[i]);
+    }
+    return out;
+  }
+
+  // index.rs:1290-1312
+  size_t num_documents() const { return (size_t)info_.num_documents; }
+  size_t num_embeddings() const { return (size_t)info_.num_embeddings; }
+  size_t num_partitions() const { return (size_t)info_.num_partitions; }
+  double avg_doclen() const { return info_.avg_doclen; }
+  size_t embedding_dim() const { return (size_t)info_.embedding_dim; }
+  const np_info& info() const { return info_; }
+  np_index* handle() const { return h_; }
+
+  std::string path;
+  mutable np_stats last_stats{};
+
+ private:
+  MmapIndex(np_index* h, std::string p) : path(std::move(p)), h_(h) { check(np_hip_index_info(h_, &info_)); }
+  void close() {
+    if (h_) np_hip_index_close(h_);
+    h_ = nullptr;
+  }
+  np_index* h_ = nullptr;
+  np_info info_{};
+};
+
+}  // namespace next_plaid

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
   echo "== gpu"; /opt/rocm/bin/rocm-smi --showmeminfo vram 2>/dev/null | head -8
 } > gpurun_out/host.txt 2>&1
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
-for f in tests/test_gpu_parity.py tests/test_gpu_sharded.py; do
+for f in tests/test_gpu_parity.py tests/test_gpu_sharded.py tests/test_gpu_cpp_host.py; do
   timeout 1500 python -m pytest $f -q -m gpu --timeout 600 -rA 2>&1 | tail -150 > gpurun_out/$(basename $f .py).log
 done
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
