@@ -24,6 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define NP_NEG_INF (-__builtin_huge_valf())
+#define NP_MAX_QT 8      // query tiles of 32 tokens (LQP <= 256); exact kernels are instantiated for 1, 2 and 8
 
 // Orderable key of search.rs:110-117's comparator: finite values keep f32::total_cmp order in
 // [0x00800000, 0xFF7FFFFF]; every non-finite value maps to 0 (all Equal, below any finite).
@@ -225,6 +226,7 @@ struct ProbeP {
   const int32_t* n_elig;   // popcount of elig, else NULL
   int has_thr;
   float thr;
+  int64_t slab;            // > 0: batched-probe semantics (search.rs:140-254) with this centroid_batch_size
   uint32_t* cellbits;      // [B][KP/32] zeroed
   uint32_t* cells_tmp;     // [B][KP]
   uint32_t* cells;         // [B][KP]
@@ -259,6 +261,7 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
   __shared__ uint32_t part[8 * 32];
   __shared__ uint32_t s_prefix[32], s_rem[32], s_taug[32], s_gcnt[32];
   __shared__ uint32_t s_glist[32 * NP_PROBE_CAPG];
+  __shared__ uint32_t s_tauq[32 * NP_MAX_QT];   // per token: okey of its n_probe-th best centroid (0 = everything)
   __shared__ uint32_t s_ntmp, s_nfinal;
   const int b = blockIdx.x, tid = threadIdx.x, q = tid & 31, r = tid >> 5;
   const int wave = tid >> 6, lane = tid & 63;
@@ -273,6 +276,7 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
   const uint32_t n_probe = (uint32_t)min(eff, pool);  // search.rs:405
   const bool take_all = pool <= (int64_t)n_probe;
   if (tid == 0) { s_ntmp = 0; s_nfinal = 0; }
+  for (int i = tid; i < 32 * NP_MAX_QT; i += 256) s_tauq[i] = 0;
 
   if (n_probe > 0 && take_all && Lq > 0) {
     // every pooled centroid is selected by every token (search.rs:406: len <= n_probe)
@@ -341,6 +345,7 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
           }
           uint32_t tau, rem;
           wave_select_mark(nslots, n_probe, keys, tau, rem);
+          if (lane == 0) s_tauq[tq] = tau ? tau - 1u : 0u;
           uint32_t taken = 0;  // ties at the cut (unspecified in the reference): first `rem` in slot order
 #pragma unroll
           for (int j = 0; j < 32; ++j) {
@@ -385,6 +390,7 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
           }
           const uint32_t gt = count_ge(prefix, true);
           const uint32_t rem = n_probe > gt ? n_probe - gt : 0u;
+          if (lane == 0) s_tauq[tq] = prefix ? prefix - 1u : 0u;
           uint32_t taken = 0;
           for (int64_t g0 = 0; g0 < G; g0 += 64) {
             const int64_t g = g0 + lane;
@@ -419,8 +425,13 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
     }
   }
   __syncthreads();
-  // ---- threshold (search.rs:417-425): keep c iff finite-first max_q QC[q,c] >= t_cs.
-  // max_by keeps the LAST of equal maxima, so an all-non-finite column yields QC[Lq-1, c].
+  // ---- threshold.
+  // dense path (search.rs:417-425): keep c iff finite-first max_q QC[q,c] >= t_cs; max_by keeps the
+  //   LAST of equal maxima, so an all-non-finite column yields QC[Lq-1, c].
+  // batched path (search.rs:184-196,243-251): the max runs only over (q,c) pairs that were ever
+  //   pushed into token q's slab-local heap: pushed <=> fewer than n_probe earlier centroids of the
+  //   same slab score >= QC[q,c].  Pairs inside token q's global top-n_probe are always pushed, so
+  //   the slab prefix is only counted for a token with QC[q,c] >= t_cs outside its top-n_probe.
   const uint32_t ntmp = s_ntmp;
   uint32_t* outc = p.cells + (int64_t)b * p.KP;
   for (uint32_t i = wave; i < ntmp; i += 4) {
@@ -428,18 +439,58 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
     bool pass = true;
     if (p.has_thr) {
       const float* row = QCT + (int64_t)c * LQP;
-      uint32_t km = 0;
-      for (int q0 = 0; q0 < Lq; q0 += 64) {
-        const int qx = q0 + lane;
-        const uint32_t k = (qx < Lq) ? okey(row[qx]) : 0u;
-        km = max(km, k);
-      }
+      if (p.slab <= 0) {
+        uint32_t km = 0;
+        for (int q0 = 0; q0 < Lq; q0 += 64) {
+          const int qx = q0 + lane;
+          const uint32_t k = (qx < Lq) ? okey(row[qx]) : 0u;
+          km = max(km, k);
+        }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, o));
-      float mx;
-      if (km != 0) mx = unkey(km);
-      else mx = (Lq > 0) ? row[Lq - 1] : NP_NEG_INF;
-      pass = mx >= p.thr;
+        for (int o = 32; o > 0; o >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, o));
+        float mx;
+        if (km != 0) mx = unkey(km);
+        else mx = (Lq > 0) ? row[Lq - 1] : NP_NEG_INF;
+        pass = mx >= p.thr;
+      } else {
+        const int64_t slab0 = ((int64_t)c / p.slab) * p.slab;
+        uint32_t km = 0;       // best finite score among the always-pushed pairs
+        int first_sel = 0x7FFFFFFF;
+        pass = false;
+        for (int q0 = 0; q0 < Lq && !pass; q0 += 64) {
+          const int qx = q0 + lane;
+          const bool qv = qx < Lq;
+          const float v = qv ? row[qx] : 0.f;
+          const uint32_t k = qv ? okey(v) : 0u;
+          const bool sel = qv && k >= s_tauq[qx];
+          uint32_t kk2 = sel ? k : 0u;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) kk2 = max(kk2, (uint32_t)__shfl_xor((int)kk2, o));
+          km = max(km, kk2);
+          const unsigned long long selb = __ballot(sel);
+          if (selb && first_sel == 0x7FFFFFFF) first_sel = q0 + (__ffsll((long long)selb) - 1);
+          if (km != 0 && unkey(km) >= p.thr) { pass = true; break; }
+          // tokens outside their top-n_probe whose score alone would pass: count the slab prefix
+          unsigned long long cand = __ballot(qv && !sel && finitef(v) && v >= p.thr);
+          while (cand && !pass) {
+            const int ql = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const int q2 = q0 + ql;
+            const uint32_t k2 = __shfl((int)k, ql);
+            uint32_t cnt = 0;
+            for (int64_t c0 = slab0; c0 < (int64_t)c && cnt < n_probe; c0 += 64) {
+              const int64_t cc = c0 + lane;
+              const bool ge = cc < (int64_t)c && okey(QCT[cc * LQP + q2]) >= k2;
+              cnt += (uint32_t)__popcll(__ballot(ge));
+            }
+            if (cnt < n_probe) pass = true;   // pushed, finite and >= t_cs
+          }
+        }
+        if (!pass && km == 0 && first_sel != 0x7FFFFFFF) {
+          // every always-pushed score is non-finite: max_score() keeps the first inserted one
+          pass = row[first_sel] >= p.thr;
+        }
+      }
     }
     if (pass && lane == 0) outc[atomicAdd(&s_nfinal, 1u)] = c;
   }
@@ -870,7 +921,6 @@ struct ExactP {
 };
 
 #define NP_EXACT_DPW 4   // documents per wave
-#define NP_MAX_QT 8      // query tiles of 32 tokens (LQP <= 256); kernels are instantiated for 1, 2 and 8
 
 template <int NBITS>
 __device__ __forceinline__ float seg_weight(const float* sW, uint32_t byte, int e) {

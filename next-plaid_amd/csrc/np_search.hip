@@ -309,6 +309,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     pp.n_elig = use_elig ? w.misc.as<int32_t>() : nullptr;
     pp.has_thr = prm.has_threshold;
     pp.thr = prm.centroid_score_threshold;
+    pp.slab = batched ? (int64_t)prm.centroid_batch_size : 0;
     pp.cellbits = w.cellbits.as<uint32_t>();
     pp.cells_tmp = w.cells_tmp.as<uint32_t>();
     pp.cells = w.cells.as<uint32_t>();

@@ -88,7 +88,7 @@ def test_search_equals_batch_of_one(mid):
     assert r1.query_id == 0 and np.array_equal(r1.passage_ids, rb.passage_ids) and np.array_equal(r1.scores, rb.scores)
 
 
-@pytest.mark.parametrize("case", [c[0] for c in MG.CASES if not c[0].startswith("batched")])
+@pytest.mark.parametrize("case", [c[0] for c in MG.CASES])
 def test_golden_search(case):
     spec = synth.SynthSpec(**MG.GOLDEN_SPEC)
     a = synth.generate_arrays(spec)
@@ -247,3 +247,40 @@ def test_concurrent_calls_share_one_index(mid):
     for t in range(6):
         for r, o in zip(out[t], ref):
             assert np.array_equal(r.passage_ids, o.passage_ids) and np.array_equal(r.scores, o.scores)
+
+
+def test_batched_probe_semantics():
+    """K > centroid_batch_size (search.rs:140-254, 521-640): per-slab heaps; the threshold sees only
+    (token, centroid) pairs that entered a slab-local heap.  nprobe small + low threshold makes the
+    heap-only max differ from the true column max, which exercises the slab-prefix count."""
+    spec, a = make_arrays(num_docs=3000, num_centroids=700, dim=64, nbits=4, doc_len_min=5, doc_len_max=40, seed=41)
+    ox, hx = oracle_index(a), hip_index(a)
+    qs, _ = synth.make_queries(spec, 6, n_tokens=24, cen=a["centroids"], sigma_q=1.0)
+    # every other token is "weak" (scaled down): its best centroids score below t_cs while a strong
+    # token scores above t_cs on the same centroid without having it in its own top-nprobe
+    qs = [q * np.where(np.arange(24) % 2 == 0, 0.35, 1.0)[:, None].astype(np.float32) for q in qs]
+    n_diff = 0
+    for thr in (0.2, 0.3):
+        for nprobe in (1, 5):
+            for cbs in (64, 333):
+                pb = P(n_full_scores=128, top_k=8, n_ivf_probe=nprobe, centroid_score_threshold=thr, centroid_batch_size=cbs)
+                pd_ = P(n_full_scores=128, top_k=8, n_ivf_probe=nprobe, centroid_score_threshold=thr)
+                for qi, q in enumerate(qs):
+                    tb = hx.debug_trace(q, pb)
+                    ob = ox.search(q, to_oracle_params(pb), trace=True)
+                    assert ob.trace.used_batched
+                    assert np.array_equal(tb["cells"], ob.trace.cells), f"thr={thr} np={nprobe} cbs={cbs} q{qi}: cells"
+                    assert np.array_equal(tb["cand"], ob.trace.cand)
+                    # approx scores: the reference's batched path uses mat-vec summation order (search.rs:259-272)
+                    assert np.allclose(tb["approx"], ob.trace.approx, rtol=0, atol=2e-5)
+                    r = hx.search(q, pb)
+                    assert_ranking_close(r.passage_ids, r.scores, ob.passage_ids, ob.scores, 5e-5, f"batched q{qi}")
+                    n_diff += int(not np.array_equal(ob.trace.cells, ox.search(q, to_oracle_params(pd_), trace=True).trace.cells))
+    assert n_diff > 0, "test data never separated batched from dense threshold semantics"
+    # subset in batched mode only filters candidates (search.rs:542-545)
+    sub = np.arange(0, 3000, 3, dtype=np.int64)
+    pb = P(n_full_scores=64, top_k=5, n_ivf_probe=4, centroid_score_threshold=None, centroid_batch_size=100)
+    for q in qs[:3]:
+        tb = hx.debug_trace(q, pb, sub)
+        ob = ox.search(q, to_oracle_params(pb), sub, trace=True)
+        assert np.array_equal(tb["cells"], ob.trace.cells) and np.array_equal(tb["cand"], ob.trace.cand)
