@@ -51,7 +51,8 @@ def parse():
     ap.add_argument("--n-full-scores", type=int, default=4096)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--threshold", type=float, default=0.4, help="centroid_score_threshold; <0 = None")
-    ap.add_argument("--precision", type=int, default=0, help="0 = fp32 everywhere (parity mode), 1 = bf16 MaxSim")
+    ap.add_argument("--precision", type=int, default=0,
+                    help="exact MaxSim arithmetic: 0 exact-f32 MFMA, 1 QC-reuse bf16, 2 QC-reuse split-bf16 (f32-class), 3 plain bf16")
     ap.add_argument("--cpu-queries", type=int, default=64, help="queries of the CPU-oracle leg (0 = skip)")
     ap.add_argument("--query-batches", type=int, default=4)
     return ap.parse_args()
@@ -176,6 +177,7 @@ def main():
         "select(S5)": (stages["ms_select"], "hbm", (stages["n_candidates"] * 8) / 1e9, "GB/s", HBM_PEAK_GBS),
         "exact(S6)": ((stages["ms_exact"], "mfma", 2.0 * Lq * d * exact_tokens / 1e12, "TFLOP/s",
                        MFMA_F32_PEAK_TF if a.precision == 0 else MFMA_BF16_PEAK_TF)),
+        "exact-hbm(S6)": (stages["ms_exact"], "hbm", (exact_tokens * (pd + 8) + exact_tokens * 128) / 1e9, "GB/s", HBM_PEAK_GBS),
     }
     dom = max(per_stage, key=lambda k: per_stage[k][0])
     ms, bound, units, unit, peak = per_stage[dom]
@@ -226,7 +228,9 @@ def main():
         "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "p50_batch_latency_ms": None if p50 is None else round(p50, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if a.precision == 0 else "f32+bf16-maxsim", "data": "synthetic",
+        "dtype": {0: "f32", 1: "f32 (bf16 MFMA on the residual term of MaxSim)",
+                  2: "f32 (split-bf16 hi/lo MFMA on the residual term of MaxSim, f32-class accuracy)",
+                  3: "f32 + bf16 MaxSim"}[a.precision], "data": "synthetic",
         "config": {"workload": f"{a.docs_per_gpu * world} docs x {a.doc_len} tok x d128 (nbits=4), 2^{int(np.log2(a.centroids))} centroids, "
                                f"nprobe={a.nprobe}, batch={a.batch}x{a.query_tokens} tok, n_full_scores={a.n_full_scores}, "
                                f"t_cs={thr}, top_k={a.top_k}; {a.docs_per_gpu} docs per GPU shard",

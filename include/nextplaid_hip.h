@@ -67,8 +67,11 @@ typedef struct np_search_params {
                                      semantics of search.rs:140-254 */
   float centroid_score_threshold; /* search.rs:47 */
   int32_t has_threshold;          /* 0 = None */
-  int32_t precision;              /* 0 = fp32 everywhere (exact-f32 MFMA; parity mode)
-                                     1 = bf16 MFMA for the exact MaxSim stage only */
+  int32_t precision;              /* exact MaxSim stage (S1-S5 are always exact f32):
+                                     0 = exact-f32 MFMA on decompressed rows (strict parity mode)
+                                     1 = QC-reuse form, bf16 MFMA on the residual term
+                                     2 = QC-reuse form, split-bf16 (hi/lo) MFMA: f32-class accuracy
+                                     3 = bf16 MFMA on decompressed rows (plain bf16 MaxSim) */
 } np_search_params;
 
 typedef struct np_info {            /* accessors of index.rs:1290-1312 */

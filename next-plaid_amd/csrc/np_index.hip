@@ -97,6 +97,7 @@ void destroy_device_index(DeviceIndex* ix) {
   (void)hipFree(ix->d_codes);
   (void)hipFree(ix->d_ucodes);
   (void)hipFree(ix->d_ulen);
+  (void)hipFree(ix->d_inv_norm);
   (void)hipFree(ix->d_residuals);
   (void)hipFree(ix->d_doc_offsets);
   (void)hipFree(ix->d_ivf);
@@ -188,6 +189,50 @@ __global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __rest
     __syncthreads();
   }
   if (tid == 0) ulen[d] = base;
+}
+
+
+// ---- derived: 1 / ||centroid[code] + residual|| per token (codec.rs:443-467's normaliser) ------------------
+// one wave per 64 consecutive tokens; lanes sweep the dims of one token at a time (coalesced rows)
+__global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim, int nbits, int pd,
+                                                       const float* __restrict__ centroids,
+                                                       const float* __restrict__ wlut,
+                                                       const uint32_t* __restrict__ codes,
+                                                       const uint8_t* __restrict__ residuals,
+                                                       float* __restrict__ inv_norm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int per = 8 / nbits;
+  const uint32_t mask = (1u << nbits) - 1u;
+  float mine = 0.f;
+  for (int i = 0; i < 64; ++i) {
+    const int64_t tok = t0 + i;
+    if (tok >= T) break;
+    const uint32_t code = codes[tok];
+    float ss = 0.f;
+    for (int j = lane; j < dim; j += 64) {
+      const uint32_t byte = residuals[tok * pd + j / per];
+      const int e = j % per;
+      const float x = centroids[(int64_t)code * dim + j] + wlut[(byte >> (8 - nbits * (e + 1))) & mask];
+      ss = fmaf(x, x, ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == i) mine = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+  if (t0 + lane < T) inv_norm[t0 + lane] = mine;
+}
+
+static int build_inv_norm(DeviceIndex* ix) {
+  NP_TRY(dev_alloc(&ix->d_inv_norm, (size_t)ix->T, &ix->device_bytes));
+  if (ix->T > 0) {
+    const int64_t nblk = (ix->T + 255) / 256;
+    inv_norm_kernel<<<(unsigned)nblk, 256>>>(ix->T, ix->dim, ix->nbits, ix->pd, ix->d_centroids, ix->d_wlut, ix->d_codes,
+                                             ix->d_residuals, ix->d_inv_norm);
+  }
+  NP_HIP(hipGetLastError());
+  NP_HIP(hipDeviceSynchronize());
+  return NP_OK;
 }
 
 static int build_unique_codes(DeviceIndex* ix) {
@@ -334,6 +379,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
   }
   NP_TRY(build_unique_codes(ix));
+  NP_TRY(build_inv_norm(ix));
   cleanup.p = nullptr;
   *out = ix;
   return NP_OK;
@@ -560,6 +606,8 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     ix->n_emb_total = ix->n_docs > 0 ? (int64_t)((double)ix->T / (double)ix->n_docs * (double)s->num_docs) : 0;
   ix->avg_doclen = s->num_docs > 0 ? (double)ix->n_emb_total / (double)s->num_docs : 0.0;
   NP_TRY(build_unique_codes(ix));
+  NP_TRY(build_inv_norm(ix));
+  NP_TRY(build_inv_norm(ix));
   cleanup.p = nullptr;
   *out = ix;
   return NP_OK;

@@ -7,6 +7,7 @@
 //   codes       u32 [T]                 centroid id per token       (N.codes.npy, i64 on disk)
 //   residuals   u8  [T][pd]             packed buckets, unchanged   (N.residuals.npy)
 //   ucodes/ulen u32 [T] / i32 [n_docs]  derived at open: each document's DISTINCT codes (S4 gathers these)
+//   inv_norm    f32 [T]                 derived at open: 1/||centroid + residual|| per token (S6 QC-reuse form)
 //   doc_offsets i64 [n_docs+1]          prefix sum of doclens       (index.rs:1106-1110)
 //   ivf         u32 [ivf_size]          shard-local doc ids         (ivf.npy re-based)
 //   ivf_offsets i64 [K+1]                                           (index.rs:1089-1094)
@@ -108,6 +109,7 @@ struct DeviceIndex {
   uint32_t* d_codes = nullptr;
   uint32_t* d_ucodes = nullptr;   // [T] per-document sorted distinct codes at the document's offset (derived)
   int32_t* d_ulen = nullptr;      // [n_docs] number of distinct codes per document (derived)
+  float* d_inv_norm = nullptr;    // [T] 1 / max(||centroid[code] + residual||, 1e-12) per token (derived)
   uint8_t* d_residuals = nullptr;
   int64_t* d_doc_offsets = nullptr;
   uint32_t* d_ivf = nullptr;

@@ -52,7 +52,7 @@ struct Counters {  // per-call work counters (np_stats)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restrict__ q, const int32_t* __restrict__ qoff,
                                                            int dim, int LQP, float* __restrict__ Qt,
-                                                           __bf16* __restrict__ Qb) {
+                                                           __bf16* __restrict__ Qb, __bf16* __restrict__ Qb_lo) {
   const int b = blockIdx.x;
   const int t0 = qoff[b], Lq = qoff[b + 1] - t0;
   const int n = dim * LQP;
@@ -65,7 +65,9 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
     {  // row-major bf16
       int qq = i / dim, k = i - qq * dim;
       float v = (qq < Lq) ? q[(int64_t)(t0 + qq) * dim + k] : 0.0f;
-      Qb[(int64_t)b * n + i] = (__bf16)v;
+      const __bf16 hi = (__bf16)v;
+      Qb[(int64_t)b * n + i] = hi;
+      Qb_lo[(int64_t)b * n + i] = (__bf16)(v - (float)hi);   // q = hi + lo to ~2^-17 relative
     }
   }
 }
@@ -297,7 +299,14 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
         radix_select32(
             [&](auto&& cb) {
               if (qvalid)
-                for (int64_t g = r; g < G; g += 8) cb(gm[g * LQP + qq]);
+                for (int64_t g = r; g < G; g += 64) {   // 8 independent loads in flight
+                  uint32_t kv[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) kv[u] = (g + 8 * u < G) ? gm[(g + 8 * u) * LQP + qq] : 0u;
+#pragma unroll
+                  for (int u = 0; u < 8; ++u)
+                    if (g + 8 * u < G) cb(kv[u]);
+                }
             },
             n_probe, hist, part, s_prefix, s_rem, tid);
         if (r == 0) s_taug[q] = s_prefix[q];
@@ -309,11 +318,16 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
       // ---- surviving groups -> per-token lists (order irrelevant)
       if (qvalid) {
         const uint32_t taug = s_taug[q];
-#pragma unroll 8
-        for (int64_t g = r; g < G; g += 8) {
-          if (gm[g * LQP + qq] >= taug) {
-            const uint32_t pos = atomicAdd(&s_gcnt[q], 1u);
-            if (pos < NP_PROBE_CAPG) s_glist[q * NP_PROBE_CAPG + pos] = (uint32_t)g;
+        for (int64_t g = r; g < G; g += 64) {
+          uint32_t kv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) kv[u] = (g + 8 * u < G) ? gm[(g + 8 * u) * LQP + qq] : 0u;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (g + 8 * u < G && kv[u] >= taug) {
+              const uint32_t pos = atomicAdd(&s_gcnt[q], 1u);
+              if (pos < NP_PROBE_CAPG) s_glist[q * NP_PROBE_CAPG + pos] = (uint32_t)(g + 8 * u);
+            }
           }
         }
       }
@@ -904,6 +918,10 @@ __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
 struct ExactP {
   const float* Qt;          // [B][DIM][LQP] f32
   const __bf16* Qb;         // [B][LQP][DIM]
+  const __bf16* Qb_lo;      // [B][LQP][DIM] bf16(q - Qb)
+  const float* QCT;         // [B][KP][LQP] from S1
+  int64_t KP;
+  const float* inv_norm;    // [T] 1 / max(||centroid + residual||, 1e-12), derived at index open
   const int32_t* qoff;
   int LQP;
   const float* centroids;
@@ -1122,6 +1140,215 @@ __global__ void __launch_bounds__(256) exact_bf16_kernel(ExactP p) {
             if (qt == 0) bq = bq0[s];
             else bq = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)(qt * 32 + li) * DIM + 16 * s + 8 * kk);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq, acc, 0, 0, 0);
+          }
+          float mm = m[qt];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int trow = t0 + mfma_row(r, kk);
+            const float x = acc[r] * rrow[r];
+            if (trow < len && finitef(x)) mm = fmaxf(mm, x);
+          }
+          m[qt] = mm;
+        }
+      }
+    }
+    float total = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+      if (qt < nqt) {
+        const float mm = fmaxf(m[qt], __shfl_xor(m[qt], 32));
+        const int nq = min(32, Lq - qt * 32);
+        for (int qi = 0; qi < nq; ++qi) {
+          const float x = readlane_f(mm, qi);
+          if (x > NP_NEG_INF) total += x;
+        }
+      }
+    }
+    if (lane == 0) p.exact[oj] = total;
+  }
+  if (lane == 0 && ndocs) {
+    atomicAdd(&p.ctr->n_exact_docs, ndocs);
+    atomicAdd(&p.ctr->n_exact_tokens, toks);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S6, QC-reuse form (precision 1 and 2).  With D_t = (C[code_t] + R_t) / n_t (codec.rs:443-467):
+//     Q . D_t  =  ( QC[q, code_t]  +  Q . R_t ) / n_t
+// QC[q, code_t] is S1's exact-f32 output (one 128-B QCT line per token) and becomes the MFMA
+// accumulator's initial value; only the residual part goes through the matrix cores.  R_t takes 2^nbits
+// distinct values, so a 256-entry byte -> packed-bf16 LUT in LDS turns the packed residual bytes
+// directly into MFMA A fragments (no per-value VALU unpack, no centroid gather, no norm reduction):
+// per token the kernel reads pd residual bytes + a code + 1/n_t (derived at index open).
+// SPLIT = 1: plain bf16.  SPLIT = 3: R and Q are split hi+lo in bf16 and hi.hi + lo.hi + hi.lo are
+// accumulated in f32 -- the residual term is then f32-accurate (~2^-17 relative).
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int NBITS, int NQT, int SPLIT>
+__global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
+  constexpr int NS = DIM / 16;            // MFMA k-steps
+  constexpr int PD = DIM * NBITS / 8;     // bytes per token
+  constexpr int PH = PD / 2;              // bytes per lane: lane (tok, kk) owns dims [kk*DIM/2, +DIM/2)
+  constexpr int NW = PH / 4;              // residual dwords per lane
+  constexpr int WPB = (NBITS == 4) ? 1 : 2;  // u32 words of packed bf16 per residual byte (2 or 4 values)
+  static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0, "unsupported DIM/NBITS");
+  // byte -> {hi words, lo words}: one LDS read per residual byte returns both halves of the split
+  __shared__ uint32_t lut[256 * WPB * 2];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  {
+    constexpr int PER = 8 / NBITS;
+    constexpr uint32_t MASK = (1u << NBITS) - 1u;
+    uint16_t hh[4] = {0, 0, 0, 0}, ll[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {   // first dim of the byte = highest segment -> low half-word
+      const float w = p.wlut[((uint32_t)tid >> (8 - NBITS * (e + 1))) & MASK];
+      const __bf16 h = (__bf16)w;
+      const __bf16 l = (__bf16)(w - (float)h);
+      hh[e] = __builtin_bit_cast(uint16_t, h);
+      ll[e] = __builtin_bit_cast(uint16_t, l);
+    }
+#pragma unroll
+    for (int w2 = 0; w2 < WPB; ++w2) {
+      lut[(tid * WPB + w2) * 2 + 0] = (uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16);
+      lut[(tid * WPB + w2) * 2 + 1] = (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16);
+    }
+  }
+  __syncthreads();
+  const uint2* lut2 = reinterpret_cast<const uint2*>(lut);
+  const int LQP = p.LQP;
+  const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
+  const int Lq = p.qoff[b + 1] - p.qoff[b];
+  const int nqt = (Lq + 31) >> 5;
+  const int nsel = p.nsel[b];
+  const uint64_t cut = p.cut ? p.cut[b] : 0ull;
+  // slot (s, kk, e) of the MFMA k dimension <-> dim kk*DIM/2 + 8s + e, for A (tokens) and B (query) alike
+  const __bf16* Qb = p.Qb + (int64_t)b * LQP * DIM + kk * (DIM / 2);
+  const __bf16* Ql = p.Qb_lo + (int64_t)b * LQP * DIM + kk * (DIM / 2);
+  const float* QC = p.QCT + (int64_t)b * p.KP * LQP;
+  bf16x8 bh0[NS], bl0[SPLIT == 3 ? NS : 1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    bh0[s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)li * DIM + 8 * s);
+    if (SPLIT == 3) bl0[s] = *reinterpret_cast<const bf16x8*>(Ql + (int64_t)li * DIM + 8 * s);
+  }
+  unsigned long long toks = 0, ndocs = 0;
+  for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
+    const int j = (blockIdx.x * 4 + wave) * NP_EXACT_DPW + dd;
+    if (j >= nsel) break;
+    const int64_t oj = (int64_t)b * p.n_sel + j;
+    if (p.sel_keys[oj] < cut) {
+      if (lane == 0) p.exact[oj] = 0.f;
+      continue;
+    }
+    const uint32_t doc = p.sel_doc[oj];
+    const int64_t off = p.doc_off[doc];
+    const int len = (int)(p.doc_off[doc + 1] - off);
+    toks += (unsigned long long)len;
+    ++ndocs;
+    float m[NQT];
+#pragma unroll
+    for (int x = 0; x < NQT; ++x) m[x] = NP_NEG_INF;
+    // software pipeline: the NEXT tile's code / 1/n / residual words are in flight during this tile
+    uint32_t code_n = 0, rw_n[NW];
+    float rn_n = 0.f;
+    auto fetch = [&](int t0) {
+      const int tt = t0 + li;
+      const bool valid = tt < len;
+      const int64_t tok = off + (valid ? tt : len - 1);
+      code_n = p.codes[tok];
+      rn_n = valid ? p.inv_norm[tok] : 0.f;
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(p.residuals + tok * PD + kk * PH);
+      if constexpr (NW % 4 == 0) {
+#pragma unroll
+        for (int w4 = 0; w4 < NW / 4; ++w4) {
+          const uint4 v = reinterpret_cast<const uint4*>(rp)[w4];
+          rw_n[4 * w4] = v.x; rw_n[4 * w4 + 1] = v.y; rw_n[4 * w4 + 2] = v.z; rw_n[4 * w4 + 3] = v.w;
+        }
+      } else if constexpr (NW % 2 == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < NW / 2; ++w2) {
+          const uint2 v = reinterpret_cast<const uint2*>(rp)[w2];
+          rw_n[2 * w2] = v.x; rw_n[2 * w2 + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int w1 = 0; w1 < NW; ++w1) rw_n[w1] = rp[w1];
+      }
+    };
+    if (len > 0) fetch(0);
+    for (int t0 = 0; t0 < len; t0 += 32) {
+      const uint32_t code = code_n;
+      const float rn = rn_n;
+      uint32_t rw[NW];
+#pragma unroll
+      for (int w1 = 0; w1 < NW; ++w1) rw[w1] = rw_n[w1];
+      if (t0 + 32 < len) fetch(t0 + 32);
+      // per output row (token t0 + mfma_row(r, kk)): its code (for the QC line) and 1/n_t
+      uint32_t crow[16];
+      float rrow[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        crow[r] = (uint32_t)__shfl((int)code, mfma_row(r, kk));
+        rrow[r] = __shfl(rn, mfma_row(r, kk));
+      }
+      f32x16 acc0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = QC[(int64_t)crow[r] * LQP + li];   // C-in = Q.C[code], q-tile 0
+      // residual bytes -> bf16 A fragments (8 dims = 8*NBITS/8 bytes per k-step)
+      bf16x8 ah[NS], al[SPLIT == 3 ? NS : 1];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        uint32_t wh[4], wl[4];
+        if constexpr (NBITS == 4) {
+          const uint32_t word = rw[s];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint2 e = lut2[(word >> (8 * i)) & 0xFFu];
+            wh[i] = e.x;
+            wl[i] = e.y;
+          }
+        } else {
+          const uint32_t word = rw[s >> 1] >> (16 * (s & 1));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const uint32_t byte = (word >> (8 * i)) & 0xFFu;
+            const uint2 e0 = lut2[byte * 2], e1 = lut2[byte * 2 + 1];
+            wh[2 * i] = e0.x; wl[2 * i] = e0.y;
+            wh[2 * i + 1] = e1.x; wl[2 * i + 1] = e1.y;
+          }
+        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 vh = {wh[0], wh[1], wh[2], wh[3]};
+        ah[s] = __builtin_bit_cast(bf16x8, vh);
+        if constexpr (SPLIT == 3) {
+          u32x4 vl = {wl[0], wl[1], wl[2], wl[3]};
+          al[s] = __builtin_bit_cast(bf16x8, vl);
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+        if (qt < nqt) {
+          f32x16 acc;
+          if (qt == 0) {
+            acc = acc0;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = QC[(int64_t)crow[r] * LQP + qt * 32 + li];
+          }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            bf16x8 bh, bl;
+            if (qt == 0) {
+              bh = bh0[s];
+              if constexpr (SPLIT == 3) bl = bl0[s];
+            } else {
+              bh = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)(qt * 32 + li) * DIM + 8 * s);
+              if constexpr (SPLIT == 3) bl = *reinterpret_cast<const bf16x8*>(Ql + (int64_t)(qt * 32 + li) * DIM + 8 * s);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh, acc, 0, 0, 0);
+            if constexpr (SPLIT == 3) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl, acc, 0, 0, 0);
+            }
           }
           float mm = m[qt];
 #pragma unroll

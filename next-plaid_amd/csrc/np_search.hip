@@ -13,7 +13,7 @@
 namespace np {
 
 struct Workspace {
-  DevBuf q, qoff, Qt, Qb, QCT, gmax, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, approx, n_cand,
+  DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, approx, n_cand,
       prefix, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset, subset_bits,
       elig, misc, cut;
   void* h_pin = nullptr;
@@ -21,7 +21,7 @@ struct Workspace {
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
   bool done_valid = false;
   void release_all() {
-    DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &QCT, &gmax, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
+    DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
                      &chunk_counts, &cand, &approx, &n_cand, &prefix, &sel_keys, &sel_doc, &nsel, &exact, &out_ids,
                      &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc, &cut};
     for (DevBuf* b : all) b->release();
@@ -150,7 +150,7 @@ static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_sear
               n_sel_of(p));
     return NP_ERR_SEARCH;
   }
-  if (p->precision != 0 && p->precision != 1) {
+  if (p->precision < 0 || p->precision > 3) {
     set_error("Search failed: unknown precision %d", p->precision);
     return NP_ERR_INVALID_ARGUMENT;
   }
@@ -180,6 +180,10 @@ static int launch_exact(hipStream_t st, const ExactP& p, int B, int precision) {
       NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_f32_kernel<DIM, NBITS, NQT>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     exact_f32_kernel<DIM, NBITS, NQT><<<dim3(gx, B), 256, lds, st>>>(p);
+  } else if (precision == 1) {
+    exact_qc_kernel<DIM, NBITS, NQT, 1><<<dim3(gx, B), 256, 0, st>>>(p);
+  } else if (precision == 2) {
+    exact_qc_kernel<DIM, NBITS, NQT, 3><<<dim3(gx, B), 256, 0, st>>>(p);
   } else {
     exact_bf16_kernel<DIM, NBITS, NQT><<<dim3(gx, B), 256, 0, st>>>(p);
   }
@@ -230,6 +234,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
 
   NP_TRY(w.Qt.reserve((size_t)B * ix->dim * LQP * 4));
   NP_TRY(w.Qb.reserve((size_t)B * ix->dim * LQP * 2));
+  NP_TRY(w.Qbl.reserve((size_t)B * ix->dim * LQP * 2));
   NP_TRY(w.QCT.reserve((size_t)B * KP * LQP * 4));
   NP_TRY(w.gmax.reserve((size_t)B * G * LQP * 4));
   NP_TRY(w.cellbits.reserve((size_t)B * G * 4));
@@ -264,7 +269,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   if (B == 0) return NP_OK;
 
   // ---- S1
-  prep_queries_kernel<<<B, 256, 0, st>>>(d_q, d_qoff, ix->dim, LQP, w.Qt.as<float>(), w.Qb.as<__bf16>());
+  prep_queries_kernel<<<B, 256, 0, st>>>(d_q, d_qoff, ix->dim, LQP, w.Qt.as<float>(), w.Qb.as<__bf16>(),
+                                         w.Qbl.as<__bf16>());
   switch (ix->dim) {
     case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
     case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
@@ -383,6 +389,10 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ExactP ep;
     ep.Qt = w.Qt.as<float>();
     ep.Qb = w.Qb.as<__bf16>();
+    ep.Qb_lo = w.Qbl.as<__bf16>();
+    ep.QCT = w.QCT.as<float>();
+    ep.KP = ix->KP;
+    ep.inv_norm = ix->d_inv_norm;
     ep.qoff = d_qoff;
     ep.LQP = cs->LQP;
     ep.centroids = ix->d_centroids;

@@ -65,9 +65,10 @@ def test_stages_mid(mid):
             check_trace(hx, ox, qs[qi], p, what=f"thr={thr} q{qi}")
 
 
-def test_batch_mid_fp32_and_bf16(mid):
+def test_batch_mid_all_precisions(mid):
+    # precision 0: exact-f32 MFMA; 2: QC-reuse + split-bf16 (f32-class); 1: QC-reuse + bf16; 3: plain bf16
     spec, a, ox, hx, qs, src = mid
-    for prec, rtol in ((0, RTOL_F32), (1, RTOL_BF16)):
+    for prec, rtol in ((0, RTOL_F32), (2, RTOL_F32), (1, RTOL_BF16), (3, RTOL_BF16)):
         p = P(n_full_scores=1024, top_k=10, n_ivf_probe=16, precision=prec)
         res = hx.search_batch(qs, p)
         ref = ox.search_batch(qs, to_oracle_params(p))
