@@ -640,6 +640,8 @@ __global__ void __launch_bounds__(256) count_chunks_kernel(const uint32_t* __res
 __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict__ docbits, int64_t NW, int nchunks,
                                                       const int32_t* __restrict__ chunk_counts,
                                                       uint32_t* __restrict__ cand, int64_t cand_stride,
+                                                      const int64_t* __restrict__ doc_off,
+                                                      const int32_t* __restrict__ ulen, uint4* __restrict__ cand_meta,
                                                       int32_t* __restrict__ n_cand, Counters* ctr) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
@@ -679,13 +681,18 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
   for (int k = 0; k < wave; ++k) woff += s_wave[k];
   int pos = base + woff + incl - cnt;
   uint32_t* out = cand + (int64_t)b * cand_stride;
+  uint4* outm = cand_meta + (int64_t)b * cand_stride;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     uint32_t m = w[k];
     while (m) {
       const int bit = __ffs(m) - 1;
       m &= m - 1;
-      out[pos++] = (uint32_t)((w0 + k) * 32 + bit);
+      const uint32_t d = (uint32_t)((w0 + k) * 32 + bit);
+      const int64_t o = doc_off[d];
+      const uint32_t dl = (uint32_t)(doc_off[d + 1] - o);   // w = offset bits 32..39 | doc length << 8
+      outm[pos] = make_uint4(d, (uint32_t)ulen[d], (uint32_t)(o & 0xFFFFFFFFll), (uint32_t)((o >> 32) & 0xFF) | (dl << 8));
+      out[pos++] = d;
     }
   }
   if (ch == nchunks - 1 && tid == 255) {
@@ -707,77 +714,129 @@ __global__ void cand_prefix_kernel(const int32_t* __restrict__ n_cand, int B, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// S4  approximate score: one wave per candidate document.  QL = lanes per token (32: two tokens
-// per step, 64: one).  Each lane owns one query token q and gathers QCT[code][q] -- one
-// contiguous 4*QL-byte line per document token.  max uses '>' semantics (NaN ignored, +inf kept),
-// the sum runs in q order and skips tokens whose max stayed -inf (search.rs:305-324).
+// S4  approximate score: one wave per candidate document (search.rs:305-324).
+//   score(d) = sum_q max_{c in codes(d)} QC[q, c]        max over tokens == max over DISTINCT codes
+// QCT[b][c][:] is one contiguous row.  The chip's limit for this gather is vector-memory INSTRUCTIONS
+// (a 64-lane 4-byte load costs the texture addresser as much as a 64-lane 16-byte load; measured:
+// ~40 G row-gathers/s whether the table sits in L2, in the Infinity Cache, or the request is halved),
+// so each lane fetches a float4: LPR lanes cover one row, one instruction fetches 64/LPR rows.
+// max uses '>' semantics (NaN ignored, +inf kept); the sum runs in q order and skips tokens whose max
+// stayed -inf, so the value is bit-identical to the reference loop.
+// Candidates are walked in GLOBAL order (query after query) by all waves together, so one query's table
+// is hot in the Infinity Cache at a time; per candidate ONE 16-byte meta record {doc, n_codes, offset,
+// doc_len} (written by compact_kernel) and a 3-stage software pipeline across the wave's candidates
+// (meta of w+2nw, codes of w+nw, gathers of w) keep the dependent-load chain off the critical path.
 // ---------------------------------------------------------------------------------------------
-template <int QL>
+#define NP_S4_UNR 8       // row-gather instructions in flight per wave (the asm fence lists 8 operands)
+#define NP_S4_MAXB 1024   // queries per launch (prefix / Lq tables live in LDS)
+template <int LPR>        // lanes per QCT row: 4*LPR >= LQP, power of two in {8,16,32,64}
 __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
                                                      const int32_t* __restrict__ qoff,
-                                                     const uint32_t* __restrict__ cand, int64_t cand_stride,
+                                                     const uint4* __restrict__ cand_meta, int64_t cand_stride,
                                                      const int64_t* __restrict__ prefix, int B,
-                                                     const int64_t* __restrict__ doc_off,
-                                                     const uint32_t* __restrict__ codes,
-                                                     const int32_t* __restrict__ ulen, float* __restrict__ approx,
+                                                     const uint32_t* __restrict__ codes, float* __restrict__ approx,
                                                      Counters* ctr) {
-  // `codes` holds, at each document's offset, its codes sorted and de-duplicated (ulen[doc] of
-  // them): max over tokens == max over distinct codes, so the value is unchanged and the gather
-  // shrinks by the document's code multiplicity.
-  constexpr int TPS = 64 / QL;  // tokens per step
+  constexpr int RPI = 64 / LPR;  // rows (codes) per gather instruction
+  __shared__ int64_t s_prefix[NP_S4_MAXB + 1];
+  __shared__ int s_lq[NP_S4_MAXB];
+  for (int k = threadIdx.x; k <= B; k += 256) s_prefix[k] = prefix[k];
+  for (int k = threadIdx.x; k < B; k += 256) s_lq[k] = qoff[k + 1] - qoff[k];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int ql = lane & (QL - 1), h = lane / QL;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const int64_t total = prefix[B];
+  const int jq = lane & (LPR - 1), grp = lane / LPR;   // this lane holds q = 4*jq .. 4*jq+3 of row `grp`
+  const bool jok = 4 * jq < LQP;
+  const int jcol = jok ? 4 * jq : 0;
+  const int64_t total = s_prefix[B];
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int bc = 0;  // monotone cursor: largest b with prefix[b] <= w (empty queries are skipped)
+  auto locate = [&](int64_t w, int& bo, int64_t& io) {
+    while (bc < B - 1 && w >= s_prefix[bc + 1]) ++bc;
+    bo = bc;
+    io = w - s_prefix[bc];
+  };
   unsigned long long toks = 0, ucodes = 0;
-  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += nwaves) {
-    int lo = 0, hi = B;  // largest b with prefix[b] <= w
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (prefix[mid] <= w) lo = mid; else hi = mid;
+  uint4 m1 = make_uint4(0, 0, 0, 0), m2 = m1;
+  int b1 = 0, b2 = 0;
+  int64_t i1 = 0, i2 = 0;
+  uint32_t c1 = 0;
+  if (w0 < total) {
+    locate(w0, b1, i1);
+    m1 = cand_meta[(int64_t)b1 * cand_stride + i1];
+  }
+  if (w0 + nw < total) {
+    locate(w0 + nw, b2, i2);
+    m2 = cand_meta[(int64_t)b2 * cand_stride + i2];
+  }
+  if (w0 < total) {
+    const int64_t off1 = (int64_t)m1.z | ((int64_t)(m1.w & 0xFF) << 32);
+    c1 = (lane < (int)m1.y) ? codes[off1 + lane] : 0u;
+  }
+  for (int64_t w = w0; w < total; w += nw) {
+    const uint4 m0 = m1;
+    const int b0 = b1;
+    const int64_t i0 = i1;
+    const uint32_t creg0 = c1;
+    m1 = m2; b1 = b2; i1 = i2;
+    if (w + 2 * nw < total) {
+      locate(w + 2 * nw, b2, i2);
+      m2 = cand_meta[(int64_t)b2 * cand_stride + i2];
     }
-    const int b = lo;
-    const int64_t i = w - prefix[b];
-    const uint32_t doc = cand[(int64_t)b * cand_stride + i];
-    const int64_t off = doc_off[doc];
-    const int len = ulen[doc];
-    const int Lq = qoff[b + 1] - qoff[b];
-    const float* T = QCT + (int64_t)b * KP * LQP;
-    toks += (unsigned long long)(doc_off[doc + 1] - off);
+    if (w + nw < total) {
+      const int64_t off1 = (int64_t)m1.z | ((int64_t)(m1.w & 0xFF) << 32);
+      c1 = (lane < (int)m1.y) ? codes[off1 + lane] : 0u;
+    }
+    const int64_t off = (int64_t)m0.z | ((int64_t)(m0.w & 0xFF) << 32);
+    const int len = (int)m0.y;
+    const int Lq = s_lq[b0];
+    const float* Tj = QCT + (int64_t)b0 * KP * LQP + jcol;
+    toks += (unsigned long long)(m0.w >> 8);
     ucodes += (unsigned long long)len;
-    float score = 0.f;
-    for (int q0 = 0; q0 < Lq; q0 += QL) {
-      const int q = q0 + ql;
-      const bool qok = q < LQP;
-      const float* Tq = T + (qok ? q : LQP - 1);
-      float m = NP_NEG_INF;
-      for (int t0 = 0; t0 < len; t0 += 64) {
-        const int tl = t0 + lane;
-        const uint32_t creg = (tl < len) ? codes[off + tl] : 0u;
-        const int nt = min(64, len - t0);
-        // 8 independent gathers in flight per lane (no early exit inside the unrolled group)
-        for (int s0 = 0; s0 < 64 / TPS; s0 += 8) {
-          if (s0 * TPS >= nt) break;
-          float v[8];
+    float mx = NP_NEG_INF, my = NP_NEG_INF, mz = NP_NEG_INF, mw = NP_NEG_INF;
+    for (int t0 = 0; t0 < len; t0 += 64) {
+      const int tl = t0 + lane;
+      const uint32_t creg = (t0 == 0) ? creg0 : ((tl < len) ? codes[off + tl] : 0u);
+      const int nt = min(64, len - t0);
+      for (int s0 = 0; s0 < 64; s0 += RPI * NP_S4_UNR) {
+        if (s0 >= nt) break;
+        float4 v[NP_S4_UNR];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int t = (s0 + u) * TPS + h;
-            const uint32_t c = (uint32_t)__shfl((int)creg, t);
-            const float x = Tq[(int64_t)c * LQP];   // unconditional (c = 0 past the end): no branch per load
-            v[u] = (t < nt && qok) ? x : NP_NEG_INF;
-          }
+        for (int u = 0; u < NP_S4_UNR; ++u) {
+          const int t = s0 + u * RPI + grp;
+          const uint32_t c = (uint32_t)__shfl((int)creg, t & 63);   // c = 0 past the end: a valid row
+          v[u] = *reinterpret_cast<const float4*>(Tj + (int64_t)c * LQP);
+        }
+        // keep all NP_S4_UNR row gathers in flight together (otherwise the scheduler folds every load into
+        // its max: one destination register and an s_waitcnt vmcnt(0) after each load)
+        asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x),
+                     "+v"(v[6].x), "+v"(v[7].x));
 #pragma unroll
-          for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);  // == `if v > m` for NaN v (kept out) and +inf (kept)
+        for (int u = 0; u < NP_S4_UNR; ++u) {
+          const bool ok = (s0 + u * RPI + grp) < nt;   // fmaxf == `if v > m`: NaN never wins, +inf does
+          mx = fmaxf(mx, ok ? v[u].x : NP_NEG_INF);
+          my = fmaxf(my, ok ? v[u].y : NP_NEG_INF);
+          mz = fmaxf(mz, ok ? v[u].z : NP_NEG_INF);
+          mw = fmaxf(mw, ok ? v[u].w : NP_NEG_INF);
         }
       }
-      if (TPS == 2) m = fmaxf(m, __shfl_xor(m, 32));
-      const int nq = min(QL, Lq - q0);
-      for (int j = 0; j < nq; ++j) {
-        const float x = readlane_f(m, j);
-        if (x > NP_NEG_INF) score += x;
-      }
     }
-    if (lane == 0) approx[(int64_t)b * cand_stride + i] = score;
+    // combine the RPI row groups: lanes with equal jq
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      my = fmaxf(my, __shfl_xor(my, o));
+      mz = fmaxf(mz, __shfl_xor(mz, o));
+      mw = fmaxf(mw, __shfl_xor(mw, o));
+    }
+    float score = 0.f;   // q-ordered sum (search.rs:308-321)
+    for (int j = 0; 4 * j < Lq; ++j) {
+      const float x0 = readlane_f(mx, j), x1 = readlane_f(my, j), x2 = readlane_f(mz, j), x3 = readlane_f(mw, j);
+      if (x0 > NP_NEG_INF) score += x0;
+      if (4 * j + 1 < Lq && x1 > NP_NEG_INF) score += x1;
+      if (4 * j + 2 < Lq && x2 > NP_NEG_INF) score += x2;
+      if (4 * j + 3 < Lq && x3 > NP_NEG_INF) score += x3;
+    }
+    if (lane == 0) approx[(int64_t)b0 * cand_stride + i0] = score;
   }
   if (lane == 0 && toks) {
     atomicAdd(&ctr->n_cand_tokens, toks);

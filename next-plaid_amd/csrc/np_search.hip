@@ -8,12 +8,13 @@
 #include "np_kernels.h"
 
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 
 namespace np {
 
 struct Workspace {
-  DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, approx, n_cand,
+  DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       prefix, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset, subset_bits,
       elig, misc, cut;
   void* h_pin = nullptr;
@@ -22,7 +23,7 @@ struct Workspace {
   bool done_valid = false;
   void release_all() {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &approx, &n_cand, &prefix, &sel_keys, &sel_doc, &nsel, &exact, &out_ids,
+                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &prefix, &sel_keys, &sel_doc, &nsel, &exact, &out_ids,
                      &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc, &cut};
     for (DevBuf* b : all) b->release();
     if (h_pin) (void)hipHostFree(h_pin);
@@ -244,6 +245,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.docbits.reserve((size_t)B * std::max<int64_t>(NW, 1) * 4));
   NP_TRY(w.chunk_counts.reserve((size_t)B * std::max(nchunks, 1) * 4));
   NP_TRY(w.cand.reserve((size_t)B * cand_stride * 4));
+  NP_TRY(w.cand_meta.reserve((size_t)B * cand_stride * 16));
   NP_TRY(w.approx.reserve((size_t)B * cand_stride * 4));
   NP_TRY(w.n_cand.reserve((size_t)B * 4));
   NP_TRY(w.prefix.reserve((size_t)(B + 1) * 8));
@@ -335,6 +337,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
                                                           w.chunk_counts.as<int32_t>());
     compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
                                                      w.chunk_counts.as<int32_t>(), w.cand.as<uint32_t>(), cand_stride,
+                                                     ix->d_doc_offsets, ix->d_ulen, w.cand_meta.as<uint4>(),
                                                      w.n_cand.as<int32_t>(), w.ctr.as<Counters>());
   }
   cand_prefix_kernel<<<1, 64, 0, st>>>(w.n_cand.as<int32_t>(), B, w.prefix.as<int64_t>());
@@ -343,14 +346,15 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   // ---- S4
   if (!cs->empty_subset && ix->n_docs > 0) {
     const unsigned grid = 2048;
-    if (LQP == 32)
-      approx_kernel<32><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand.as<uint32_t>(), cand_stride,
-                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
-                                              w.approx.as<float>(), w.ctr.as<Counters>());
-    else
-      approx_kernel<64><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand.as<uint32_t>(), cand_stride,
-                                              w.prefix.as<int64_t>(), B, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
-                                              w.approx.as<float>(), w.ctr.as<Counters>());
+#define NP_LAUNCH_APPROX(LPR)                                                                                      \
+  approx_kernel<LPR><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(), cand_stride, \
+                                           w.prefix.as<int64_t>(), B, ix->d_ucodes, w.approx.as<float>(),           \
+                                           w.ctr.as<Counters>())
+    if (LQP <= 32) NP_LAUNCH_APPROX(8);
+    else if (LQP <= 64) NP_LAUNCH_APPROX(16);
+    else if (LQP <= 128) NP_LAUNCH_APPROX(32);
+    else NP_LAUNCH_APPROX(64);
+#undef NP_LAUNCH_APPROX
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
 
@@ -460,7 +464,7 @@ static int slice_size(const DeviceIndex* ix, const int32_t* h_qoff, int B) {
   for (int b = 0; b < B; ++b) maxLq = std::max(maxLq, h_qoff[b + 1] - h_qoff[b]);
   const int LQP = std::min((maxLq + 31) / 32 * 32, 32 * NP_MAX_QT);
   int64_t s = ix->opts.workspace_bytes / std::max<int64_t>(per_query_bytes(ix, LQP), 1);
-  s = std::max<int64_t>(1, std::min<int64_t>(s, ix->opts.max_batch));
+  s = std::max<int64_t>(1, std::min<int64_t>(s, std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB)));
   return (int)std::min<int64_t>(s, std::max(B, 1));
 }
 
