@@ -727,7 +727,74 @@ __global__ void cand_prefix_kernel(const int32_t* __restrict__ n_cand, int B, in
 // doc_len} (written by compact_kernel) and a 3-stage software pipeline across the wave's candidates
 // (meta of w+2nw, codes of w+nw, gathers of w) keep the dependent-load chain off the critical path.
 // ---------------------------------------------------------------------------------------------
-#define NP_S4_UNR 8       // row-gather instructions in flight per wave (the asm fence lists 8 operands)
+// N0 row-gather instructions from code register creg0 plus N1 from creg1 (the document's second 64-code
+// chunk), all in flight together: straight-line and unconditional (a load behind a branch makes the compiler
+// drain vmcnt after each one), one fence (without it the scheduler folds every load into its max: one
+// destination register and s_waitcnt vmcnt(0) per load), then the running max.
+template <int N>
+__device__ __forceinline__ void s4_fence(float4 (&v)[N]) {
+  if constexpr (N == 1) asm volatile("" : "+v"(v[0].x));
+  else if constexpr (N == 2) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x));
+  else if constexpr (N == 3) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x));
+  else if constexpr (N == 4) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x));
+  else if constexpr (N == 5) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x));
+  else if constexpr (N == 6) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x));
+  else if constexpr (N == 7) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x));
+  else if constexpr (N == 8) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
+  else if constexpr (N == 9) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x), "+v"(v[8].x));
+  else if constexpr (N == 10) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x), "+v"(v[8].x), "+v"(v[9].x));
+  else if constexpr (N == 11) asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x), "+v"(v[8].x), "+v"(v[9].x), "+v"(v[10].x));
+  else asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x), "+v"(v[8].x), "+v"(v[9].x), "+v"(v[10].x), "+v"(v[11].x));
+}
+
+template <int LPR, int N0, int N1>
+__device__ __forceinline__ void s4_gather(const float* __restrict__ Tj, int LQP, uint32_t creg0, uint32_t creg1, int s0,
+                                          int grp, int nt0, int nt1, float& mx, float& my, float& mz, float& mw) {
+  constexpr int RPI = 64 / LPR;
+  static_assert(N0 + N1 >= 1 && N0 + N1 <= 12, "fence lists at most 12 operands");
+  float4 v[N0 + N1];
+#pragma unroll
+  for (int u = 0; u < N0; ++u) {
+    const uint32_t c = (uint32_t)__shfl((int)creg0, (s0 + u * RPI + grp) & 63);   // c = 0 past the end: a valid row
+    v[u] = *reinterpret_cast<const float4*>(Tj + (int64_t)c * LQP);
+  }
+#pragma unroll
+  for (int u = 0; u < N1; ++u) {
+    const uint32_t c = (uint32_t)__shfl((int)creg1, (u * RPI + grp) & 63);
+    v[N0 + u] = *reinterpret_cast<const float4*>(Tj + (int64_t)c * LQP);
+  }
+  s4_fence<N0 + N1>(v);
+#pragma unroll
+  for (int u = 0; u < N0 + N1; ++u) {
+    const bool ok = u < N0 ? (s0 + u * RPI + grp) < nt0 : ((u - N0) * RPI + grp) < nt1;
+    mx = fmaxf(mx, ok ? v[u].x : NP_NEG_INF);   // fmaxf == `if v > m`: NaN never wins, +inf does
+    my = fmaxf(my, ok ? v[u].y : NP_NEG_INF);
+    mz = fmaxf(mz, ok ? v[u].z : NP_NEG_INF);
+    mw = fmaxf(mw, ok ? v[u].w : NP_NEG_INF);
+  }
+}
+
+// exactly ni (1..8) instructions of one 64-code chunk
+template <int LPR>
+__device__ __forceinline__ void s4_chunk(const float* __restrict__ Tj, int LQP, uint32_t creg, int grp, int nt,
+                                         float& mx, float& my, float& mz, float& mw) {
+  constexpr int RPI = 64 / LPR;
+  int s0 = 0, ni = (nt + RPI - 1) / RPI;
+  for (; ni > 8; ni -= 8, s0 += 8 * RPI) s4_gather<LPR, 8, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw);
+  switch (ni) {
+    case 8: s4_gather<LPR, 8, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 7: s4_gather<LPR, 7, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 6: s4_gather<LPR, 6, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 5: s4_gather<LPR, 5, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 4: s4_gather<LPR, 4, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 3: s4_gather<LPR, 3, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 2: s4_gather<LPR, 2, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 1: s4_gather<LPR, 1, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    default: break;
+  }
+}
+
+#define NP_S4_UNR 8       // row-gather instructions in flight per wave
 #define NP_S4_MAXB 1024   // queries per launch (prefix / Lq tables live in LDS)
 template <int LPR>        // lanes per QCT row: 4*LPR >= LQP, power of two in {8,16,32,64}
 __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
@@ -759,7 +826,7 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
   uint4 m1 = make_uint4(0, 0, 0, 0), m2 = m1;
   int b1 = 0, b2 = 0;
   int64_t i1 = 0, i2 = 0;
-  uint32_t c1 = 0;
+  uint32_t c1 = 0, c1b = 0;   // first 128 distinct codes of the next candidate
   if (w0 < total) {
     locate(w0, b1, i1);
     m1 = cand_meta[(int64_t)b1 * cand_stride + i1];
@@ -771,12 +838,13 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
   if (w0 < total) {
     const int64_t off1 = (int64_t)m1.z | ((int64_t)(m1.w & 0xFF) << 32);
     c1 = (lane < (int)m1.y) ? codes[off1 + lane] : 0u;
+    c1b = (lane + 64 < (int)m1.y) ? codes[off1 + 64 + lane] : 0u;
   }
   for (int64_t w = w0; w < total; w += nw) {
     const uint4 m0 = m1;
     const int b0 = b1;
     const int64_t i0 = i1;
-    const uint32_t creg0 = c1;
+    const uint32_t creg0 = c1, creg1 = c1b;
     m1 = m2; b1 = b2; i1 = i2;
     if (w + 2 * nw < total) {
       locate(w + 2 * nw, b2, i2);
@@ -785,6 +853,7 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
     if (w + nw < total) {
       const int64_t off1 = (int64_t)m1.z | ((int64_t)(m1.w & 0xFF) << 32);
       c1 = (lane < (int)m1.y) ? codes[off1 + lane] : 0u;
+      c1b = (lane + 64 < (int)m1.y) ? codes[off1 + 64 + lane] : 0u;
     }
     const int64_t off = (int64_t)m0.z | ((int64_t)(m0.w & 0xFF) << 32);
     const int len = (int)m0.y;
@@ -793,31 +862,25 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
     toks += (unsigned long long)(m0.w >> 8);
     ucodes += (unsigned long long)len;
     float mx = NP_NEG_INF, my = NP_NEG_INF, mz = NP_NEG_INF, mw = NP_NEG_INF;
-    for (int t0 = 0; t0 < len; t0 += 64) {
-      const int tl = t0 + lane;
-      const uint32_t creg = (t0 == 0) ? creg0 : ((tl < len) ? codes[off + tl] : 0u);
-      const int nt = min(64, len - t0);
-      for (int s0 = 0; s0 < 64; s0 += RPI * NP_S4_UNR) {
-        if (s0 >= nt) break;
-        float4 v[NP_S4_UNR];
-#pragma unroll
-        for (int u = 0; u < NP_S4_UNR; ++u) {
-          const int t = s0 + u * RPI + grp;
-          const uint32_t c = (uint32_t)__shfl((int)creg, t & 63);   // c = 0 past the end: a valid row
-          v[u] = *reinterpret_cast<const float4*>(Tj + (int64_t)c * LQP);
+    {
+      constexpr int RPI8 = (64 / LPR) * 8;   // codes covered by 8 instructions (64 when LPR == 8)
+      const int n1 = len - 64;               // codes in the second chunk
+      const int ni1 = (n1 + RPI - 1) / RPI;
+      int t0 = 0;
+      if (RPI8 == 64 && len > 64 && ni1 <= 4) {
+        // first chunk (8 instructions) and the short second chunk in flight together
+        switch (ni1) {
+          case 1: s4_gather<LPR, 8, 1>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
+          case 2: s4_gather<LPR, 8, 2>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
+          case 3: s4_gather<LPR, 8, 3>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
+          default: s4_gather<LPR, 8, 4>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
         }
-        // keep all NP_S4_UNR row gathers in flight together (otherwise the scheduler folds every load into
-        // its max: one destination register and an s_waitcnt vmcnt(0) after each load)
-        asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x),
-                     "+v"(v[6].x), "+v"(v[7].x));
-#pragma unroll
-        for (int u = 0; u < NP_S4_UNR; ++u) {
-          const bool ok = (s0 + u * RPI + grp) < nt;   // fmaxf == `if v > m`: NaN never wins, +inf does
-          mx = fmaxf(mx, ok ? v[u].x : NP_NEG_INF);
-          my = fmaxf(my, ok ? v[u].y : NP_NEG_INF);
-          mz = fmaxf(mz, ok ? v[u].z : NP_NEG_INF);
-          mw = fmaxf(mw, ok ? v[u].w : NP_NEG_INF);
-        }
+        t0 = 128;
+      }
+      for (; t0 < len; t0 += 64) {
+        const int tl = t0 + lane;
+        const uint32_t creg = (t0 == 0) ? creg0 : (t0 == 64 ? creg1 : ((tl < len) ? codes[off + tl] : 0u));
+        s4_chunk<LPR>(Tj, LQP, creg, grp, min(64, len - t0), mx, my, mz, mw);
       }
     }
     // combine the RPI row groups: lanes with equal jq
