@@ -730,7 +730,9 @@ __global__ void cand_prefix_kernel(const int32_t* __restrict__ n_cand, int B, in
 // N0 row-gather instructions from code register creg0 plus N1 from creg1 (the document's second 64-code
 // chunk), all in flight together: straight-line and unconditional (a load behind a branch makes the compiler
 // drain vmcnt after each one), one fence (without it the scheduler folds every load into its max: one
-// destination register and s_waitcnt vmcnt(0) per load), then the running max.
+// destination register and s_waitcnt vmcnt(0) per load), then the running max.  Lanes past the document's
+// last code carry a DUPLICATE of a valid code, so no load needs masking.  Rows are addressed as a wave-uniform
+// base + 32-bit byte offset (one query's table is < 4 GiB).
 template <int N>
 __device__ __forceinline__ void s4_fence(float4 (&v)[N]) {
   if constexpr (N == 1) asm volatile("" : "+v"(v[0].x));
@@ -748,54 +750,52 @@ __device__ __forceinline__ void s4_fence(float4 (&v)[N]) {
 }
 
 template <int LPR, int N0, int N1>
-__device__ __forceinline__ void s4_gather(const float* __restrict__ Tj, int LQP, uint32_t creg0, uint32_t creg1, int s0,
-                                          int grp, int nt0, int nt1, float& mx, float& my, float& mz, float& mw) {
+__device__ __forceinline__ void s4_gather(const char* __restrict__ Tb, uint32_t row_bytes, uint32_t col_bytes, uint32_t creg0,
+                                          uint32_t creg1, int s0, int grp, float& mx, float& my, float& mz, float& mw) {
   constexpr int RPI = 64 / LPR;
   static_assert(N0 + N1 >= 1 && N0 + N1 <= 12, "fence lists at most 12 operands");
   float4 v[N0 + N1];
 #pragma unroll
   for (int u = 0; u < N0; ++u) {
-    const uint32_t c = (uint32_t)__shfl((int)creg0, (s0 + u * RPI + grp) & 63);   // c = 0 past the end: a valid row
-    v[u] = *reinterpret_cast<const float4*>(Tj + (int64_t)c * LQP);
+    const uint32_t c = (uint32_t)__shfl((int)creg0, (s0 + u * RPI + grp) & 63);
+    v[u] = *reinterpret_cast<const float4*>(Tb + (c * row_bytes + col_bytes));
   }
 #pragma unroll
   for (int u = 0; u < N1; ++u) {
     const uint32_t c = (uint32_t)__shfl((int)creg1, (u * RPI + grp) & 63);
-    v[N0 + u] = *reinterpret_cast<const float4*>(Tj + (int64_t)c * LQP);
+    v[N0 + u] = *reinterpret_cast<const float4*>(Tb + (c * row_bytes + col_bytes));
   }
   s4_fence<N0 + N1>(v);
 #pragma unroll
-  for (int u = 0; u < N0 + N1; ++u) {
-    const bool ok = u < N0 ? (s0 + u * RPI + grp) < nt0 : ((u - N0) * RPI + grp) < nt1;
-    mx = fmaxf(mx, ok ? v[u].x : NP_NEG_INF);   // fmaxf == `if v > m`: NaN never wins, +inf does
-    my = fmaxf(my, ok ? v[u].y : NP_NEG_INF);
-    mz = fmaxf(mz, ok ? v[u].z : NP_NEG_INF);
-    mw = fmaxf(mw, ok ? v[u].w : NP_NEG_INF);
+  for (int u = 0; u < N0 + N1; ++u) {   // fmaxf == `if v > m`: NaN never wins, +inf does
+    mx = fmaxf(mx, v[u].x);
+    my = fmaxf(my, v[u].y);
+    mz = fmaxf(mz, v[u].z);
+    mw = fmaxf(mw, v[u].w);
   }
 }
 
-// exactly ni (1..8) instructions of one 64-code chunk
+// exactly ceil(nt / RPI) instructions of one 64-code chunk
 template <int LPR>
-__device__ __forceinline__ void s4_chunk(const float* __restrict__ Tj, int LQP, uint32_t creg, int grp, int nt,
-                                         float& mx, float& my, float& mz, float& mw) {
+__device__ __forceinline__ void s4_chunk(const char* __restrict__ Tb, uint32_t row_bytes, uint32_t col_bytes, uint32_t creg,
+                                         int grp, int nt, float& mx, float& my, float& mz, float& mw) {
   constexpr int RPI = 64 / LPR;
   int s0 = 0, ni = (nt + RPI - 1) / RPI;
-  for (; ni > 8; ni -= 8, s0 += 8 * RPI) s4_gather<LPR, 8, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw);
+  for (; ni > 8; ni -= 8, s0 += 8 * RPI) s4_gather<LPR, 8, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw);
   switch (ni) {
-    case 8: s4_gather<LPR, 8, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
-    case 7: s4_gather<LPR, 7, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
-    case 6: s4_gather<LPR, 6, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
-    case 5: s4_gather<LPR, 5, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
-    case 4: s4_gather<LPR, 4, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
-    case 3: s4_gather<LPR, 3, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
-    case 2: s4_gather<LPR, 2, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
-    case 1: s4_gather<LPR, 1, 0>(Tj, LQP, creg, 0u, s0, grp, nt, 0, mx, my, mz, mw); break;
+    case 8: s4_gather<LPR, 8, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
+    case 7: s4_gather<LPR, 7, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
+    case 6: s4_gather<LPR, 6, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
+    case 5: s4_gather<LPR, 5, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
+    case 4: s4_gather<LPR, 4, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
+    case 3: s4_gather<LPR, 3, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
+    case 2: s4_gather<LPR, 2, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
+    case 1: s4_gather<LPR, 1, 0>(Tb, row_bytes, col_bytes, creg, 0u, s0, grp, mx, my, mz, mw); break;
     default: break;
   }
 }
 
-#define NP_S4_UNR 8       // row-gather instructions in flight per wave
-#define NP_S4_MAXB 1024   // queries per launch (prefix / Lq tables live in LDS)
+#define NP_S4_MAXB 256    // queries per launch (prefix / Lq tables live in LDS)
 template <int LPR>        // lanes per QCT row: 4*LPR >= LQP, power of two in {8,16,32,64}
 __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
                                                      const int32_t* __restrict__ qoff,
@@ -803,30 +803,56 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
                                                      const int64_t* __restrict__ prefix, int B,
                                                      const uint32_t* __restrict__ codes, float* __restrict__ approx,
                                                      Counters* ctr) {
-  constexpr int RPI = 64 / LPR;  // rows (codes) per gather instruction
+  constexpr int RPI = 64 / LPR;            // rows (codes) per gather instruction
+  constexpr int RW = 4 * LPR + 1;          // LDS row stride in floats (+1: conflict-free column walks)
+  constexpr int DPF = 256 / LPR;         // documents per flush (32 at Lq <= 32): ~17 KB of LDS per block
   __shared__ int64_t s_prefix[NP_S4_MAXB + 1];
   __shared__ int s_lq[NP_S4_MAXB];
+  __shared__ float s_rows[4][DPF * RW];    // per wave: combined per-token maxima of the last DPF documents
+  __shared__ int64_t s_out[4][DPF];        // their output positions
+  __shared__ int s_olq[4][DPF];            // and query lengths
   for (int k = threadIdx.x; k <= B; k += 256) s_prefix[k] = prefix[k];
   for (int k = threadIdx.x; k < B; k += 256) s_lq[k] = qoff[k + 1] - qoff[k];
   __syncthreads();
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jq = lane & (LPR - 1), grp = lane / LPR;   // this lane holds q = 4*jq .. 4*jq+3 of row `grp`
-  const bool jok = 4 * jq < LQP;
-  const int jcol = jok ? 4 * jq : 0;
+  const uint32_t row_bytes = (uint32_t)LQP * 4u;
+  const uint32_t col_bytes = (4 * jq < LQP) ? (uint32_t)jq * 16u : 0u;
   const int64_t total = s_prefix[B];
   const int64_t nw = (int64_t)gridDim.x * 4;
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave;
+  float* rows = s_rows[wave];
   int bc = 0;  // monotone cursor: largest b with prefix[b] <= w (empty queries are skipped)
   auto locate = [&](int64_t w, int& bo, int64_t& io) {
     while (bc < B - 1 && w >= s_prefix[bc + 1]) ++bc;
     bo = bc;
     io = w - s_prefix[bc];
   };
+  // q-ordered sums (search.rs:308-321) of the buffered documents: lane d walks document d's row, so the 32
+  // dependent adds are paid once per DPF documents instead of once per document
+  auto flush = [&](int nbuf) {
+    if (lane < nbuf) {
+      const float* r = rows + lane * RW;
+      const int lq = s_olq[wave][lane];
+      float score = 0.f;
+      for (int q = 0; q < lq; ++q) {
+        const float x = r[q];
+        if (x > NP_NEG_INF) score += x;
+      }
+      approx[s_out[wave][lane]] = score;
+    }
+  };
   unsigned long long toks = 0, ucodes = 0;
   uint4 m1 = make_uint4(0, 0, 0, 0), m2 = m1;
   int b1 = 0, b2 = 0;
   int64_t i1 = 0, i2 = 0;
-  uint32_t c1 = 0, c1b = 0;   // first 128 distinct codes of the next candidate
+  uint32_t c1 = 0, c1b = 0;   // first 128 distinct codes of the next candidate (padding lanes: a duplicate)
+  auto fetch_codes = [&](const uint4& m) {
+    const int64_t off1 = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
+    const int n = (int)m.y;
+    c1 = n > 0 ? codes[off1 + min(lane, n - 1)] : 0u;
+    c1b = n > 64 ? codes[off1 + min(64 + lane, n - 1)] : 0u;
+  };
   if (w0 < total) {
     locate(w0, b1, i1);
     m1 = cand_meta[(int64_t)b1 * cand_stride + i1];
@@ -835,11 +861,8 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
     locate(w0 + nw, b2, i2);
     m2 = cand_meta[(int64_t)b2 * cand_stride + i2];
   }
-  if (w0 < total) {
-    const int64_t off1 = (int64_t)m1.z | ((int64_t)(m1.w & 0xFF) << 32);
-    c1 = (lane < (int)m1.y) ? codes[off1 + lane] : 0u;
-    c1b = (lane + 64 < (int)m1.y) ? codes[off1 + 64 + lane] : 0u;
-  }
+  if (w0 < total) fetch_codes(m1);
+  int nbuf = 0;
   for (int64_t w = w0; w < total; w += nw) {
     const uint4 m0 = m1;
     const int b0 = b1;
@@ -850,37 +873,30 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
       locate(w + 2 * nw, b2, i2);
       m2 = cand_meta[(int64_t)b2 * cand_stride + i2];
     }
-    if (w + nw < total) {
-      const int64_t off1 = (int64_t)m1.z | ((int64_t)(m1.w & 0xFF) << 32);
-      c1 = (lane < (int)m1.y) ? codes[off1 + lane] : 0u;
-      c1b = (lane + 64 < (int)m1.y) ? codes[off1 + 64 + lane] : 0u;
-    }
+    if (w + nw < total) fetch_codes(m1);
     const int64_t off = (int64_t)m0.z | ((int64_t)(m0.w & 0xFF) << 32);
     const int len = (int)m0.y;
-    const int Lq = s_lq[b0];
-    const float* Tj = QCT + (int64_t)b0 * KP * LQP + jcol;
+    const char* Tb = reinterpret_cast<const char*>(QCT + (int64_t)b0 * KP * LQP);
     toks += (unsigned long long)(m0.w >> 8);
     ucodes += (unsigned long long)len;
     float mx = NP_NEG_INF, my = NP_NEG_INF, mz = NP_NEG_INF, mw = NP_NEG_INF;
     {
-      constexpr int RPI8 = (64 / LPR) * 8;   // codes covered by 8 instructions (64 when LPR == 8)
       const int n1 = len - 64;               // codes in the second chunk
       const int ni1 = (n1 + RPI - 1) / RPI;
       int t0 = 0;
-      if (RPI8 == 64 && len > 64 && ni1 <= 4) {
+      if (RPI == 8 && len > 64 && ni1 <= 4) {
         // first chunk (8 instructions) and the short second chunk in flight together
         switch (ni1) {
-          case 1: s4_gather<LPR, 8, 1>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
-          case 2: s4_gather<LPR, 8, 2>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
-          case 3: s4_gather<LPR, 8, 3>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
-          default: s4_gather<LPR, 8, 4>(Tj, LQP, creg0, creg1, 0, grp, 64, n1, mx, my, mz, mw); break;
+          case 1: s4_gather<LPR, 8, 1>(Tb, row_bytes, col_bytes, creg0, creg1, 0, grp, mx, my, mz, mw); break;
+          case 2: s4_gather<LPR, 8, 2>(Tb, row_bytes, col_bytes, creg0, creg1, 0, grp, mx, my, mz, mw); break;
+          case 3: s4_gather<LPR, 8, 3>(Tb, row_bytes, col_bytes, creg0, creg1, 0, grp, mx, my, mz, mw); break;
+          default: s4_gather<LPR, 8, 4>(Tb, row_bytes, col_bytes, creg0, creg1, 0, grp, mx, my, mz, mw); break;
         }
         t0 = 128;
       }
       for (; t0 < len; t0 += 64) {
-        const int tl = t0 + lane;
-        const uint32_t creg = (t0 == 0) ? creg0 : (t0 == 64 ? creg1 : ((tl < len) ? codes[off + tl] : 0u));
-        s4_chunk<LPR>(Tj, LQP, creg, grp, min(64, len - t0), mx, my, mz, mw);
+        const uint32_t creg = (t0 == 0) ? creg0 : (t0 == 64 ? creg1 : codes[off + min(t0 + lane, len - 1)]);
+        s4_chunk<LPR>(Tb, row_bytes, col_bytes, creg, grp, min(64, len - t0), mx, my, mz, mw);
       }
     }
     // combine the RPI row groups: lanes with equal jq
@@ -891,16 +907,20 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
       mz = fmaxf(mz, __shfl_xor(mz, o));
       mw = fmaxf(mw, __shfl_xor(mw, o));
     }
-    float score = 0.f;   // q-ordered sum (search.rs:308-321)
-    for (int j = 0; 4 * j < Lq; ++j) {
-      const float x0 = readlane_f(mx, j), x1 = readlane_f(my, j), x2 = readlane_f(mz, j), x3 = readlane_f(mw, j);
-      if (x0 > NP_NEG_INF) score += x0;
-      if (4 * j + 1 < Lq && x1 > NP_NEG_INF) score += x1;
-      if (4 * j + 2 < Lq && x2 > NP_NEG_INF) score += x2;
-      if (4 * j + 3 < Lq && x3 > NP_NEG_INF) score += x3;
+    if (lane < LPR) {
+      float* r = rows + nbuf * RW + 4 * jq;
+      r[0] = mx; r[1] = my; r[2] = mz; r[3] = mw;
     }
-    if (lane == 0) approx[(int64_t)b0 * cand_stride + i0] = score;
+    if (lane == 0) {
+      s_out[wave][nbuf] = (int64_t)b0 * cand_stride + i0;
+      s_olq[wave][nbuf] = s_lq[b0];
+    }
+    if (++nbuf == DPF) {
+      flush(nbuf);
+      nbuf = 0;
+    }
   }
+  flush(nbuf);
   if (lane == 0 && toks) {
     atomicAdd(&ctr->n_cand_tokens, toks);
     atomicAdd(&ctr->n_cand_codes, ucodes);
