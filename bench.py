@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--n-full-scores", type=int, default=4096)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--threshold", type=float, default=0.4, help="centroid_score_threshold; <0 = None")
-    ap.add_argument("--precision", type=int, default=0,
+    ap.add_argument("--precision", type=int, default=2,
                     help="exact MaxSim arithmetic: 0 exact-f32 MFMA, 1 QC-reuse bf16, 2 QC-reuse split-bf16 (f32-class), 3 plain bf16")
     ap.add_argument("--cpu-queries", type=int, default=64, help="queries of the CPU-oracle leg (0 = skip)")
     ap.add_argument("--query-batches", type=int, default=4)

@@ -166,16 +166,17 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// S2 helpers: block-level radix select for 32 query tokens at once.
-// Thread (r = tid>>5, q = tid&31); `enumerate(cb)` calls cb(key) for this thread's items of
+// S2 helpers: block-level radix select for QW query tokens at once.
+// Thread (r = tid / QW, q = tid % QW); `enumerate(cb)` calls cb(key) for this thread's items of
 // token q.  On return s_prefix[q] = key of the want-th largest item, s_rem[q] = how many items
 // equal to that key belong to the top `want`.
 // ---------------------------------------------------------------------------------------------
-template <class Enum>
-__device__ __forceinline__ void radix_select32(Enum&& enumerate, uint32_t want, uint32_t* hist /*[256*32]*/,
-                                               uint32_t* part /*[8*32]*/, uint32_t* s_prefix, uint32_t* s_rem,
-                                               int tid) {
-  const int q = tid & 31, r = tid >> 5;
+template <int QW, class Enum>
+__device__ __forceinline__ void radix_select(Enum&& enumerate, uint32_t want, uint32_t* hist /*[256*QW]*/,
+                                             uint32_t* part /*[256]*/, uint32_t* s_prefix, uint32_t* s_rem, int tid) {
+  constexpr int NR = 256 / QW;      // thread rows
+  constexpr int BPR = 256 / NR;     // histogram bins summed per row-thread (= QW)
+  const int q = tid % QW, r = tid / QW;
   if (r == 0) {
     s_prefix[q] = 0;
     s_rem[q] = want;
@@ -183,29 +184,29 @@ __device__ __forceinline__ void radix_select32(Enum&& enumerate, uint32_t want, 
   __syncthreads();
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
-    for (int i = tid; i < 256 * 32; i += 256) hist[i] = 0;
+    for (int i = tid; i < 256 * QW; i += 256) hist[i] = 0;
     __syncthreads();
     const uint32_t pre = s_prefix[q];
     enumerate([&](uint32_t key) {
-      if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&hist[((key >> shift) & 255u) * 32 + q], 1u);
+      if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&hist[((key >> shift) & 255u) * QW + q], 1u);
     });
     __syncthreads();
-    uint32_t s = 0;
-    for (int i = 0; i < 32; ++i) s += hist[(r * 32 + i) * 32 + q];
-    part[r * 32 + q] = s;
+    uint32_t sum = 0;
+    for (int i = 0; i < BPR; ++i) sum += hist[(r * BPR + i) * QW + q];
+    part[r * QW + q] = sum;
     __syncthreads();
     if (r == 0) {
       const uint32_t rem = s_rem[q];
       uint32_t cum = 0;
-      int R = 7;
+      int R = NR - 1;
       for (; R > 0; --R) {
-        const uint32_t pr = part[R * 32 + q];
+        const uint32_t pr = part[R * QW + q];
         if (cum + pr >= rem) break;
         cum += pr;
       }
-      int bin = R * 32 + 31;
-      for (; bin > R * 32; --bin) {
-        const uint32_t h = hist[bin * 32 + q];
+      int bin = R * BPR + BPR - 1;
+      for (; bin > R * BPR; --bin) {
+        const uint32_t h = hist[bin * QW + q];
         if (cum + h >= rem) break;
         cum += h;
       }
@@ -230,6 +231,7 @@ struct ProbeP {
   float thr;
   int64_t slab;            // > 0: batched-probe semantics (search.rs:140-254) with this centroid_batch_size
   uint32_t* cellbits;      // [B][KP/32] zeroed
+  uint32_t* tauq;          // [B][LQP] per token: okey of its n_probe-th best centroid (0 = everything)
   uint32_t* cells_tmp;     // [B][KP]
   uint32_t* cells;         // [B][KP]
   int32_t* n_cells;        // [B]
@@ -258,14 +260,15 @@ __device__ __forceinline__ void wave_select_mark(int nslots, uint32_t n_probe, c
   rem = n_probe > gt ? n_probe - gt : 0u;
 }
 
-__global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
-  __shared__ uint32_t hist[256 * 32];
-  __shared__ uint32_t part[8 * 32];
-  __shared__ uint32_t s_prefix[32], s_rem[32], s_taug[32], s_gcnt[32];
-  __shared__ uint32_t s_glist[32 * NP_PROBE_CAPG];
-  __shared__ uint32_t s_tauq[32 * NP_MAX_QT];   // per token: okey of its n_probe-th best centroid (0 = everything)
-  __shared__ uint32_t s_ntmp, s_nfinal;
-  const int b = blockIdx.x, tid = threadIdx.x, q = tid & 31, r = tid >> 5;
+#define NP_PROBE_QW 8   // query tokens per probe block: grid = (LQP / 8, B)
+__global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
+  constexpr int QW = NP_PROBE_QW;
+  __shared__ uint32_t hist[256 * QW];
+  __shared__ uint32_t part[256];
+  __shared__ uint32_t s_prefix[QW], s_rem[QW], s_taug[QW], s_gcnt[QW];
+  __shared__ uint32_t s_glist[QW * NP_PROBE_CAPG];
+  constexpr int NR = 256 / QW;
+  const int b = blockIdx.y, qc = blockIdx.x, tid = threadIdx.x, q = tid % QW, r = tid / QW;
   const int wave = tid >> 6, lane = tid & 63;
   const int Lq = p.qoff[b + 1] - p.qoff[b];
   const int64_t G = p.KP >> 5;
@@ -277,10 +280,10 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
   const int64_t eff = p.nprobe_dev ? (int64_t)*p.nprobe_dev : (int64_t)p.nprobe;
   const uint32_t n_probe = (uint32_t)min(eff, pool);  // search.rs:405
   const bool take_all = pool <= (int64_t)n_probe;
-  if (tid == 0) { s_ntmp = 0; s_nfinal = 0; }
-  for (int i = tid; i < 32 * NP_MAX_QT; i += 256) s_tauq[i] = 0;
+  uint32_t* tauq = p.tauq + (int64_t)b * LQP;
 
   if (n_probe > 0 && take_all && Lq > 0) {
+    if (qc != 0) return;   // one block marks the whole pool
     // every pooled centroid is selected by every token (search.rs:406: len <= n_probe)
     for (int64_t w = tid; w < G; w += 256) {
       uint32_t m = p.elig ? p.elig[w] : 0xFFFFFFFFu;
@@ -289,23 +292,23 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
       if (m) atomicOr(&bits[w], m);
     }
   } else if (n_probe > 0) {
-    for (int qc = 0; qc < (LQP >> 5); ++qc) {
-      if (qc * 32 >= Lq) break;
-      const int qq = qc * 32 + q;
+    {
+      if (qc * QW >= Lq) return;
+      const int qq = qc * QW + q;
       const bool qvalid = qq < Lq;
       // ---- phase 1 (block, 32 tokens at once): tau_g[q] = n_probe-th largest group maximum
       const bool use_groups = G > (int64_t)n_probe;
       if (use_groups) {
-        radix_select32(
+        radix_select<QW>(
             [&](auto&& cb) {
               if (qvalid)
-                for (int64_t g = r; g < G; g += 64) {   // 8 independent loads in flight
+                for (int64_t g = r; g < G; g += 8 * NR) {   // 8 independent loads in flight
                   uint32_t kv[8];
 #pragma unroll
-                  for (int u = 0; u < 8; ++u) kv[u] = (g + 8 * u < G) ? gm[(g + 8 * u) * LQP + qq] : 0u;
+                  for (int u = 0; u < 8; ++u) kv[u] = (g + NR * u < G) ? gm[(g + NR * u) * LQP + qq] : 0u;
 #pragma unroll
                   for (int u = 0; u < 8; ++u)
-                    if (g + 8 * u < G) cb(kv[u]);
+                    if (g + NR * u < G) cb(kv[u]);
                 }
             },
             n_probe, hist, part, s_prefix, s_rem, tid);
@@ -318,23 +321,23 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
       // ---- surviving groups -> per-token lists (order irrelevant)
       if (qvalid) {
         const uint32_t taug = s_taug[q];
-        for (int64_t g = r; g < G; g += 64) {
+        for (int64_t g = r; g < G; g += 8 * NR) {
           uint32_t kv[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) kv[u] = (g + 8 * u < G) ? gm[(g + 8 * u) * LQP + qq] : 0u;
+          for (int u = 0; u < 8; ++u) kv[u] = (g + NR * u < G) ? gm[(g + NR * u) * LQP + qq] : 0u;
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            if (g + 8 * u < G && kv[u] >= taug) {
+            if (g + NR * u < G && kv[u] >= taug) {
               const uint32_t pos = atomicAdd(&s_gcnt[q], 1u);
-              if (pos < NP_PROBE_CAPG) s_glist[q * NP_PROBE_CAPG + pos] = (uint32_t)(g + 8 * u);
+              if (pos < NP_PROBE_CAPG) s_glist[q * NP_PROBE_CAPG + pos] = (uint32_t)(g + NR * u);
             }
           }
         }
       }
       __syncthreads();
       // ---- phases 2+3: one wave per token
-      for (int t = wave; t < 32; t += 4) {
-        const int tq = qc * 32 + t;
+      for (int t = wave; t < QW; t += 4) {
+        const int tq = qc * QW + t;
         if (tq >= Lq) break;
         const uint32_t ng = s_gcnt[t];
         const float* col = QCT + tq;
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
           }
           uint32_t tau, rem;
           wave_select_mark(nslots, n_probe, keys, tau, rem);
-          if (lane == 0) s_tauq[tq] = tau ? tau - 1u : 0u;
+          if (lane == 0) tauq[tq] = tau ? tau - 1u : 0u;
           uint32_t taken = 0;  // ties at the cut (unspecified in the reference): first `rem` in slot order
 #pragma unroll
           for (int j = 0; j < 32; ++j) {
@@ -404,7 +407,7 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
           }
           const uint32_t gt = count_ge(prefix, true);
           const uint32_t rem = n_probe > gt ? n_probe - gt : 0u;
-          if (lane == 0) s_tauq[tq] = prefix ? prefix - 1u : 0u;
+          if (lane == 0) tauq[tq] = prefix ? prefix - 1u : 0u;
           uint32_t taken = 0;
           for (int64_t g0 = 0; g0 < G; g0 += 64) {
             const int64_t g = g0 + lane;
@@ -426,7 +429,22 @@ __global__ void __launch_bounds__(256) probe_kernel(ProbeP p) {
       __syncthreads();
     }
   }
-  __threadfence();
+}
+
+__global__ void __launch_bounds__(256) probe_finish_kernel(ProbeP p) {
+  __shared__ uint32_t s_ntmp, s_nfinal;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int Lq = p.qoff[b + 1] - p.qoff[b];
+  const int64_t G = p.KP >> 5;
+  const int LQP = p.LQP;
+  const float* QCT = p.QCT + (int64_t)b * p.KP * LQP;
+  uint32_t* bits = p.cellbits + (int64_t)b * G;
+  const uint32_t* s_tauq = p.tauq + (int64_t)b * LQP;
+  const int64_t pool = p.elig ? (int64_t)*p.n_elig : p.K;
+  const int64_t eff = p.nprobe_dev ? (int64_t)*p.nprobe_dev : (int64_t)p.nprobe;
+  const uint32_t n_probe = (uint32_t)min(eff, pool);
+  if (tid == 0) { s_ntmp = 0; s_nfinal = 0; }
   __syncthreads();
   // ---- compact the marked cells
   uint32_t* tmp = p.cells_tmp + (int64_t)b * p.KP;
@@ -1365,7 +1383,8 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
   // slot (s, kk, e) of the MFMA k dimension <-> dim kk*DIM/2 + 8s + e, for A (tokens) and B (query) alike
   const __bf16* Qb = p.Qb + (int64_t)b * LQP * DIM + kk * (DIM / 2);
   const __bf16* Ql = p.Qb_lo + (int64_t)b * LQP * DIM + kk * (DIM / 2);
-  const float* QC = p.QCT + (int64_t)b * p.KP * LQP;
+  const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP) + li * 4;
+  const uint32_t row_bytes = (uint32_t)LQP * 4u;
   bf16x8 bh0[NS], bl0[SPLIT == 3 ? NS : 1];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -1397,7 +1416,7 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
       const bool valid = tt < len;
       const int64_t tok = off + (valid ? tt : len - 1);
       code_n = p.codes[tok];
-      rn_n = valid ? p.inv_norm[tok] : 0.f;
+      rn_n = valid ? p.inv_norm[tok] : __builtin_nanf("");   // rows past the end become NaN and drop out of fmaxf
       const uint32_t* rp = reinterpret_cast<const uint32_t*>(p.residuals + tok * PD + kk * PH);
       if constexpr (NW % 4 == 0) {
 #pragma unroll
@@ -1434,7 +1453,7 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
       }
       f32x16 acc0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = QC[(int64_t)crow[r] * LQP + li];   // C-in = Q.C[code], q-tile 0
+      for (int r = 0; r < 16; ++r) acc0[r] = *reinterpret_cast<const float*>(QCb + crow[r] * row_bytes);   // C-in = Q.C[code], q-tile 0
       // residual bytes -> bf16 A fragments (8 dims = 8*NBITS/8 bytes per k-step)
       bf16x8 ah[NS], al[SPLIT == 3 ? NS : 1];
 #pragma unroll
@@ -1474,7 +1493,7 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
             acc = acc0;
           } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = QC[(int64_t)crow[r] * LQP + qt * 32 + li];
+            for (int r = 0; r < 16; ++r) acc[r] = *reinterpret_cast<const float*>(QCb + (crow[r] * row_bytes + qt * 128));
           }
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
@@ -1495,9 +1514,10 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
           float mm = m[qt];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int trow = t0 + mfma_row(r, kk);
             const float x = acc[r] * rrow[r];
-            if (trow < len && finitef(x)) mm = fmaxf(mm, x);
+            // maxsim.rs:284-291 ignores non-finite entries: x + (x - x) is x when finite and NaN for
+            // +-inf / NaN, and fmaxf never returns a NaN operand
+            mm = fmaxf(mm, x + (x - x));
           }
           m[qt] = mm;
         }

@@ -14,7 +14,7 @@
 namespace np {
 
 struct Workspace {
-  DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
+  DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       prefix, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset, subset_bits,
       elig, misc, cut;
   void* h_pin = nullptr;
@@ -22,7 +22,7 @@ struct Workspace {
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
   bool done_valid = false;
   void release_all() {
-    DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
+    DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
                      &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &prefix, &sel_keys, &sel_doc, &nsel, &exact, &out_ids,
                      &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc, &cut};
     for (DevBuf* b : all) b->release();
@@ -239,6 +239,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.QCT.reserve((size_t)B * KP * LQP * 4));
   NP_TRY(w.gmax.reserve((size_t)B * G * LQP * 4));
   NP_TRY(w.cellbits.reserve((size_t)B * G * 4));
+  NP_TRY(w.tauq.reserve((size_t)B * LQP * 4));
   NP_TRY(w.cells_tmp.reserve((size_t)B * KP * 4));
   NP_TRY(w.cells.reserve((size_t)B * KP * 4));
   NP_TRY(w.n_cells.reserve((size_t)B * 4));
@@ -266,6 +267,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_HIP(hipMemsetAsync(w.n_cand.p, 0, (size_t)B * 4, st));
   NP_HIP(hipMemsetAsync(w.nsel.p, 0, (size_t)B * 4, st));
   NP_HIP(hipMemsetAsync(w.cellbits.p, 0, (size_t)B * G * 4, st));
+  NP_HIP(hipMemsetAsync(w.tauq.p, 0, (size_t)B * LQP * 4, st));
   if (NW > 0) NP_HIP(hipMemsetAsync(w.docbits.p, 0, (size_t)B * NW * 4, st));
   if (cs->n_sel > 0) NP_HIP(hipMemsetAsync(w.sel_keys.p, 0, (size_t)B * cs->n_sel * 8, st));
   if (B == 0) return NP_OK;
@@ -319,11 +321,13 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     pp.thr = prm.centroid_score_threshold;
     pp.slab = batched ? (int64_t)prm.centroid_batch_size : 0;
     pp.cellbits = w.cellbits.as<uint32_t>();
+    pp.tauq = w.tauq.as<uint32_t>();
     pp.cells_tmp = w.cells_tmp.as<uint32_t>();
     pp.cells = w.cells.as<uint32_t>();
     pp.n_cells = w.n_cells.as<int32_t>();
     pp.ctr = w.ctr.as<Counters>();
-    probe_kernel<<<B, 256, 0, st>>>(pp);
+    probe_mark_kernel<<<dim3((unsigned)(LQP / NP_PROBE_QW), B), 256, 0, st>>>(pp);
+    probe_finish_kernel<<<B, 256, 0, st>>>(pp);
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));
 
