@@ -55,6 +55,9 @@ def parse():
                     help="exact MaxSim arithmetic: 0 exact-f32 MFMA, 1 QC-reuse bf16, 2 QC-reuse split-bf16 (f32-class), 3 plain bf16")
     ap.add_argument("--cpu-queries", type=int, default=64, help="queries of the CPU-oracle leg (0 = skip)")
     ap.add_argument("--query-batches", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the steps are issued on round-robin (each step = one full batch pass; 2 lets the "
+                         "small launch-bound kernels of one batch overlap the memory-bound ones of the next)")
     return ap.parse_args()
 
 
@@ -85,7 +88,7 @@ def main():
     cen = synth.centroids(spec)
     t0 = time.time()
     ix = npa.MmapIndex.synth(spec, centroids=cen, device=local_rank, shard_rank=rank, shard_count=world,
-                             max_batch=a.batch, n_contexts=1)
+                             max_batch=a.batch, n_contexts=max(1, a.streams))
     t_build = time.time() - t0
     thr = None if a.threshold < 0 else a.threshold
     prm = npa.SearchParameters(n_full_scores=a.n_full_scores, top_k=a.top_k, n_ivf_probe=a.nprobe,
@@ -95,13 +98,16 @@ def main():
     nq = a.batch * a.query_batches
     qs, src = synth.make_queries(spec, nq, n_tokens=a.query_tokens, cen=cen)
     off = np.arange(a.batch + 1, dtype=np.int32) * a.query_tokens
-    stream = torch.cuda.Stream(dev)
+    nstr = max(1, a.streams) if world == 1 else 1
+    streams = [torch.cuda.Stream(dev) for _ in range(nstr)]
+    stream = streams[0]
     with torch.cuda.stream(stream):
         dq = [torch.from_numpy(np.concatenate(qs[i * a.batch:(i + 1) * a.batch], 0)).to(dev) for i in range(a.query_batches)]
         doff = torch.from_numpy(off).to(dev)
-        o_ids = torch.zeros((a.batch, max(a.top_k, 1)), dtype=torch.int64, device=dev)
-        o_sc = torch.zeros((a.batch, max(a.top_k, 1)), dtype=torch.float32, device=dev)
-        o_cnt = torch.zeros(a.batch, dtype=torch.int32, device=dev)
+        o_ids = [torch.zeros((a.batch, max(a.top_k, 1)), dtype=torch.int64, device=dev) for _ in range(nstr)]
+        o_sc = [torch.zeros((a.batch, max(a.top_k, 1)), dtype=torch.float32, device=dev) for _ in range(nstr)]
+        o_cnt = [torch.zeros(a.batch, dtype=torch.int32, device=dev) for _ in range(nstr)]
+    torch.cuda.synchronize(dev)
     L = api.lib()
     cp = prm._c()
 
@@ -113,11 +119,12 @@ def main():
             return ss.search_batch_device(dq[i % a.query_batches], doff, off, prm)
     else:
         def step(i):
+            s = i % nstr
             api._check(L.np_hip_search_batch_device(
                 ix._h, C.c_void_p(dq[i % a.query_batches].data_ptr()), C.c_void_p(doff.data_ptr()),
-                off.ctypes.data_as(C.c_void_p), a.batch, 128, C.byref(cp), None, -1, C.c_void_p(o_ids.data_ptr()),
-                C.c_void_p(o_sc.data_ptr()), C.c_void_p(o_cnt.data_ptr()), C.c_void_p(stream.cuda_stream)))
-            return o_ids, o_sc, o_cnt
+                off.ctypes.data_as(C.c_void_p), a.batch, 128, C.byref(cp), None, -1, C.c_void_p(o_ids[s].data_ptr()),
+                C.c_void_p(o_sc[s].data_ptr()), C.c_void_p(o_cnt[s].data_ptr()), C.c_void_p(streams[s].cuda_stream)))
+            return o_ids[s], o_sc[s], o_cnt[s]
 
     def barrier():
         if use_dist:
@@ -231,6 +238,7 @@ def main():
         "dtype": {0: "f32", 1: "f32 (bf16 MFMA on the residual term of MaxSim)",
                   2: "f32 (split-bf16 hi/lo MFMA on the residual term of MaxSim, f32-class accuracy)",
                   3: "f32 + bf16 MaxSim"}[a.precision], "data": "synthetic",
+        "streams": nstr,
         "config": {"workload": f"{a.docs_per_gpu * world} docs x {a.doc_len} tok x d128 (nbits=4), 2^{int(np.log2(a.centroids))} centroids, "
                                f"nprobe={a.nprobe}, batch={a.batch}x{a.query_tokens} tok, n_full_scores={a.n_full_scores}, "
                                f"t_cs={thr}, top_k={a.top_k}; {a.docs_per_gpu} docs per GPU shard",

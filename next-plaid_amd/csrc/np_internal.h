@@ -93,6 +93,7 @@ struct Context {
   hipEvent_t ev[10] = {};
   Workspace* ws = nullptr;
   bool busy = false;
+  uint64_t last_use = 0;   // acquisition stamp: idle contexts are handed out least-recently-used first
 };
 
 struct DeviceIndex {
@@ -121,6 +122,7 @@ struct DeviceIndex {
   mutable std::mutex mu;
   mutable std::condition_variable cv;
   mutable std::vector<Context*> contexts;
+  mutable uint64_t use_clock = 0;
 };
 
 // np_index.hip

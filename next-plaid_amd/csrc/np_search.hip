@@ -63,12 +63,18 @@ void destroy_context(Context* c) {
 static int acquire_context(const DeviceIndex* ix, Context** out) {
   std::unique_lock<std::mutex> lk(ix->mu);
   for (;;) {
+    // Prefer growing the pool, then the least recently used idle context: back-to-back device-side calls
+    // on different streams then land on different workspaces and their kernels can overlap on the GPU
+    // (a context's workspace is guarded by its `done` event, so reuse is always safe, just serialising).
+    Context* best = nullptr;
     for (Context* c : ix->contexts)
-      if (!c->busy) {
-        c->busy = true;
-        *out = c;
-        return NP_OK;
-      }
+      if (!c->busy && (!best || c->last_use < best->last_use)) best = c;
+    if (best && (int)ix->contexts.size() >= ix->opts.n_contexts) {
+      best->busy = true;
+      best->last_use = ++ix->use_clock;
+      *out = best;
+      return NP_OK;
+    }
     if ((int)ix->contexts.size() < ix->opts.n_contexts) {
       Context* c = new Context();
       c->ws = new Workspace();
@@ -82,6 +88,7 @@ static int acquire_context(const DeviceIndex* ix, Context** out) {
         return NP_ERR_DEVICE_UNAVAILABLE;
       }
       c->busy = true;
+      c->last_use = ++ix->use_clock;
       ix->contexts.push_back(c);
       *out = c;
       return NP_OK;
