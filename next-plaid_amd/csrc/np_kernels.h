@@ -78,91 +78,91 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
 // D[c][q]: lane holds q = lane&31 and centroid rows mfma_row(r, lane>>5).
 // The k loop feeds k = 2s + (lane>>5) in ascending s, so each output is the k-ordered FMA chain.
 // ---------------------------------------------------------------------------------------------
-template <int DIM>
+template <int DIM, int CPW>   // CPW = 32-centroid A fragments per wave
 __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
                                                       const float* __restrict__ Qt, int B, int LQP,
                                                       float* __restrict__ QCT, uint32_t* __restrict__ gmax) {
-  // The block's 4 waves walk the same sequence of 32-token query tiles; each tile ([DIM][32] f32,
-  // k-major) is staged once through LDS (double buffered, one barrier per tile) and read back as
-  // conflict-free ds_read_b32 B operands, so the MFMA stream never waits on an L2 round trip.
-  constexpr int NV = DIM / 32;  // float4 per thread per tile
+  // The block's 4 waves walk the same sequence of 32-token query tiles ([DIM][32] f32, k-major).  Tile t+1 is
+  // copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers) while tile t feeds
+  // the MFMAs as conflict-free ds_read B operands; tile t-1's epilogue (QCT stores, group maxima) is issued
+  // at the top of iteration t, so by the barrier that closes the iteration neither the DMA nor the stores
+  // are still outstanding and s_waitcnt vmcnt(0) costs nothing.
+  constexpr int NV = DIM / 32;  // 1-KiB DMA pieces per wave per tile
   __shared__ float sQ[2][DIM * 32];
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, kk = lane >> 5;
-  const int64_t c0 = ((int64_t)blockIdx.x * 4 + (tid >> 6)) * 64;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * CPW);
   const bool active = c0 < KP;
-  float a0[DIM / 2], a1[DIM / 2];
-  {
-    const int64_t r0 = c0 + li, r1 = c0 + 32 + li;
+  float a[CPW][DIM / 2];
+#pragma unroll
+  for (int f = 0; f < CPW; ++f) {
+    const int64_t r0 = c0 + 32 * f + li;
 #pragma unroll
     for (int m = 0; m < DIM / 4; ++m) {
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r0 < K) v0 = *reinterpret_cast<const float4*>(C + r0 * DIM + 4 * m);
-      if (r1 < K) v1 = *reinterpret_cast<const float4*>(C + r1 * DIM + 4 * m);
-      a0[2 * m] = kk ? v0.y : v0.x;
-      a0[2 * m + 1] = kk ? v0.w : v0.z;
-      a1[2 * m] = kk ? v1.y : v1.x;
-      a1[2 * m + 1] = kk ? v1.w : v1.z;
+      a[f][2 * m] = kk ? v0.y : v0.x;
+      a[f][2 * m + 1] = kk ? v0.w : v0.z;
     }
   }
   const int nqt = LQP >> 5;
   const int ntiles = B * nqt;
   const int64_t G = KP >> 5;
-  float4 stage[NV];
-  auto load_tile = [&](int tile) {
+  auto dma_tile = [&](int tile, int buf) {
     const int b = tile / nqt, qt = tile - b * nqt;
     const float* src = Qt + (int64_t)b * DIM * LQP + qt * 32;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int i4 = j * 256 + tid;            // float4 index inside the [DIM][32] tile
-      stage[j] = *reinterpret_cast<const float4*>(src + (int64_t)(i4 >> 3) * LQP + (i4 & 7) * 4);
+      const int i4 = j * 256 + tid;   // float4 index inside the tile; the wave's 64 lanes fill 1 KiB of LDS linearly
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + (int64_t)(i4 >> 3) * LQP + (i4 & 7) * 4),
+          (__attribute__((address_space(3))) void*)(&sQ[buf][(j * 256 + wave * 64) * 4]), 16, 0, 0);
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) *reinterpret_cast<float4*>(&sQ[buf][(j * 256 + tid) * 4]) = stage[j];
-  };
-  if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
+  auto epilogue = [&](const f32x16 (&acc)[CPW], int tile) {
     const int b = tile / nqt, qt = tile - b * nqt;
-    if (tile + 1 < ntiles) load_tile(tile + 1);   // in flight under this tile's MFMAs
-    if (active) {
-      const float* qb = &sQ[tile & 1][kk * 32 + li];   // [2s+kk][q]
-      f32x16 acc0, acc1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < DIM / 2; ++s) {  // fully unrolled: a0/a1 must stay in registers
-        const float bq = qb[s * 64];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bq, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bq, acc1, 0, 0, 0);
-      }
-      float* out = QCT + ((int64_t)b * KP + c0) * LQP + qt * 32 + li;
-      uint32_t k0 = 0, k1 = 0;
+    for (int f = 0; f < CPW; ++f) {
+      float* out = QCT + ((int64_t)b * KP + c0 + 32 * f) * LQP + qt * 32 + li;
+      uint32_t k0 = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mfma_row(r, kk);
-        out[(int64_t)row * LQP] = acc0[r];
-        out[(int64_t)(row + 32) * LQP] = acc1[r];
-        const uint32_t e0 = (c0 + row < K) ? okey(acc0[r]) : 0u;
-        const uint32_t e1 = (c0 + 32 + row < K) ? okey(acc1[r]) : 0u;
-        k0 = max(k0, e0);
-        k1 = max(k1, e1);
+        out[(int64_t)row * LQP] = acc[f][r];
+        k0 = max(k0, (c0 + 32 * f + row < K) ? okey(acc[f][r]) : 0u);
       }
       k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
-      k1 = max(k1, (uint32_t)__shfl_xor((int)k1, 32));
-      if (kk == 0) {
-        uint32_t* g = gmax + ((int64_t)b * G + (c0 >> 5)) * LQP + qt * 32 + li;
-        g[0] = k0;
-        g[LQP] = k1;
-      }
+      if (kk == 0) gmax[((int64_t)b * G + ((c0 >> 5) + f)) * LQP + qt * 32 + li] = k0;
     }
-    if (tile + 1 < ntiles) store_tile((tile + 1) & 1);
+  };
+  if (ntiles > 0) dma_tile(0, 0);
+  __syncthreads();
+  f32x16 prev[CPW];
+#pragma unroll
+  for (int f = 0; f < CPW; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prev[f][r] = 0.f;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) dma_tile(tile + 1, (tile + 1) & 1);
+    if (active) {
+      if (tile > 0) epilogue(prev, tile - 1);
+      const float* qb = &sQ[tile & 1][kk * 32 + li];   // [2s+kk][q]
+      f32x16 acc[CPW];
+#pragma unroll
+      for (int f = 0; f < CPW; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < DIM / 2; ++s) {  // fully unrolled: the A fragments must stay in registers
+        const float bq = qb[s * 64];
+#pragma unroll
+        for (int f = 0; f < CPW; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[f][s], bq, acc[f], 0, 0, 0);
+      }
+#pragma unroll
+      for (int f = 0; f < CPW; ++f) prev[f] = acc[f];
+    }
     __syncthreads();
   }
+  if (active && ntiles > 0) epilogue(prev, ntiles - 1);
 }
 
 // ---------------------------------------------------------------------------------------------

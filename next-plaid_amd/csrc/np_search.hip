@@ -174,8 +174,16 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP) {
 template <int DIM>
 static void launch_gemm(hipStream_t st, const DeviceIndex* ix, const float* Qt, int B, int LQP, float* QCT,
                         uint32_t* gmax) {
-  const unsigned blocks = (unsigned)((ix->KP / 64 + 3) / 4);
-  qc_gemm_kernel<DIM><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax);
+  // one 32-centroid fragment per wave: 128 centroids per block, ~2 blocks per CU co-resident, so one wave's
+  // epilogue (stores, key maxima) hides under another wave's MFMAs.  KP is a multiple of 64.
+  static const int cpw = getenv("NP_GEMM_CPW") ? atoi(getenv("NP_GEMM_CPW")) : 1;
+  if (cpw == 2) {
+    const unsigned blocks = (unsigned)((ix->KP / 64 + 3) / 4);
+    qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax);
+  } else {
+    const unsigned blocks = (unsigned)((ix->KP / 32 + 3) / 4);
+    qc_gemm_kernel<DIM, 1><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax);
+  }
 }
 
 template <int DIM, int NBITS, int NQT>
