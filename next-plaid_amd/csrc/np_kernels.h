@@ -1543,6 +1543,224 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
   }
 }
 
+template <int DIM, int NBITS, int NQT, int SPLIT>
+__global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
+  constexpr int NS = DIM / 16;            // MFMA k-steps
+  constexpr int PD = DIM * NBITS / 8;     // bytes per token
+  constexpr int PH = PD / 2;              // bytes per lane: lane (tok, kk) owns dims [kk*DIM/2, +DIM/2)
+  constexpr int NW = PH / 4;              // residual dwords per lane
+  constexpr int WPB = (NBITS == 4) ? 1 : 2;  // u32 words of packed bf16 per residual byte (2 or 4 values)
+  static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0, "unsupported DIM/NBITS");
+  // byte -> {hi words, lo words}: one LDS read per residual byte returns both halves of the split
+  __shared__ uint32_t lut[256 * WPB * 2];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  {
+    constexpr int PER = 8 / NBITS;
+    constexpr uint32_t MASK = (1u << NBITS) - 1u;
+    uint16_t hh[4] = {0, 0, 0, 0}, ll[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {   // first dim of the byte = highest segment -> low half-word
+      const float w = p.wlut[((uint32_t)tid >> (8 - NBITS * (e + 1))) & MASK];
+      const __bf16 h = (__bf16)w;
+      const __bf16 l = (__bf16)(w - (float)h);
+      hh[e] = __builtin_bit_cast(uint16_t, h);
+      ll[e] = __builtin_bit_cast(uint16_t, l);
+    }
+#pragma unroll
+    for (int w2 = 0; w2 < WPB; ++w2) {
+      lut[(tid * WPB + w2) * 2 + 0] = (uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16);
+      lut[(tid * WPB + w2) * 2 + 1] = (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16);
+    }
+  }
+  __syncthreads();
+  const uint2* lut2 = reinterpret_cast<const uint2*>(lut);
+  const int LQP = p.LQP;
+  const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
+  const int Lq = p.qoff[b + 1] - p.qoff[b];
+  const int nqt = (Lq + 31) >> 5;
+  const int nsel = p.nsel[b];
+  const uint64_t cut = p.cut ? p.cut[b] : 0ull;
+  // slot (s, kk, e) of the MFMA k dimension <-> dim kk*DIM/2 + 8s + e, for A (tokens) and B (query) alike
+  const __bf16* Qb = p.Qb + (int64_t)b * LQP * DIM + kk * (DIM / 2);
+  const __bf16* Ql = p.Qb_lo + (int64_t)b * LQP * DIM + kk * (DIM / 2);
+  const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP);   // row base; columns added per load
+  const uint32_t row_bytes = (uint32_t)LQP * 4u;
+  bf16x8 bh0[NS], bl0[SPLIT == 3 ? NS : 1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    bh0[s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)li * DIM + 8 * s);
+    if (SPLIT == 3) bl0[s] = *reinterpret_cast<const bf16x8*>(Ql + (int64_t)li * DIM + 8 * s);
+  }
+  unsigned long long toks = 0, ndocs = 0;
+  for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
+    const int j = (blockIdx.x * 4 + wave) * NP_EXACT_DPW + dd;
+    if (j >= nsel) break;
+    const int64_t oj = (int64_t)b * p.n_sel + j;
+    if (p.sel_keys[oj] < cut) {
+      if (lane == 0) p.exact[oj] = 0.f;
+      continue;
+    }
+    const uint32_t doc = p.sel_doc[oj];
+    const int64_t off = p.doc_off[doc];
+    const int len = (int)(p.doc_off[doc + 1] - off);
+    toks += (unsigned long long)len;
+    ++ndocs;
+    // TRANSPOSED product S^T = Q . D^T: MFMA rows = query tokens, columns = document tokens, so lane
+    // (tok = li, kk) owns COLUMN tok: its accumulator rows are q = mfma_row(r, kk), the C-in values
+    // QC[code_tok][q] are four float4 pieces of the lane's OWN table row, 1/n_tok is the lane's own scalar,
+    // and the max over tokens is an element-wise running max (cross-lane only once per document).
+    float m[NQT][16];
+#pragma unroll
+    for (int x = 0; x < NQT; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m[x][r] = NP_NEG_INF;
+    // software pipeline: the NEXT tile's code / 1/n / residual words are in flight during this tile
+    uint32_t code_n = 0, rw_n[NW];
+    float rn_n = 0.f;
+    auto fetch = [&](int t0) {
+      const int tt = t0 + li;
+      const bool valid = tt < len;
+      const int64_t tok = off + (valid ? tt : len - 1);
+      code_n = p.codes[tok];
+      rn_n = valid ? p.inv_norm[tok] : __builtin_nanf("");   // rows past the end become NaN and drop out of fmaxf
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(p.residuals + tok * PD + kk * PH);
+      if constexpr (NW % 4 == 0) {
+#pragma unroll
+        for (int w4 = 0; w4 < NW / 4; ++w4) {
+          const uint4 v = reinterpret_cast<const uint4*>(rp)[w4];
+          rw_n[4 * w4] = v.x; rw_n[4 * w4 + 1] = v.y; rw_n[4 * w4 + 2] = v.z; rw_n[4 * w4 + 3] = v.w;
+        }
+      } else if constexpr (NW % 2 == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < NW / 2; ++w2) {
+          const uint2 v = reinterpret_cast<const uint2*>(rp)[w2];
+          rw_n[2 * w2] = v.x; rw_n[2 * w2 + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int w1 = 0; w1 < NW; ++w1) rw_n[w1] = rp[w1];
+      }
+    };
+    if (len > 0) fetch(0);
+    for (int t0 = 0; t0 < len; t0 += 32) {
+      const uint32_t code = code_n;
+      const float rn = rn_n;
+      uint32_t rw[NW];
+#pragma unroll
+      for (int w1 = 0; w1 < NW; ++w1) rw[w1] = rw_n[w1];
+      if (t0 + 32 < len) fetch(t0 + 32);
+      f32x16 acc0;   // C-in = Q.C[code]: rows q = 8g + 4kk + (0..3) are one float4 of this token's QCT row
+      {
+        const char* qrow = QCb + code * row_bytes;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = *reinterpret_cast<const float4*>(qrow + (8 * g + 4 * kk) * 4);
+          acc0[4 * g] = v.x; acc0[4 * g + 1] = v.y; acc0[4 * g + 2] = v.z; acc0[4 * g + 3] = v.w;
+        }
+      }
+      // residual bytes -> bf16 A fragments (8 dims = 8*NBITS/8 bytes per k-step)
+      bf16x8 ah[NS], al[SPLIT == 3 ? NS : 1];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        uint32_t wh[4], wl[4];
+        if constexpr (NBITS == 4) {
+          const uint32_t word = rw[s];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint2 e = lut2[(word >> (8 * i)) & 0xFFu];
+            wh[i] = e.x;
+            wl[i] = e.y;
+          }
+        } else {
+          const uint32_t word = rw[s >> 1] >> (16 * (s & 1));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const uint32_t byte = (word >> (8 * i)) & 0xFFu;
+            const uint2 e0 = lut2[byte * 2], e1 = lut2[byte * 2 + 1];
+            wh[2 * i] = e0.x; wl[2 * i] = e0.y;
+            wh[2 * i + 1] = e1.x; wl[2 * i + 1] = e1.y;
+          }
+        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 vh = {wh[0], wh[1], wh[2], wh[3]};
+        ah[s] = __builtin_bit_cast(bf16x8, vh);
+        if constexpr (SPLIT == 3) {
+          u32x4 vl = {wl[0], wl[1], wl[2], wl[3]};
+          al[s] = __builtin_bit_cast(bf16x8, vl);
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+        if (qt < nqt) {
+          f32x16 acc;
+          if (qt == 0) {
+            acc = acc0;
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 v = *reinterpret_cast<const float4*>(QCb + (code * row_bytes + qt * 128 + (8 * g + 4 * kk) * 4));
+              acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            bf16x8 bh, bl;
+            if (qt == 0) {
+              bh = bh0[s];
+              if constexpr (SPLIT == 3) bl = bl0[s];
+            } else {
+              bh = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)(qt * 32 + li) * DIM + 8 * s);
+              if constexpr (SPLIT == 3) bl = *reinterpret_cast<const bf16x8*>(Ql + (int64_t)(qt * 32 + li) * DIM + 8 * s);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[s], acc, 0, 0, 0);   // rows = q, cols = tokens
+            if constexpr (SPLIT == 3) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[s], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[s], acc, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float x = acc[r] * rn;
+            // maxsim.rs:284-291 ignores non-finite entries: x + (x - x) is x when finite and NaN for
+            // +-inf / NaN (rn is NaN for tokens past the end), and fmaxf never returns a NaN operand
+            m[qt][r] = fmaxf(m[qt][r], x + (x - x));
+          }
+        }
+      }
+    }
+    float total = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+      if (qt < nqt) {
+        // max over the document's tokens: across the 32 lanes of each half, once per document
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = m[qt][r];
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+          m[qt][r] = v;
+        }
+        // q-ordered sum (maxsim.rs:284-291): q = 8g + 4kk + e lives in register 4g + e of half kk
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int q = qt * 32 + 8 * g + 4 * hk + e;
+              const float x = readlane_f(m[qt][4 * g + e], hk * 32);
+              if (q < Lq && x > NP_NEG_INF) total += x;
+            }
+      }
+    }
+    if (lane == 0) p.exact[oj] = total;
+  }
+  if (lane == 0 && ndocs) {
+    atomicAdd(&p.ctr->n_exact_docs, ndocs);
+    atomicAdd(&p.ctr->n_exact_tokens, toks);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // S7  stable top-k by (exact desc [finite first], approx rank asc)   (search.rs:496-515)
 // ---------------------------------------------------------------------------------------------

@@ -196,10 +196,17 @@ static int launch_exact(hipStream_t st, const ExactP& p, int B, int precision) {
       NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_f32_kernel<DIM, NBITS, NQT>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     exact_f32_kernel<DIM, NBITS, NQT><<<dim3(gx, B), 256, lds, st>>>(p);
-  } else if (precision == 1) {
-    exact_qc_kernel<DIM, NBITS, NQT, 1><<<dim3(gx, B), 256, 0, st>>>(p);
-  } else if (precision == 2) {
-    exact_qc_kernel<DIM, NBITS, NQT, 3><<<dim3(gx, B), 256, 0, st>>>(p);
+  } else if (precision == 1 || precision == 2) {
+    // Lq <= 64: transposed form (4 float4 QC loads per tile, no per-row shuffles); longer queries keep the
+    // row-max form, whose running maxima need one register per query tile instead of sixteen
+    static const bool rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
+    if (NQT <= 2 && !rowmax) {
+      if (precision == 1) exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<dim3(gx, B), 256, 0, st>>>(p);
+      else exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<dim3(gx, B), 256, 0, st>>>(p);
+    } else {
+      if (precision == 1) exact_qc_kernel<DIM, NBITS, NQT, 1><<<dim3(gx, B), 256, 0, st>>>(p);
+      else exact_qc_kernel<DIM, NBITS, NQT, 3><<<dim3(gx, B), 256, 0, st>>>(p);
+    }
   } else {
     exact_bf16_kernel<DIM, NBITS, NQT><<<dim3(gx, B), 256, 0, st>>>(p);
   }
