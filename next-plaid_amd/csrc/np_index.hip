@@ -97,6 +97,7 @@ void destroy_device_index(DeviceIndex* ix) {
   (void)hipFree(ix->d_codes);
   (void)hipFree(ix->d_ucodes);
   (void)hipFree(ix->d_ulen);
+  (void)hipFree(ix->d_useg);
   (void)hipFree(ix->d_inv_norm);
   (void)hipFree(ix->d_residuals);
   (void)hipFree(ix->d_doc_offsets);
@@ -235,14 +236,55 @@ static int build_inv_norm(DeviceIndex* ix) {
   return NP_OK;
 }
 
+// ---- derived: where each document's sorted distinct-code list crosses the eighths of the centroid range ----
+// seg[d] = 8 x u16, seg[x] = number of distinct codes of d that are < (x+1)*ceil(K/8).  The sliced S4 kernel walks
+// one eighth (or pair / quad of eighths) of every candidate at a time so that the slice of the query's score
+// table it touches stays resident in one XCD's L2.
+__global__ void __launch_bounds__(256) useg_kernel(int64_t n_docs, const int64_t* __restrict__ doc_off,
+                                                   const uint32_t* __restrict__ ucodes, const int32_t* __restrict__ ulen,
+                                                   uint32_t slice_w, uint4* __restrict__ useg, int* __restrict__ bad) {
+  const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (d >= n_docs) return;
+  const int64_t off = doc_off[d];
+  const int n = ulen[d];
+  if (doc_off[d + 1] - off > NP_UNIQ_MAX || n > 65535) {   // list not sorted / counts do not fit
+    *bad = 1;
+    useg[d] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  uint32_t e[8];
+  int pos = 0;
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    const uint64_t hi = (uint64_t)(x + 1) * slice_w;
+    while (pos < n && (uint64_t)ucodes[off + pos] < hi) ++pos;
+    e[x] = (uint32_t)(x == 7 ? n : pos);
+  }
+  useg[d] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
 static int build_unique_codes(DeviceIndex* ix) {
   NP_TRY(dev_alloc(&ix->d_ucodes, (size_t)ix->T, &ix->device_bytes));
   NP_TRY(dev_alloc(&ix->d_ulen, (size_t)ix->n_docs, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_useg, (size_t)ix->n_docs, &ix->device_bytes));
   for (int64_t d0 = 0; d0 < ix->n_docs; d0 += (int64_t)1 << 30) {
     const int64_t n = std::min<int64_t>((int64_t)1 << 30, ix->n_docs - d0);
     unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->d_codes, ix->d_ucodes, ix->d_ulen + d0);
   }
   NP_HIP(hipGetLastError());
+  ix->sliced_ok = false;
+  if (ix->n_docs > 0) {
+    int* d_bad = nullptr;
+    NP_HIP(hipMalloc(&d_bad, sizeof(int)));
+    NP_HIP(hipMemset(d_bad, 0, sizeof(int)));
+    const uint32_t slice_w = (uint32_t)((ix->K + 7) / 8);
+    useg_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(ix->n_docs, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
+                                                              slice_w, ix->d_useg, d_bad);
+    int bad = 1;
+    NP_HIP(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(d_bad);
+    ix->sliced_ok = (bad == 0);
+  }
   NP_HIP(hipDeviceSynchronize());
   return NP_OK;
 }

@@ -110,6 +110,8 @@ struct DeviceIndex {
   uint32_t* d_codes = nullptr;
   uint32_t* d_ucodes = nullptr;   // [T] per-document sorted distinct codes at the document's offset (derived)
   int32_t* d_ulen = nullptr;      // [n_docs] number of distinct codes per document (derived)
+  uint4* d_useg = nullptr;        // [n_docs] 8 x u16: distinct codes below each eighth of the centroid range (derived)
+  bool sliced_ok = false;         // every document's distinct-code list is sorted and < 65536 long
   float* d_inv_norm = nullptr;    // [T] 1 / max(||centroid[code] + residual||, 1e-12) per token (derived)
   uint8_t* d_residuals = nullptr;
   int64_t* d_doc_offsets = nullptr;

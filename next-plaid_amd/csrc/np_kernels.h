@@ -946,6 +946,184 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
 }
 
 // ---------------------------------------------------------------------------------------------
+// S4, L2-resident variant (same value, bit for bit, as approx_kernel).
+// Measured on MI355X (tools/probes/gather_probe.hip): random 128-byte row gathers run at ~250 G rows/s when the
+// table slice sits in the XCD's 4 MiB L2 and at ~57 G rows/s when they miss it, whatever the occupancy or the row
+// size: the miss path is request-rate bound.  One query's table is 8.4 MB and every XCD touching it refills it,
+// so approx_kernel (all XCDs on one query) runs at the miss rate.  Here ONE XCD owns a query (workgroup w lands
+// on XCD w % 8; query b is walked by the workgroups with w % 8 == b % 8) and walks it in P phases: in phase p
+// every wave of the XCD gathers only the codes inside the p-th 1/P of the centroid range (an 8.4/P MB slice of
+// the table), for all of its documents, then moves on, so a row is fetched from the fabric once and reused
+// ~19x out of L2.  Each LPR-lane group owns up to NP_S4X_MAXD documents of the query (no cross-lane fold per
+// phase); their running maxima wait in LDS between phases (thread-private slots, nothing shared).  A group's
+// three code registers hold its segment of the document's sorted distinct-code list (useg gives the
+// boundaries); positions past the segment hold a duplicate of one of the SAME document's codes, which cannot
+// change a max, so no load is predicated and the position counter is wave-uniform.
+// SWZ: broadcast a code inside the 8-lane group with ds_swizzle (no address VALU) instead of ds_bpermute.
+// ---------------------------------------------------------------------------------------------
+#define NP_S4X_MAXD 6
+template <int LPR, bool SWZ>
+__global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
+                                                         const int32_t* __restrict__ qoff,
+                                                         const uint4* __restrict__ cand_meta, int64_t cand_stride,
+                                                         const int32_t* __restrict__ n_cand, int B,
+                                                         const uint32_t* __restrict__ codes, int64_t T,
+                                                         const uint4* __restrict__ useg, float* __restrict__ approx,
+                                                         int pshift, Counters* ctr) {
+  static_assert(!SWZ || LPR == 8, "the swizzle pattern broadcasts inside 8-lane groups");
+  constexpr int RPI = 64 / LPR;   // groups (documents) per wave
+  constexpr int GPB = 4 * RPI;    // groups per workgroup
+  constexpr int CAP = 3 * LPR;    // codes of one segment held in registers
+  __shared__ float4 s_state[NP_S4X_MAXD][256];
+  __shared__ int64_t s_off[NP_S4X_MAXD][GPB];
+  __shared__ uint16_t s_end[NP_S4X_MAXD][GPB][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jq = lane & (LPR - 1), grp = lane / LPR, g = wave * RPI + grp;
+  const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
+  const int64_t NG = (int64_t)NBX * GPB;
+  const int64_t gid = (int64_t)(blockIdx.x >> 3) * GPB + g;
+  const int P = 8 >> pshift;
+  const uint32_t row_bytes = (uint32_t)LQP * 4u;
+  const uint32_t col_bytes = (4 * jq < LQP) ? (uint32_t)jq * 16u : 0u;
+  const int lbase = grp * LPR;
+  unsigned long long toks = 0, ucnt = 0;
+
+  for (int b = x; b < B; b += 8) {
+    const int64_t n = n_cand[b];
+    const char* Tb = reinterpret_cast<const char*>(QCT + (int64_t)b * KP * LQP);
+    const int lq = qoff[b + 1] - qoff[b];
+    const uint4* metab = cand_meta + (int64_t)b * cand_stride;
+    for (int64_t tile0 = 0; tile0 < n; tile0 += NG * NP_S4X_MAXD) {
+      const int d = (int)min((int64_t)NP_S4X_MAXD, (n - tile0 + NG - 1) / NG);
+      __syncthreads();   // previous tile's LDS slots are free
+      for (int k = 0; k < d; ++k) {
+        const int64_t i = tile0 + (int64_t)k * NG + gid;
+        s_state[k][tid] = make_float4(NP_NEG_INF, NP_NEG_INF, NP_NEG_INF, NP_NEG_INF);
+        if (jq == 0) {
+          int64_t off = 0;
+          uint4 sg = make_uint4(0, 0, 0, 0);
+          if (i < n) {
+            const uint4 m = metab[i];
+            off = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
+            sg = useg[m.x];
+            toks += (unsigned long long)(m.w >> 8);
+            ucnt += (unsigned long long)m.y;
+          }
+          s_off[k][g] = off;
+          *reinterpret_cast<uint4*>(&s_end[k][g][0]) = sg;
+        }
+      }
+      __syncthreads();
+      // segment of (slot k, phase p): [s, e) inside the document's sorted distinct-code list
+      uint32_t cn0 = 0, cn1 = 0, cn2 = 0;
+      int ns = 0, ne = 0;
+      int64_t noff = 0;
+      auto seg_of = [&](int k, int p, int& so, int& eo, int64_t& oo) {
+        const int hi = ((p + 1) << pshift) - 1;
+        eo = (int)s_end[k][g][hi];
+        so = p ? (int)s_end[k][g][(p << pshift) - 1] : 0;
+        oo = s_off[k][g];
+      };
+      auto code_at = [&](int64_t o, int pos, int top) -> uint32_t {   // past the segment: any code of the same document
+        const int64_t a = o + (int64_t)max(min(pos, top), 0);
+        return codes[min(a, T - 1)];
+      };
+      seg_of(0, 0, ns, ne, noff);
+      cn0 = code_at(noff, ns + jq, ne - 1);
+      cn1 = code_at(noff, ns + LPR + jq, ne - 1);
+      cn2 = code_at(noff, ns + 2 * LPR + jq, ne - 1);
+      for (int p = 0; p < P; ++p) {
+        for (int k = 0; k < d; ++k) {
+          uint32_t c0 = cn0, c1 = cn1, c2 = cn2;
+          const int s = ns, e = ne;
+          const int64_t off = noff;
+          {
+            int kn = k + 1, pn = p;
+            if (kn == d) { kn = 0; pn = p + 1; }
+            if (pn < P) {
+              seg_of(kn, pn, ns, ne, noff);
+              cn0 = code_at(noff, ns + jq, ne - 1);
+              cn1 = code_at(noff, ns + LPR + jq, ne - 1);
+              cn2 = code_at(noff, ns + 2 * LPR + jq, ne - 1);
+            }
+          }
+          int lmax = e - s;
+#pragma unroll
+          for (int o = LPR; o < 64; o <<= 1) lmax = max(lmax, __shfl_xor(lmax, o));
+          lmax = __builtin_amdgcn_readfirstlane(lmax);
+          if (lmax == 0) continue;
+          float4 m = s_state[k][tid];
+          int tbase = 0;
+          for (int t0 = 0; t0 < lmax; t0 += 8) {
+            if (t0 - tbase >= CAP) {   // a segment longer than the registers hold
+              tbase = t0;
+              c0 = code_at(off, s + tbase + jq, e - 1);
+              c1 = code_at(off, s + tbase + LPR + jq, e - 1);
+              c2 = code_at(off, s + tbase + 2 * LPR + jq, e - 1);
+            }
+            const int tr0 = t0 - tbase, r = tr0 / LPR;
+            const uint32_t cr = r == 0 ? c0 : (r == 1 ? c1 : c2);
+            uint32_t cc[8];
+            if constexpr (SWZ) {
+#define NP_SWZ(J) cc[J] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)cr, 0x18 | ((J) << 5))
+              NP_SWZ(0); NP_SWZ(1); NP_SWZ(2); NP_SWZ(3); NP_SWZ(4); NP_SWZ(5); NP_SWZ(6); NP_SWZ(7);
+#undef NP_SWZ
+            } else {
+              const int jb = lbase + (tr0 & (LPR - 1));
+#pragma unroll
+              for (int u = 0; u < 8; ++u) cc[u] = (uint32_t)__shfl((int)cr, jb + u);
+            }
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(Tb + (cc[u] * row_bytes + col_bytes));
+            if (t0 + 4 < lmax) {
+#pragma unroll
+              for (int u = 4; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(Tb + (cc[u] * row_bytes + col_bytes));
+            } else {
+#pragma unroll
+              for (int u = 4; u < 8; ++u) v[u] = make_float4(NP_NEG_INF, NP_NEG_INF, NP_NEG_INF, NP_NEG_INF);
+            }
+            s4_fence<8>(v);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              m.x = fmaxf(m.x, v[u].x);
+              m.y = fmaxf(m.y, v[u].y);
+              m.z = fmaxf(m.z, v[u].z);
+              m.w = fmaxf(m.w, v[u].w);
+            }
+          }
+          s_state[k][tid] = m;
+        }
+      }
+      // q-ordered sums (search.rs:308-321), every lane of the group redundantly
+      for (int k = 0; k < d; ++k) {
+        const int64_t i = tile0 + (int64_t)k * NG + gid;
+        const float4 m = s_state[k][tid];
+        float score = 0.f;
+        for (int jj = 0; 4 * jj < lq; ++jj) {
+          const float a0 = __shfl(m.x, lbase + jj), a1 = __shfl(m.y, lbase + jj);
+          const float a2 = __shfl(m.z, lbase + jj), a3 = __shfl(m.w, lbase + jj);
+          if (a0 > NP_NEG_INF) score += a0;
+          if (4 * jj + 1 < lq && a1 > NP_NEG_INF) score += a1;
+          if (4 * jj + 2 < lq && a2 > NP_NEG_INF) score += a2;
+          if (4 * jj + 3 < lq && a3 > NP_NEG_INF) score += a3;
+        }
+        if (jq == 0 && i < n) approx[(int64_t)b * cand_stride + i] = s_end[k][g][7] ? score : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    toks += __shfl_xor(toks, o);
+    ucnt += __shfl_xor(ucnt, o);
+  }
+  if (lane == 0 && toks) {
+    atomicAdd(&ctr->n_cand_tokens, toks);
+    atomicAdd(&ctr->n_cand_codes, ucnt);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // block bitonic sort, descending, n = power of two, in LDS
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n, int tid, int nthreads) {

@@ -13,6 +13,11 @@
 
 namespace np {
 
+static inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       prefix, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset, subset_bits,
@@ -371,16 +376,34 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
 
   // ---- S4
   if (!cs->empty_subset && ix->n_docs > 0) {
-    const unsigned grid = 2048;
+    // NP_S4_MODE: 0 = all XCDs walk one query (approx_kernel), 1..4 = one XCD per query in 8/4/2/1 phases
+    const int s4_mode = env_int("NP_S4_MODE", 2), s4_minb = env_int("NP_S4_MINB", 8);
+    const unsigned s4_nbx = (unsigned)env_int("NP_S4_NBX", 128);
+    if (s4_mode > 0 && ix->sliced_ok && B >= s4_minb) {
+#define NP_LAUNCH_APPROX_X(LPR, SWZ)                                                                                   \
+  approx_xcd_kernel<LPR, SWZ><<<8 * s4_nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(), \
+                                                          cand_stride, w.n_cand.as<int32_t>(), B, ix->d_ucodes, ix->T,  \
+                                                          ix->d_useg, w.approx.as<float>(), s4_mode - 1,               \
+                                                          w.ctr.as<Counters>())
+      if (LQP <= 32) {
+        if (env_int("NP_S4_SWZ", 1)) NP_LAUNCH_APPROX_X(8, true);
+        else NP_LAUNCH_APPROX_X(8, false);
+      } else if (LQP <= 64) NP_LAUNCH_APPROX_X(16, false);
+      else if (LQP <= 128) NP_LAUNCH_APPROX_X(32, false);
+      else NP_LAUNCH_APPROX_X(64, false);
+#undef NP_LAUNCH_APPROX_X
+    } else {
+      const unsigned grid = 768;
 #define NP_LAUNCH_APPROX(LPR)                                                                                      \
   approx_kernel<LPR><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(), cand_stride, \
                                            w.prefix.as<int64_t>(), B, ix->d_ucodes, w.approx.as<float>(),           \
                                            w.ctr.as<Counters>())
-    if (LQP <= 32) NP_LAUNCH_APPROX(8);
-    else if (LQP <= 64) NP_LAUNCH_APPROX(16);
-    else if (LQP <= 128) NP_LAUNCH_APPROX(32);
-    else NP_LAUNCH_APPROX(64);
+      if (LQP <= 32) NP_LAUNCH_APPROX(8);
+      else if (LQP <= 64) NP_LAUNCH_APPROX(16);
+      else if (LQP <= 128) NP_LAUNCH_APPROX(32);
+      else NP_LAUNCH_APPROX(64);
 #undef NP_LAUNCH_APPROX
+    }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
 

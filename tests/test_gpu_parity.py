@@ -65,6 +65,29 @@ def test_stages_mid(mid):
             check_trace(hx, ox, qs[qi], p, what=f"thr={thr} q{qi}")
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_s4_kernel_variants_bit_exact(mid, mode, monkeypatch):
+    """S4 has two kernels (all XCDs on one query / one XCD per query in 8,4,2,1 phases over the centroid range);
+    the library reads NP_S4_MODE / NP_S4_MINB on every call.  Every variant must reproduce the oracle's
+    approximate scores bit for bit -- also for one-query calls (MINB=1), ragged query lengths and the
+    bpermute code broadcast."""
+    spec, a, ox, hx, qs, src = mid
+    monkeypatch.setenv("NP_S4_MODE", str(mode))
+    monkeypatch.setenv("NP_S4_MINB", "1")
+    p = P(n_full_scores=512, top_k=10, n_ivf_probe=8, centroid_score_threshold=0.4)
+    for qi in (0, 5):
+        check_trace(hx, ox, qs[qi], p, what=f"S4 mode {mode} q{qi}")
+    check_trace(hx, ox, qs[7][:13], p, what=f"S4 mode {mode} short query")
+    monkeypatch.setenv("NP_S4_SWZ", "0")
+    check_trace(hx, ox, qs[9], p, what=f"S4 mode {mode} bpermute")
+    # whole batch through the batched entry point (B >= 8 takes the per-XCD kernel when mode > 0)
+    monkeypatch.delenv("NP_S4_MINB")
+    res = hx.search_batch(qs[:16], p)
+    ref = ox.search_batch(qs[:16], to_oracle_params(p))
+    for i, (r, o) in enumerate(zip(res, ref)):
+        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32, f"S4 mode {mode} batch q{i}")
+
+
 def test_batch_mid_all_precisions(mid):
     # precision 0: exact-f32 MFMA; 2: QC-reuse + split-bf16 (f32-class); 1: QC-reuse + bf16; 3: plain bf16
     spec, a, ox, hx, qs, src = mid
