@@ -101,7 +101,7 @@ def main():
     nq = a.batch * a.query_batches
     qs, src = synth.make_queries(spec, nq, n_tokens=a.query_tokens, cen=cen)
     off = np.arange(a.batch + 1, dtype=np.int32) * a.query_tokens
-    nstr = max(1, a.streams) if not use_dist else 1
+    nstr = max(1, a.streams)
     streams = [torch.cuda.Stream(dev) for _ in range(nstr)]
     stream = streams[0]
     with torch.cuda.stream(stream):
@@ -115,11 +115,16 @@ def main():
     cp = prm._c()
 
     if use_dist:
+        # one searcher per stream, each with its own process group (= its own RCCL communicator), so the two
+        # small all-gathers of batch i overlap the kernels of batch i+1; every rank issues the same round-robin order
         from next_plaid_amd.dist import HipShardBackend, ShardedSearcher
-        ss = ShardedSearcher([HipShardBackend(ix, stream=stream)], use_dist=True)
+        groups = [dist.new_group(ranks=list(range(world))) for _ in range(nstr)]
+        sss = [ShardedSearcher([HipShardBackend(ix, stream=streams[s])], use_dist=True, group=groups[s])
+               for s in range(nstr)]
+        ss = sss[0]
 
         def step(i):
-            return ss.search_batch_device(dq[i % a.query_batches], doff, off, prm)
+            return sss[i % nstr].search_batch_device(dq[i % a.query_batches], doff, off, prm)
     else:
         def step(i):
             s = i % nstr
