@@ -234,6 +234,24 @@ int np_hip_merge_topk(const np_index* index, const int64_t* d_ids, const float* 
 int np_hip_decompress_documents(const np_index* index, const int64_t* doc_ids, int64_t n_docs,
                                 float* out_embeddings, int64_t out_capacity_rows, int64_t* out_lengths);
 
+/* N3: index-time encode of a flat batch of token embeddings against this index's codec -- replaces
+ * ResidualCodec::compress_into_codes + compress_and_residuals + quantize_residuals (codec.rs:297-411,
+ * index.rs:17-40,289-371 encode_index_chunk; the reference's CUDA path cuda.rs:185-237,353-653).
+ * out_codes[t] = nearest centroid by dot product (last index among equal maxima, non-finite scores below
+ * every finite one: Iterator::max_by(cmp_f32_for_max)); out_packed[t][dim*nbits/8] = residual buckets in the
+ * on-disk bit layout.  bucket_cutoffs holds 2^nbits - 1 floats (bucket_cutoffs.npy).  Host pointers. */
+int np_hip_encode_tokens(const np_index* index, const float* embeddings, int64_t n_tokens, int32_t dim,
+                         const float* bucket_cutoffs, int64_t* out_codes, uint8_t* out_packed);
+
+/* N4: /rerank MaxSim on caller-supplied embeddings (next-plaid-api/src/handlers/rerank.rs:57-94 compute_maxsim,
+ * :139-170 scoring + sort).  query [n_query_tokens][dim]; documents concatenated, document i owns rows
+ * doc_tok_offsets[i] .. doc_tok_offsets[i+1].  out_scores[n_docs] in input order; out_order (nullable) =
+ * document indices sorted by descending score, stable.  NP_ERR_INVALID_ARGUMENT with the handler's message for
+ * "No documents provided" and "Rerank score contains non-finite value".  Needs no index; host pointers. */
+int np_hip_rerank_maxsim(int32_t device, const float* query, int32_t n_query_tokens, int32_t dim,
+                         const float* doc_embeddings, const int64_t* doc_tok_offsets, int64_t n_docs,
+                         float* out_scores, int64_t* out_order);
+
 /* Stage-level debug access for parity tests: runs S1-S5 for ONE query and copies out the probed
  * cells (ascending), candidate doc ids (ascending, global), their approximate scores, and the
  * selected docs in approx-rank order with their exact scores.  Capacities are in elements;

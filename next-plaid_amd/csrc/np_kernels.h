@@ -2074,4 +2074,135 @@ __global__ void __launch_bounds__(256) decompress_kernel(const int64_t* __restri
   for (int j = lane; j < dim; j += 64) out[i * dim + j] = out[i * dim + j] / norm;
 }
 
+// ---------------------------------------------------------------------------------------------
+// N3  index-time encode: nearest centroid + residual quantisation (codec.rs:297-411,
+// index.rs:17-40,289-371; the reference's only CUDA code, cuda.rs:185-237).  Scores come from the same
+// exact-f32 MFMA GEMM as S1 (tokens fed as 32-token "queries"), so the argmax sees bit-identical values.
+// encode_argmax: one wave per token.  Iterator::max_by(cmp_f32_for_max) keeps the LAST of equal maxima;
+// okey() is cmp_f32_for_max as an integer (non-finite = 0 = below every finite value, all equal).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) encode_argmax_kernel(const float* __restrict__ QCT,
+                                                            const uint32_t* __restrict__ gmax, int64_t K, int64_t KP,
+                                                            int LQP, int64_t n_tokens, int64_t* __restrict__ codes) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_tokens) return;
+  const int64_t b = t / LQP;
+  const int q = (int)(t - b * LQP);
+  const int64_t G = KP >> 5;
+  const uint32_t* gm = gmax + b * G * LQP + q;
+  uint32_t mk = 0;
+  for (int64_t g = lane; g < G; g += 64) mk = max(mk, gm[g * LQP]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, o));
+  int64_t code = K - 1;   // every score non-finite: all equal, the last one wins
+  if (mk != 0u) {
+    int gl = -1;
+    for (int64_t g = lane; g < G; g += 64)
+      if (gm[g * LQP] == mk) gl = (int)g;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gl = max(gl, __shfl_xor(gl, o));
+    const int64_t c = (int64_t)gl * 32 + (lane & 31);
+    const bool hit = lane < 32 && c < K && okey(QCT[(b * KP + c) * LQP + q]) == mk;
+    const unsigned long long bal = __ballot(hit);
+    code = (int64_t)gl * 32 + (63 - __clzll(bal));
+  }
+  if (lane == 0) codes[t] = code;
+}
+
+// one thread per packed byte: residual = x - centroid[code] (f32), bucket = #cutoffs strictly below it,
+// bucket bits LSB-first into the byte MSB-first (codec.rs:356-411)
+__global__ void __launch_bounds__(256) encode_pack_kernel(const float* __restrict__ x, const float* __restrict__ C,
+                                                          const int64_t* __restrict__ codes,
+                                                          const float* __restrict__ cutoffs, int64_t n_tokens, int dim,
+                                                          int nbits, uint8_t* __restrict__ packed) {
+  const int pd = dim * nbits / 8, per = 8 / nbits, ncut = (1 << nbits) - 1;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_tokens * pd) return;
+  const int64_t t = i / pd;
+  const int jb = (int)(i - t * pd);
+  const float* xr = x + t * dim + jb * per;
+  const float* cr = C + codes[t] * dim + jb * per;
+  uint32_t byte = 0;
+  for (int e = 0; e < per; ++e) {
+    const float v = __fsub_rn(xr[e], cr[e]);
+    int bucket = 0;
+    for (int c = 0; c < ncut; ++c) bucket += (v > cutoffs[c]) ? 1 : 0;
+    for (int bb = 0; bb < nbits; ++bb) byte |= (uint32_t)((bucket >> bb) & 1) << (7 - (e * nbits + bb));
+  }
+  packed[i] = (uint8_t)byte;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N4  /rerank MaxSim on caller-supplied embeddings (next-plaid-api handlers/rerank.rs:57-94):
+// sim = sequential sum of q*d products (multiply, then add: no FMA), max over document tokens, sum over query
+// tokens in order; any non-finite sim or running total is the handler's BadRequest (flag).  One block per
+// document; 8 query rows at a time sit in LDS, a thread walks one document token against them.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rerank_kernel(const float* __restrict__ Q, int lq, int dim,
+                                                     const float* __restrict__ D, const int64_t* __restrict__ doc_off,
+                                                     float* __restrict__ scores, int* __restrict__ flags) {
+  // the handler multiplies, then adds.  hipcc contracts a*b+c into an FMA by default -- also through __fmul_rn /
+  // __fadd_rn, which are plain operators compiled with contraction allowed -- so it is switched off for this body
+#pragma clang fp contract(off)
+  extern __shared__ float sq[];   // [8][dim]
+  __shared__ float s_wmax[4][8];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t doc = blockIdx.x, t0 = doc_off[doc], t1 = doc_off[doc + 1];
+  if (tid == 0) s_bad = 0;
+  float total = 0.0f;
+  int bad0 = 0;
+  for (int q0 = 0; q0 < lq; q0 += 8) {
+    const int nq = min(8, lq - q0);
+    __syncthreads();
+    for (int i = tid; i < 8 * dim; i += 256) sq[i] = (i < nq * dim) ? Q[(int64_t)q0 * dim + i] : 0.0f;
+    __syncthreads();
+    float mx[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mx[r] = NP_NEG_INF;
+    int bad = 0;
+    for (int64_t t = t0 + tid; t < t1; t += 256) {
+      float sim[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sim[r] = 0.0f;
+      const float* dr = D + t * dim;
+      for (int k = 0; k < dim; ++k) {
+        const float dv = dr[k];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sim[r] = sim[r] + sq[r * dim + k] * dv;   // not contracted (pragma above)
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r < nq) {
+          if (!finitef(sim[r])) bad = 1;
+          if (sim[r] > mx[r]) mx[r] = sim[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o));
+      if (lane == 0) s_wmax[wave][r] = mx[r];
+    }
+    if (bad) atomicOr(&s_bad, 1);
+    __syncthreads();
+    if (tid == 0) {
+      for (int r = 0; r < nq; ++r) {
+        const float m = fmaxf(fmaxf(s_wmax[0][r], s_wmax[1][r]), fmaxf(s_wmax[2][r], s_wmax[3][r]));
+        if (m > NP_NEG_INF) {
+          total = total + m;
+          if (!finitef(total)) bad0 = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    scores[doc] = total;
+    flags[doc] = (bad0 || s_bad) ? 1 : 0;
+  }
+}
+
 }  // namespace np

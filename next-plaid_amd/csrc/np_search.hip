@@ -926,4 +926,166 @@ int np_hip_debug_trace(const np_index* ix, const float* query, int32_t n_tokens,
   return NP_OK;
 }
 
+// ---- N3: index-time encode (codec.rs:297-411; index.rs:289-371 encode_index_chunk) -----------------------------
+int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_tokens, int32_t dim,
+                         const float* bucket_cutoffs, int64_t* out_codes, uint8_t* out_packed) {
+  clear_error();
+  if (!ix || n_tokens < 0 || (n_tokens > 0 && (!embeddings || !out_codes || !out_packed)) || !bucket_cutoffs) {
+    set_error("encode_tokens: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (dim != ix->dim) {
+    set_error("Shape error: embedding dim %d does not match index dim %d", dim, ix->dim);
+    return NP_ERR_SHAPE;
+  }
+  if (!dim_supported(ix->dim, ix->nbits)) {
+    set_error("Shape error: the HIP path supports dim in {32,64,96,128} and nbits in {2,4}; index has dim=%d nbits=%d",
+              ix->dim, ix->nbits);
+    return NP_ERR_SHAPE;
+  }
+  if (ix->K <= 0) {
+    set_error("Codec error: the index has no centroids");
+    return NP_ERR_CODEC;
+  }
+  if (n_tokens == 0) return NP_OK;
+  DeviceGuard g(ix->device);
+  CallState cs;
+  NP_TRY(acquire_context(ix, &cs.ctx));
+  struct Rel {
+    const np_index* ix;
+    Context* c;
+    ~Rel() { release_context(ix, c); }
+  } rel{ix, cs.ctx};
+  Workspace& w = *cs.ctx->ws;
+  NP_TRY(begin_use(&cs, nullptr));
+  hipStream_t st = cs.stream;
+  const int LQP = 32;
+  const int64_t KP = ix->KP, G = KP >> 5;
+  int64_t S = ix->opts.workspace_bytes / std::max<int64_t>(per_query_bytes(ix, LQP), 1);
+  S = std::max<int64_t>(1, std::min<int64_t>(S, std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB)));
+  S = std::min<int64_t>(S, (n_tokens + LQP - 1) / LQP);
+  const int64_t TB = S * LQP;
+  const int pd = ix->pd, ncut = (1 << ix->nbits) - 1;
+  NP_TRY(w.q.reserve((size_t)TB * dim * 4));
+  NP_TRY(w.qoff.reserve((size_t)(S + 1) * 4));
+  NP_TRY(w.Qt.reserve((size_t)S * dim * LQP * 4));
+  NP_TRY(w.Qb.reserve((size_t)S * dim * LQP * 2));
+  NP_TRY(w.Qbl.reserve((size_t)S * dim * LQP * 2));
+  NP_TRY(w.QCT.reserve((size_t)S * KP * LQP * 4));
+  NP_TRY(w.gmax.reserve((size_t)S * G * LQP * 4));
+  NP_TRY(w.out_ids.reserve((size_t)TB * 8));
+  NP_TRY(w.cand.reserve((size_t)TB * pd));
+  NP_TRY(w.misc.reserve(64));
+  NP_HIP(hipMemcpyAsync(w.misc.p, bucket_cutoffs, (size_t)ncut * 4, hipMemcpyHostToDevice, st));
+  std::vector<int32_t> h_off((size_t)S + 1);
+  for (int64_t t0 = 0; t0 < n_tokens; t0 += TB) {
+    const int64_t nb = std::min<int64_t>(TB, n_tokens - t0);
+    const int Sb = (int)((nb + LQP - 1) / LQP);
+    for (int s = 0; s <= Sb; ++s) h_off[(size_t)s] = (int32_t)std::min<int64_t>((int64_t)s * LQP, nb);
+    NP_HIP(hipMemcpyAsync(w.q.p, embeddings + t0 * dim, (size_t)nb * dim * 4, hipMemcpyHostToDevice, st));
+    NP_HIP(hipMemcpyAsync(w.qoff.p, h_off.data(), (size_t)(Sb + 1) * 4, hipMemcpyHostToDevice, st));
+    prep_queries_kernel<<<Sb, 256, 0, st>>>(w.q.as<float>(), w.qoff.as<int32_t>(), dim, LQP, w.Qt.as<float>(),
+                                            w.Qb.as<__bf16>(), w.Qbl.as<__bf16>());
+    switch (ix->dim) {
+      case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), Sb, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+      case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), Sb, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+      case 96: launch_gemm<96>(st, ix, w.Qt.as<float>(), Sb, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+      default: launch_gemm<128>(st, ix, w.Qt.as<float>(), Sb, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+    }
+    encode_argmax_kernel<<<(unsigned)((nb + 3) / 4), 256, 0, st>>>(w.QCT.as<float>(), w.gmax.as<uint32_t>(), ix->K, KP,
+                                                                  LQP, nb, w.out_ids.as<int64_t>());
+    encode_pack_kernel<<<(unsigned)((nb * pd + 255) / 256), 256, 0, st>>>(w.q.as<float>(), ix->d_centroids,
+                                                                         w.out_ids.as<int64_t>(), w.misc.as<float>(), nb,
+                                                                         dim, ix->nbits, w.cand.as<uint8_t>());
+    NP_HIP(hipGetLastError());
+    NP_HIP(hipMemcpyAsync(out_codes + t0, w.out_ids.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+    NP_HIP(hipMemcpyAsync(out_packed + t0 * pd, w.cand.p, (size_t)nb * pd, hipMemcpyDeviceToHost, st));
+    NP_HIP(hipStreamSynchronize(st));   // h_off / the workspace are reused by the next slice
+  }
+  NP_TRY(end_use(&cs));
+  return NP_OK;
+}
+
+// ---- N4: /rerank MaxSim on caller-supplied embeddings (next-plaid-api handlers/rerank.rs:57-94,139-170) ---------
+int np_hip_rerank_maxsim(int32_t device, const float* query, int32_t n_query_tokens, int32_t dim,
+                         const float* doc_embeddings, const int64_t* doc_tok_offsets, int64_t n_docs, float* out_scores,
+                         int64_t* out_order) {
+  clear_error();
+  if (n_docs <= 0) {  // rerank.rs:113-115
+    set_error("No documents provided");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (!query || !doc_tok_offsets || !out_scores || n_query_tokens < 0 || dim <= 0) {
+    set_error("rerank_maxsim: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (dim > 1024) {
+    set_error("Shape error: rerank supports dim <= 1024, got %d", dim);
+    return NP_ERR_SHAPE;
+  }
+  for (int64_t i = 0; i < n_docs; ++i)
+    if (doc_tok_offsets[i + 1] < doc_tok_offsets[i] || doc_tok_offsets[0] != 0) {
+      set_error("rerank_maxsim: doc_tok_offsets must start at 0 and be non-decreasing");
+      return NP_ERR_INVALID_ARGUMENT;
+    }
+  const int64_t T = doc_tok_offsets[n_docs];
+  if (T > 0 && !doc_embeddings) {
+    set_error("rerank_maxsim: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    (void)hipGetLastError();
+    set_error("no usable gfx950 device %d", device);
+    return NP_ERR_DEVICE_UNAVAILABLE;
+  }
+  DeviceGuard g(device);
+  float *d_q = nullptr, *d_d = nullptr, *d_s = nullptr;
+  int64_t* d_off = nullptr;
+  int* d_f = nullptr;
+  struct Free {
+    float **a, **b, **c;
+    int64_t** d;
+    int** e;
+    ~Free() {
+      (void)hipFree(*a);
+      (void)hipFree(*b);
+      (void)hipFree(*c);
+      (void)hipFree(*d);
+      (void)hipFree(*e);
+    }
+  } fr{&d_q, &d_d, &d_s, &d_off, &d_f};
+  NP_HIP(hipMalloc(&d_q, std::max<size_t>((size_t)n_query_tokens * dim * 4, 4)));
+  NP_HIP(hipMalloc(&d_d, std::max<size_t>((size_t)T * dim * 4, 4)));
+  NP_HIP(hipMalloc(&d_s, (size_t)n_docs * 4));
+  NP_HIP(hipMalloc(&d_off, (size_t)(n_docs + 1) * 8));
+  NP_HIP(hipMalloc(&d_f, (size_t)n_docs * 4));
+  if (n_query_tokens > 0) NP_HIP(hipMemcpy(d_q, query, (size_t)n_query_tokens * dim * 4, hipMemcpyHostToDevice));
+  if (T > 0) NP_HIP(hipMemcpy(d_d, doc_embeddings, (size_t)T * dim * 4, hipMemcpyHostToDevice));
+  NP_HIP(hipMemcpy(d_off, doc_tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+  rerank_kernel<<<(unsigned)n_docs, 256, (size_t)8 * dim * 4>>>(d_q, n_query_tokens, dim, d_d, d_off, d_s, d_f);
+  NP_HIP(hipGetLastError());
+  std::vector<int> flags((size_t)n_docs);
+  NP_HIP(hipMemcpy(out_scores, d_s, (size_t)n_docs * 4, hipMemcpyDeviceToHost));
+  NP_HIP(hipMemcpy(flags.data(), d_f, (size_t)n_docs * 4, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n_docs; ++i)
+    if (flags[(size_t)i]) {  // rerank.rs:71-75,85-89
+      set_error("Rerank score contains non-finite value");
+      return NP_ERR_INVALID_ARGUMENT;
+    }
+  if (out_order) {  // rerank.rs:162-163: stable sort by score_desc_cmp (all scores are finite here: b.total_cmp(a))
+    auto key = [](float x) {
+      uint32_t b;
+      memcpy(&b, &x, 4);
+      return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    };
+    std::vector<int64_t> ord((size_t)n_docs);
+    for (int64_t i = 0; i < n_docs; ++i) ord[(size_t)i] = i;
+    std::stable_sort(ord.begin(), ord.end(),
+                     [&](int64_t a, int64_t b) { return key(out_scores[a]) > key(out_scores[b]); });
+    memcpy(out_order, ord.data(), (size_t)n_docs * 8);
+  }
+  return NP_OK;
+}
+
 }  // extern "C"

@@ -110,7 +110,7 @@ EXPORTS = [
     "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_close",
     "np_hip_index_info", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
     "np_hip_search_phase_b", "np_hip_search_end", "np_hip_n_sel", "np_hip_select_cut", "np_hip_merge_topk",
-    "np_hip_decompress_documents", "np_hip_debug_trace",
+    "np_hip_decompress_documents", "np_hip_encode_tokens", "np_hip_rerank_maxsim", "np_hip_debug_trace",
 ]
 
 _lib = None
@@ -154,6 +154,8 @@ def lib():
     L.np_hip_select_cut.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.np_hip_merge_topk.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.np_hip_decompress_documents.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.np_hip_encode_tokens.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.np_hip_rerank_maxsim.argtypes = [i32, vp, i32, i32, vp, vp, i64, vp, vp]
     L.np_hip_debug_trace.argtypes = [vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,
                                      vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, vp]
     _lib = L
@@ -164,6 +166,28 @@ def _check(rc: int):
     if rc:
         msg = lib().np_hip_last_error().decode("utf-8", "replace")
         raise _ERR.get(rc, NextPlaidError)(msg or f"np_status {rc}")
+
+
+def rerank_maxsim(query, documents, device: int = 0):
+    """/rerank (next-plaid-api handlers/rerank.rs:57-170): MaxSim of one query against caller-supplied document
+    embeddings.  Returns (order, scores): document indices by descending score (stable) and the scores in INPUT
+    order.  ValueError carries the handler's BadRequest messages."""
+    q = np.ascontiguousarray(query, np.float32)
+    docs = [np.ascontiguousarray(d, np.float32) for d in documents]
+    if q.ndim != 2:
+        raise ShapeError(f"Shape error: query has shape {q.shape}")
+    for d in docs:
+        if d.ndim != 2 or d.shape[1] != q.shape[1]:   # ApiError::DimensionMismatch (rerank.rs:141-146)
+            raise ShapeError(f"Shape error: expected dim {q.shape[1]}, got {d.shape}")
+    off = np.zeros(len(docs) + 1, np.int64)
+    if docs:
+        off[1:] = np.cumsum([d.shape[0] for d in docs])
+    flat = np.concatenate(docs, 0) if docs and off[-1] > 0 else np.zeros((1, max(q.shape[1], 1)), np.float32)
+    scores = np.zeros(max(len(docs), 1), np.float32)
+    order = np.zeros(max(len(docs), 1), np.int64)
+    _check(lib().np_hip_rerank_maxsim(int(device), _ptr(q), q.shape[0], q.shape[1], _ptr(flat), _ptr(off), len(docs),
+                                      _ptr(scores), _ptr(order)))
+    return order[: len(docs)], scores[: len(docs)]
 
 
 def device_count() -> int:
@@ -353,6 +377,22 @@ class MmapIndex:
         out = np.zeros((max(total, 1), self.embedding_dim()), np.float32)
         _check(lib().np_hip_decompress_documents(self._h, _ptr(ids), ids.size, _ptr(out), total, _ptr(lens)))
         return out[:total], lens
+
+    def encode_tokens(self, embeddings, bucket_cutoffs):
+        """Index-time encode of a flat [n, dim] batch against this index's codec (codec.rs:297-411,
+        index.rs:289-371): (codes i64 [n], packed residuals u8 [n, dim*nbits/8])."""
+        x = np.ascontiguousarray(embeddings, np.float32)
+        if x.ndim != 2 or x.shape[1] != self.embedding_dim():
+            raise ShapeError(f"Shape error: embeddings have shape {x.shape}, index dim is {self.embedding_dim()}")
+        nbits = int(self.info.nbits)
+        cut = np.ascontiguousarray(bucket_cutoffs, np.float32)
+        if cut.size != (1 << nbits) - 1:
+            raise CodecError(f"Codec error: bucket_cutoffs has {cut.size} entries, nbits={nbits} needs {(1 << nbits) - 1}")
+        n = x.shape[0]
+        codes = np.zeros(max(n, 1), np.int64)
+        packed = np.zeros((max(n, 1), x.shape[1] * nbits // 8), np.uint8)
+        _check(lib().np_hip_encode_tokens(self._h, _ptr(x), n, x.shape[1], _ptr(cut), _ptr(codes), _ptr(packed)))
+        return codes[:n], packed[:n]
 
     def debug_trace(self, query, params: SearchParameters, subset=None) -> dict:
         q = np.ascontiguousarray(query, np.float32)

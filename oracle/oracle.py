@@ -74,6 +74,9 @@ def lib():
         L.po_bucket_weight_indices_lookup.argtypes = [C.c_int, C.c_void_p]
         L.po_packbits.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.po_quantize_residuals.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.po_compress_into_codes.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.po_encode_tokens.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p]
         L.po_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.po_index_create.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32] + [C.c_void_p] * 7
         L.po_index_create.restype = C.c_void_p
@@ -193,6 +196,24 @@ def quantize_residuals(residuals, nbits, cutoffs):
     out = np.zeros((n, dim * nbits // 8), np.uint8)
     lib().po_quantize_residuals(_ptr(r), n, dim, nbits, _ptr(c), c.size, _ptr(out))
     return out
+
+
+def compress_into_codes(embeddings, centroids):
+    """codec.rs:297-345: nearest centroid by dot product, last index among equal maxima."""
+    x, c = _f32(embeddings), _f32(centroids)
+    codes = np.zeros(x.shape[0], np.int64)
+    lib().po_compress_into_codes(_ptr(x), x.shape[0], _ptr(c), c.shape[0], c.shape[1], _ptr(codes))
+    return codes
+
+
+def encode_tokens(embeddings, centroids, nbits, cutoffs):
+    """index.rs:289-371 encode_index_chunk for one flat batch of tokens: (codes i64 [n], packed u8 [n, pd])."""
+    x, c, cut = _f32(embeddings), _f32(centroids), _f32(cutoffs)
+    n, dim = x.shape
+    codes = np.zeros(n, np.int64)
+    packed = np.zeros((n, dim * nbits // 8), np.uint8)
+    lib().po_encode_tokens(_ptr(x), n, _ptr(c), c.shape[0], dim, nbits, _ptr(cut), cut.size, _ptr(codes), _ptr(packed))
+    return codes, packed
 
 
 def decompress(packed, codes, centroids, bucket_weights, nbits):

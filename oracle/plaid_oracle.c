@@ -183,6 +183,44 @@ PO_API void po_quantize_residuals(const float* residuals, int64_t n, int64_t dim
   }
 }
 
+/* codec.rs:22-30 cmp_f32_for_max as an integer key: finite values keep total_cmp order, every
+ * non-finite value sits below them and all non-finite values are equal. */
+static uint32_t po_key_for_max(float x) {
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  if ((b & 0x7F800000u) == 0x7F800000u) return 0u;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+/* codec.rs:297-345 compress_into_codes_cpu (N3 row): scores = batch.dot(centroids.t())
+ * (matrixmultiply: k-ordered fused chain, po_dot_fma), then per row
+ * enumerate().max_by(cmp_f32_for_max) -- Iterator::max_by keeps the LAST of equal maxima. */
+PO_API void po_compress_into_codes(const float* X, int64_t n, const float* C, int64_t K, int64_t d,
+                                   int64_t* codes) {
+#pragma omp parallel for schedule(static)
+  for (int64_t t = 0; t < n; ++t) {
+    int64_t best = 0;
+    uint32_t bk = 0;
+    for (int64_t c = 0; c < K; ++c) {
+      const uint32_t k = po_key_for_max(po_dot_fma(X + t * d, C + c * d, d));
+      if (c == 0 || k >= bk) { best = c; bk = k; }
+    }
+    codes[t] = best;
+  }
+}
+
+/* index.rs:17-40 compress_and_residuals_cpu + index.rs:352 quantize_residuals (encode_index_chunk):
+ * codes, residual = embedding - centroid[code] (f32), packed buckets. */
+PO_API void po_encode_tokens(const float* X, int64_t n, const float* C, int64_t K, int64_t d, int nbits,
+                             const float* cutoffs, int64_t n_cutoffs, int64_t* codes, uint8_t* packed) {
+  po_compress_into_codes(X, n, C, K, d, codes);
+  float* res = (float*)malloc((size_t)(n > 0 ? n : 1) * (size_t)d * sizeof(float));
+  for (int64_t t = 0; t < n; ++t)
+    for (int64_t j = 0; j < d; ++j) res[t * d + j] = X[t * d + j] - C[codes[t] * d + j];
+  po_quantize_residuals(res, n, d, nbits, cutoffs, n_cutoffs, packed);
+  free(res);
+}
+
 /* codec.rs:423-470 decompress: out[i,j] = centroid[codes[i]][j] + weights[bucket(i,j)];
  * then each row /= max(sqrt(row.row), 1e-12).  codes are i64 (as usize in the reference). */
 PO_API void po_decompress(const uint8_t* packed, const int64_t* codes, int64_t n, int64_t dim,

@@ -308,3 +308,65 @@ def test_batched_probe_semantics():
         tb = hx.debug_trace(q, pb, sub)
         ob = ox.search(q, to_oracle_params(pb), sub, trace=True)
         assert np.array_equal(tb["cells"], ob.trace.cells) and np.array_equal(tb["cand"], ob.trace.cand)
+
+
+# ---- index-time encode, N4: /rerank MaxSim -------------------------------------------------------
+@pytest.mark.parametrize("dim,nbits,K,n", [(128, 4, 1024, 3001), (64, 2, 300, 257)])
+def test_encode_tokens_matches_oracle(dim, nbits, K, n):
+    """codec.rs:297-411 / index.rs:289-371: nearest-centroid codes (last of equal maxima, non-finite below finite)
+    and packed residual buckets, bit for bit; more tokens than one workspace slice, ragged tail."""
+    spec, a = make_arrays(num_docs=400, num_centroids=K, dim=dim, nbits=nbits, doc_len_min=4, doc_len_max=12, seed=91)
+    a = dict(a)
+    cen = a["centroids"].copy()
+    cen[7] = cen[K - 5]                      # identical centroids: the later index must win
+    a["centroids"] = cen
+    hx = hip_index(a)
+    rng = np.random.default_rng(92)
+    z = rng.integers(0, K, n)
+    x = cen[z] + 0.2 * rng.standard_normal((n, dim)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    x[5] = 0.0                               # every score +0.0: all equal -> last centroid
+    x[6, 3] = np.nan                         # every score non-finite -> last centroid
+    x[n - 1] = cen[K - 5]                    # hits the duplicated pair exactly
+    cut, _ = synth.bucket_tables(spec)
+    codes, packed = hx.encode_tokens(x, cut)
+    rc, rp = O.encode_tokens(x, cen, nbits, cut)
+    bad = np.nonzero(codes != rc)[0]
+    assert bad.size == 0, f"codes differ at {bad[:8]}: hip {codes[bad[:8]]} oracle {rc[bad[:8]]}"
+    assert codes[5] == K - 1 and codes[6] == K - 1 and codes[n - 1] == K - 5
+    assert np.array_equal(packed, rp)
+    with pytest.raises(npa.ShapeError):
+        hx.encode_tokens(x[:, : dim - 1], cut)
+    c0, p0 = hx.encode_tokens(x[:0], cut)
+    assert c0.shape == (0,) and p0.shape[0] == 0
+
+
+def test_rerank_maxsim_matches_handler():
+    """next-plaid-api handlers/rerank.rs:57-170: scores bit-identical to the sequential multiply-then-add loop,
+    stable descending order, the integration test's 2.0 / 1.0 / 0.0 answers, and the two BadRequest cases."""
+    rng = np.random.default_rng(93)
+    for lq, dim, lens in ((32, 128, [300, 1, 37, 0, 513, 64]), (5, 100, [3, 9]), (2, 4, [2, 1, 1])):
+        q = rng.standard_normal((lq, dim)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        docs = []
+        for n in lens:
+            d = rng.standard_normal((n, dim)).astype(np.float32)
+            docs.append((d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)).astype(np.float32))
+        docs.append(docs[0].copy())          # equal scores: the stable sort keeps input order
+        order, scores = npa.rerank_maxsim(q, docs)
+        ref = np.array([O.rerank_maxsim(q, d) if d.shape[0] else 0.0 for d in docs], np.float32)
+        assert np.array_equal(scores.view(np.uint32), ref.view(np.uint32)), f"{scores} vs {ref}"
+        assert np.array_equal(order, np.argsort(-ref.astype(np.float64), kind="stable"))
+    # integration_tests.rs:2301-2376
+    q = np.array([[1, 0, 0, 0], [0, 1, 0, 0]], np.float32)
+    d_both = np.array([[1, 0, 0, 0], [0, 1, 0, 0]], np.float32)
+    d_one = np.array([[1, 0, 0, 0], [0, 0, 1, 0]], np.float32)
+    d_none = np.array([[0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+    order, scores = npa.rerank_maxsim(q, [d_none, d_both, d_one])
+    assert np.allclose(scores, [0.0, 2.0, 1.0], atol=1e-6) and order.tolist() == [1, 2, 0]
+    with pytest.raises(ValueError, match="non-finite"):
+        npa.rerank_maxsim(np.array([[np.nan, 0, 0, 0]], np.float32), [d_both])
+    with pytest.raises(ValueError, match="No documents"):
+        npa.rerank_maxsim(q, [])
+    with pytest.raises(npa.ShapeError):
+        npa.rerank_maxsim(q, [np.zeros((2, 5), np.float32)])

@@ -120,3 +120,53 @@ def test_unrolled_dot_matches_sum():
         from oracle.oracle import lib, _ptr
         v = lib().po_unrolled_dot(_ptr(x), _ptr(y), n)
         assert abs(v - float(np.dot(x.astype(np.float64), y.astype(np.float64)))) < 1e-4
+
+
+# ---- N3: index-time encode (codec.rs:297-411, index.rs:17-40) --------------------------------------------------
+def _unit(x):
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_compress_into_codes_last_of_equal_maxima_and_non_finite():
+    rng = np.random.default_rng(5)
+    cen = _unit(rng.standard_normal((64, 16)))
+    cen[9] = cen[3]                                   # two identical rows: Iterator::max_by keeps the LAST
+    z = rng.integers(0, 64, 500)
+    x = _unit(cen[z] + 0.05 * rng.standard_normal((500, 16)))
+    codes = O.compress_into_codes(x, cen)
+    ref = np.argmax(x.astype(np.float64) @ cen.T.astype(np.float64), 1)
+    ref = np.where(ref == 3, 9, ref)
+    assert np.array_equal(codes, ref)
+    assert not np.any(codes == 3) and np.any(codes == 9)
+    # a NaN embedding makes every score non-finite: all equal, the last centroid wins (cmp_f32_for_max)
+    bad = x[:1].copy()
+    bad[0, 0] = np.nan
+    assert O.compress_into_codes(bad, cen)[0] == 63
+    # a finite score always beats a non-finite one
+    cen2 = cen.copy()
+    cen2[50:] = np.inf
+    assert np.all(O.compress_into_codes(x, cen2) < 50)
+
+
+def test_encode_tokens_matches_numpy_bit_layout_and_roundtrips():
+    from next_plaid_amd import synth
+    rng = np.random.default_rng(6)
+    for nbits in (2, 4):
+        dim = 32
+        cen = _unit(rng.standard_normal((40, dim)))
+        x = _unit(cen[rng.integers(0, 40, 300)] + 0.08 * rng.standard_normal((300, dim)))
+        n = 1 << nbits
+        cut = np.quantile((x - cen[np.argmax(x @ cen.T, 1)]).ravel(), [i / n for i in range(1, n)]).astype(np.float32)
+        codes, packed = O.encode_tokens(x, cen, nbits, cut)
+        assert packed.shape == (300, dim * nbits // 8)           # codec.rs:722-729
+        res = x - cen[codes]
+        buckets = (res[:, :, None] > cut[None, None, :]).sum(-1)  # strictly-below count (codec.rs:386)
+        assert np.array_equal(synth.unpack_buckets(packed, nbits), buckets)
+        # independent packing: bucket bits LSB-first, written MSB-first
+        bits = ((buckets[:, :, None] >> np.arange(nbits)) & 1).astype(np.uint8).reshape(300, -1)
+        assert np.array_equal(np.packbits(bits, axis=1, bitorder="big"), packed)
+        # decompress(encode(x)) points the same way as x (codec.rs:700-713 sign agreement, cosine)
+        wts = np.array([res[buckets == b].mean() if np.any(buckets == b) else 0.0 for b in range(n)], np.float32)
+        rec = O.decompress(packed, codes, cen, wts, nbits)
+        cos = (rec * x).sum(1)
+        assert cos.min() > 0.9
