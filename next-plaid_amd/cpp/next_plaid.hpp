@@ -131,6 +131,33 @@ class MmapIndex {
     return out;
   }
 
+  // index.rs:1197-1245 decompress_documents: (embeddings [sum len, dim], lengths)
+  std::pair<std::vector<float>, std::vector<int64_t>> decompress_documents(const std::vector<int64_t>& doc_ids) const {
+    std::vector<int64_t> lens(std::max<size_t>(doc_ids.size(), 1));
+    check(np_hip_decompress_documents(h_, doc_ids.data(), (int64_t)doc_ids.size(), nullptr, 0, lens.data()));
+    lens.resize(doc_ids.size());
+    int64_t total = 0;
+    for (int64_t l : lens) total += l;
+    std::vector<float> emb((size_t)std::max<int64_t>(total, 1) * embedding_dim());
+    check(np_hip_decompress_documents(h_, doc_ids.data(), (int64_t)doc_ids.size(), emb.data(), total, lens.data()));
+    emb.resize((size_t)total * embedding_dim());
+    return {std::move(emb), std::move(lens)};
+  }
+
+  // index.rs:289-371 encode_index_chunk for a flat [n, dim] batch: (codes, packed residuals [n, dim*nbits/8])
+  std::pair<std::vector<int64_t>, std::vector<uint8_t>> encode_tokens(const float* embeddings, size_t n,
+                                                                      const std::vector<float>& bucket_cutoffs) const {
+    const size_t pd = embedding_dim() * (size_t)info_.nbits / 8;
+    std::vector<int64_t> codes(std::max<size_t>(n, 1));
+    std::vector<uint8_t> packed(std::max<size_t>(n * pd, 1));
+    if (bucket_cutoffs.size() + 1 != ((size_t)1 << info_.nbits)) throw Error(NP_ERR_CODEC, "Codec error: bucket_cutoffs size");
+    check(np_hip_encode_tokens(h_, embeddings, (int64_t)n, (int32_t)embedding_dim(), bucket_cutoffs.data(), codes.data(),
+                               packed.data()));
+    codes.resize(n);
+    packed.resize(n * pd);
+    return {std::move(codes), std::move(packed)};
+  }
+
   // index.rs:1290-1312
   size_t num_documents() const { return (size_t)info_.num_documents; }
   size_t num_embeddings() const { return (size_t)info_.num_embeddings; }
@@ -152,5 +179,21 @@ class MmapIndex {
   np_index* h_ = nullptr;
   np_info info_{};
 };
+
+// next-plaid-api handlers/rerank.rs:57-170: MaxSim of one query against caller-supplied document embeddings
+// (document i = rows doc_tok_offsets[i] .. doc_tok_offsets[i+1] of `docs`).  Returns (order, scores).
+inline std::pair<std::vector<int64_t>, std::vector<float>> rerank_maxsim(const float* query, size_t n_query_tokens,
+                                                                         size_t dim, const float* docs,
+                                                                         const std::vector<int64_t>& doc_tok_offsets,
+                                                                         int device = 0) {
+  const size_t n = doc_tok_offsets.empty() ? 0 : doc_tok_offsets.size() - 1;
+  std::vector<float> scores(std::max<size_t>(n, 1));
+  std::vector<int64_t> order(std::max<size_t>(n, 1));
+  check(np_hip_rerank_maxsim(device, query, (int32_t)n_query_tokens, (int32_t)dim, docs, doc_tok_offsets.data(), (int64_t)n,
+                             scores.data(), order.data()));
+  scores.resize(n);
+  order.resize(n);
+  return {std::move(order), std::move(scores)};
+}
 
 }  // namespace next_plaid
