@@ -1274,6 +1274,8 @@ struct ExactP {
   int n_sel;
   float* exact;             // [B][n_sel]
   Counters* ctr;
+  int xcd_B;                // > 0: 1-D grid, workgroup w serves query (w/8/gx)*8 + w%8 so a query stays on one XCD
+  int gx;                   // workgroups per query
 };
 
 #define NP_EXACT_DPW 4   // documents per wave
@@ -1731,7 +1733,17 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
   static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0, "unsupported DIM/NBITS");
   // byte -> {hi words, lo words}: one LDS read per residual byte returns both halves of the split
   __shared__ uint32_t lut[256 * WPB * 2];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  // S6 gathers one 128-B row of the query's score table per token (the MFMA C-in): the same L2-miss-bound
+  // access as S4.  With xcd_B set, all workgroups of a query run on ONE XCD (workgroup w -> XCD w % 8), so rows
+  // are reused out of that XCD's L2 instead of being refetched by eight.
+  int b = blockIdx.y, bx = blockIdx.x;
+  if (p.xcd_B > 0) {
+    const int slot = blockIdx.x >> 3;
+    b = (slot / p.gx) * 8 + (blockIdx.x & 7);
+    bx = slot % p.gx;
+    if (b >= p.xcd_B) return;
+  }
+  const int tid = threadIdx.x;
   {
     constexpr int PER = 8 / NBITS;
     constexpr uint32_t MASK = (1u << NBITS) - 1u;
@@ -1771,7 +1783,7 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
   }
   unsigned long long toks = 0, ndocs = 0;
   for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
-    const int j = (blockIdx.x * 4 + wave) * NP_EXACT_DPW + dd;
+    const int j = (bx * 4 + wave) * NP_EXACT_DPW + dd;
     if (j >= nsel) break;
     const int64_t oj = (int64_t)b * p.n_sel + j;
     if (p.sel_keys[oj] < cut) {

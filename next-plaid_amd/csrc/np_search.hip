@@ -206,8 +206,15 @@ static int launch_exact(hipStream_t st, const ExactP& p, int B, int precision) {
     // row-max form, whose running maxima need one register per query tile instead of sixteen
     static const bool rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
     if (NQT <= 2 && !rowmax) {
-      if (precision == 1) exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<dim3(gx, B), 256, 0, st>>>(p);
-      else exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<dim3(gx, B), 256, 0, st>>>(p);
+      ExactP px = p;
+      dim3 grid(gx, B);
+      if (B >= 8 && env_int("NP_S6_XCD", 1)) {   // one XCD per query (see exact_qct_kernel)
+        px.xcd_B = B;
+        px.gx = (int)gx;
+        grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
+      }
+      if (precision == 1) exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<grid, 256, 0, st>>>(px);
+      else exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<grid, 256, 0, st>>>(px);
     } else {
       if (precision == 1) exact_qc_kernel<DIM, NBITS, NQT, 1><<<dim3(gx, B), 256, 0, st>>>(p);
       else exact_qc_kernel<DIM, NBITS, NQT, 3><<<dim3(gx, B), 256, 0, st>>>(p);
@@ -460,6 +467,8 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.n_sel = cs->n_sel;
     ep.exact = w.exact.as<float>();
     ep.ctr = w.ctr.as<Counters>();
+    ep.xcd_B = 0;
+    ep.gx = 0;
     switch (ix->dim) {
       case 32: NP_TRY((launch_exact_nb<32>(st, ep, B, cs->prm.precision, ix->nbits))); break;
       case 64: NP_TRY((launch_exact_nb<64>(st, ep, B, cs->prm.precision, ix->nbits))); break;
