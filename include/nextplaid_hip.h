@@ -226,6 +226,12 @@ int np_hip_merge_topk(const np_index* index, const int64_t* d_ids, const float* 
                       int32_t top_k, int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts,
                       void* stream);
 
+/* Host-only validation of an index directory: parses and checks every file exactly as np_hip_index_open
+ * does (MmapIndex::load, index.rs:1026-1139; NPY headers mmap.rs:659-749; fast-plaid dtypes mmap.rs:1780-1808)
+ * without touching a device, and reports the index geometry (out->device = -1).  Same error codes/messages as
+ * np_hip_index_open. */
+int np_hip_index_probe_dir(const char* index_dir, np_info* out);
+
 /* ---- adjacent rows ----------------------------------------------------- */
 
 /* N2: MmapIndex::get_document_embeddings / decompress_documents (index.rs:1159-1245): decompressed,

@@ -818,4 +818,49 @@ int np_hip_index_info(const np_index* ix, np_info* out) {
   return NP_OK;
 }
 
+// Host-only: parse and validate an index directory exactly like np_hip_index_open does (MmapIndex::load,
+// index.rs:1026-1139; file formats mmap.rs:659-749) without touching a device.  Lets a service (or a CPU test)
+// check an index before it claims a GPU.  out->device = -1, no shard fields.
+int np_hip_index_probe_dir(const char* index_dir, np_info* out) {
+  clear_error();
+  if (!out) {
+    set_error("np_hip_index_probe_dir: NULL argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  HostIndex h;
+  NP_TRY(load_index_dir(index_dir, &h));
+  NP_TRY(check_geometry(h.K, h.dim, h.nbits, h.num_documents_total));
+  // every code must name a centroid and every posting a document (the same checks build_device_index makes)
+  for (const HostChunk& c : h.chunks)
+    for (int64_t t = 0; t < c.n_tokens; ++t)
+      if (c.codes[t] < 0 || c.codes[t] >= h.K) {
+        set_error("Index load failed: code %lld is outside [0, %lld)", (long long)c.codes[t], (long long)h.K);
+        return NP_ERR_INDEX_LOAD;
+      }
+  int64_t ivf_sum = 0;
+  for (int64_t i = 0; i < h.K; ++i) ivf_sum += h.ivf_lengths[i];
+  for (int64_t i = 0; i < ivf_sum; ++i)
+    if (h.ivf[i] < 0 || h.ivf[i] >= h.num_documents_total) {
+      set_error("Index load failed: ivf entry %lld is outside [0, %lld)", (long long)h.ivf[i],
+                (long long)h.num_documents_total);
+      return NP_ERR_INDEX_LOAD;
+    }
+  memset(out, 0, sizeof *out);
+  int64_t tokens = 0;
+  for (const HostChunk& c : h.chunks) tokens += c.n_tokens;
+  out->num_documents = h.num_documents_total;
+  out->num_embeddings = h.num_embeddings_total;
+  out->num_partitions = h.K;
+  out->embedding_dim = h.dim;
+  out->nbits = h.nbits;
+  out->avg_doclen = h.avg_doclen;
+  out->shard_doc_begin = 0;
+  out->shard_doc_end = h.num_documents_total;
+  out->shard_embeddings = tokens;
+  out->device_bytes = 0;
+  out->device = -1;
+  out->abi_version = NP_ABI_VERSION;
+  return NP_OK;
+}
+
 }  // extern "C"

@@ -108,7 +108,7 @@ class np_synth_spec(C.Structure):
 EXPORTS = [
     "np_hip_device_count", "np_hip_last_error", "np_hip_index_open", "np_hip_index_from_arrays",
     "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_close",
-    "np_hip_index_info", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
+    "np_hip_index_info", "np_hip_index_probe_dir", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
     "np_hip_search_phase_b", "np_hip_search_end", "np_hip_n_sel", "np_hip_select_cut", "np_hip_merge_topk",
     "np_hip_decompress_documents", "np_hip_encode_tokens", "np_hip_rerank_maxsim", "np_hip_debug_trace",
 ]
@@ -140,6 +140,7 @@ def lib():
     L.np_hip_index_close.argtypes = [vp]
     L.np_hip_index_close.restype = None
     L.np_hip_index_info.argtypes = [vp, C.POINTER(np_info)]
+    L.np_hip_index_probe_dir.argtypes = [C.c_char_p, C.POINTER(np_info)]
     L.np_hip_search_batch.argtypes = [vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64, vp, vp, vp,
                                       C.POINTER(np_stats)]
     L.np_hip_search_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,
@@ -166,6 +167,13 @@ def _check(rc: int):
     if rc:
         msg = lib().np_hip_last_error().decode("utf-8", "replace")
         raise _ERR.get(rc, NextPlaidError)(msg or f"np_status {rc}")
+
+
+def probe_index_dir(path: str) -> np_info:
+    """Host-only parse + validation of an index directory (same checks and errors as MmapIndex.load; no GPU)."""
+    info = np_info()
+    _check(lib().np_hip_index_probe_dir(os.fsencode(path), C.byref(info)))
+    return info
 
 
 def rerank_maxsim(query, documents, device: int = 0):
