@@ -116,6 +116,29 @@ EXPORTS = [
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes cannot share a
+    process: if libnextplaid_hip.so pulls in /opt/rocm's copy first, a later `import torch` loads the bundled one
+    next to it and torch's device init fails ("no ROCm-capable device is detected").  So when torch is installed
+    its runtime is loaded first (without importing torch); our NEEDED libamdhip64.so.7 then binds to that copy and
+    torch reuses it.  Without torch (C++/Rust hosts, plain ctypes users) the system runtime is used."""
+    if os.environ.get("NEXTPLAID_HIP_NO_TORCH_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libnextplaid_hip.so.  Raises DeviceUnavailableError if it is not built."""
     global _lib
@@ -124,6 +147,7 @@ def lib():
     path = library_path()
     if not os.path.exists(path):
         raise DeviceUnavailableError(f"{path} not built (run python -c 'import __graft_entry__ as g; g.build()')")
+    _preload_hip_runtime()
     try:
         L = C.CDLL(path)
     except OSError as e:  # e.g. libamdhip64 missing

@@ -108,3 +108,21 @@ def test_params_mirror_reference_defaults():
     assert c.has_threshold == 1 and abs(c.centroid_score_threshold - 0.4) < 1e-7
     assert api.lib().np_hip_n_sel(C.byref(c)) == 1024          # max(4096/4, 10)
     assert api.lib().np_hip_n_sel(C.byref(npa.SearchParameters(n_full_scores=8, top_k=10)._c())) == 8
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """PyTorch-ROCm bundles its own libamdhip64; if libnextplaid_hip.so dragged in /opt/rocm's copy first, a later
+    `import torch` would add a second runtime and torch.cuda would report "no ROCm-capable device".  api.lib()
+    therefore loads torch's copy first when torch is installed.  Checked in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from next_plaid_amd import api\n"
+        "api.lib()\n"
+        "import torch\n"
+        "libs = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+        "print(len(libs), sorted(libs))\n"
+        "assert len(libs) == 1, libs\n" % os.path.join(ROOT, "next-plaid_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
