@@ -43,6 +43,13 @@ def _worker(rank, world, port, top_k, nfs, thr):
         flat = torch.from_numpy(np.concatenate(qs, 0))
         p = npa.SearchParameters(n_full_scores=nfs, top_k=top_k, n_ivf_probe=4, centroid_score_threshold=thr)
         ids, sc, cnt = ShardedSearcher([be]).search_batch_device(flat, torch.from_numpy(off), off, p)
+        # bench.py overlaps batches on per-stream process groups: two searchers on their own groups, interleaved,
+        # must give the same answer as the default group
+        g1, g2 = dist.new_group(ranks=list(range(world))), dist.new_group(ranks=list(range(world)))
+        s1, s2 = ShardedSearcher([be], group=g1), ShardedSearcher([be], group=g2)
+        for ss in (s1, s2, s1):
+            i2, c2, n2 = ss.search_batch_device(flat, torch.from_numpy(off), off, p)
+            assert torch.equal(i2, ids) and torch.equal(c2, sc) and torch.equal(n2, cnt), rank
         full = oracle_index(a)
         po = O.SearchParameters(n_full_scores=nfs, top_k=top_k, n_ivf_probe=4, centroid_score_threshold=thr)
         for i, q in enumerate(qs):
