@@ -1124,6 +1124,211 @@ __global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// S4, L2-resident + streamed variant (NP_S4_MODE 5..8; same value, bit for bit).
+// approx_xcd_kernel advances the 8 groups of a wave in lockstep over ONE document each, so every step runs to the
+// longest of 8 segments (about 1.4 rows issued per useful row) and pays one dependent code fetch per step.
+// Here a group's segments of the current phase (one per owned document) form one stream: segment k occupies
+// positions [pfx[k], pfx[k] + pad4(len_k)), padded with duplicates of its own last code, so every aligned
+// 4-position sub-batch belongs to exactly one document.  Per phase the whole stream window is staged into LDS
+// in one burst (16 independent code loads per lane, u16 code - slice base), then the wave walks
+// max_g(stream length) positions: 4 row gathers per sub-batch, folded into the running maxima of that
+// sub-batch's document by an LDS read-modify-write (thread-private).  Positions past a group's stream read
+// row `slice base` into a trash slot, so no load is predicated.  Streams longer than the window take
+// further rounds.
+// ---------------------------------------------------------------------------------------------
+#define NP_S4S_MAXD 5      // documents per group per tile; slot NP_S4S_MAXD is the trash slot
+#define NP_S4S_CAP 128     // stream positions staged per round
+template <int LPR>
+__global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
+                                                            const int32_t* __restrict__ qoff,
+                                                            const uint4* __restrict__ cand_meta, int64_t cand_stride,
+                                                            const int32_t* __restrict__ n_cand, int B,
+                                                            const uint32_t* __restrict__ codes, int64_t T,
+                                                            const uint4* __restrict__ useg, float* __restrict__ approx,
+                                                            int pshift, uint32_t slice_w, Counters* ctr) {
+  constexpr int RPI = 64 / LPR;   // groups per wave
+  constexpr int GPB = 4 * RPI;    // groups per workgroup
+  constexpr int NST = NP_S4S_CAP / LPR;   // staged positions per lane per round
+  static_assert(LPR >= 8 && NP_S4S_MAXD <= 8, "one lane per slot builds the segment table");
+  __shared__ float4 s_state[NP_S4S_MAXD + 1][256];
+  __shared__ int64_t s_off[NP_S4S_MAXD][GPB];
+  __shared__ uint16_t s_end[NP_S4S_MAXD][GPB][8];
+  __shared__ int64_t s_abs[GPB][NP_S4S_MAXD];     // this phase: first code of each segment (absolute index)
+  __shared__ int s_len[GPB][NP_S4S_MAXD];         //             its length
+  __shared__ int s_pfx[GPB][NP_S4S_MAXD];         //             its first stream position
+  __shared__ uint16_t s_codes[GPB][NP_S4S_CAP];   // staged window: code - slice base
+  __shared__ uint8_t s_slot[GPB][NP_S4S_CAP / 4]; // document slot of every 4-position sub-batch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jq = lane & (LPR - 1), grp = lane / LPR, g = wave * RPI + grp;
+  const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
+  const int64_t NG = (int64_t)NBX * GPB;
+  const int64_t gid = (int64_t)(blockIdx.x >> 3) * GPB + g;
+  const int P = 8 >> pshift;
+  const uint32_t row_bytes = (uint32_t)LQP * 4u;
+  const uint32_t col_bytes = (4 * jq < LQP) ? (uint32_t)jq * 16u : 0u;
+  const int lbase = grp * LPR;
+  unsigned long long toks = 0, ucnt = 0;
+
+  for (int b = x; b < B; b += 8) {
+    const int64_t n = n_cand[b];
+    const char* Tb = reinterpret_cast<const char*>(QCT + (int64_t)b * KP * LQP);
+    const int lq = qoff[b + 1] - qoff[b];
+    const uint4* metab = cand_meta + (int64_t)b * cand_stride;
+    for (int64_t tile0 = 0; tile0 < n; tile0 += NG * NP_S4S_MAXD) {
+      const int d = (int)min((int64_t)NP_S4S_MAXD, (n - tile0 + NG - 1) / NG);
+      __syncthreads();   // previous tile's LDS slots are free
+      for (int k = 0; k < d; ++k) {
+        const int64_t i = tile0 + (int64_t)k * NG + gid;
+        s_state[k][tid] = make_float4(NP_NEG_INF, NP_NEG_INF, NP_NEG_INF, NP_NEG_INF);
+        if (jq == 0) {
+          int64_t off = 0;
+          uint4 sg = make_uint4(0, 0, 0, 0);
+          if (i < n) {
+            const uint4 m = metab[i];
+            off = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
+            sg = useg[m.x];
+            toks += (unsigned long long)(m.w >> 8);
+            ucnt += (unsigned long long)m.y;
+          }
+          s_off[k][g] = off;
+          *reinterpret_cast<uint4*>(&s_end[k][g][0]) = sg;
+        }
+      }
+      __syncthreads();
+      for (int p = 0; p < P; ++p) {
+        // segment table of this phase: lane jq < d of every group describes slot jq
+        int len = 0;
+        int64_t abs0 = 0;
+        if (jq < d) {
+          const int e = (int)s_end[jq][g][((p + 1) << pshift) - 1];
+          const int s = p ? (int)s_end[jq][g][(p << pshift) - 1] : 0;
+          len = e - s;
+          abs0 = s_off[jq][g] + s;
+        }
+        const int pad = (len + 3) & ~3;
+        int incl = pad;
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) {
+          const int v = __shfl_up(incl, o, LPR);
+          if (jq >= o) incl += v;
+        }
+        if (jq < NP_S4S_MAXD) {
+          s_pfx[g][jq] = incl - pad;
+          s_abs[g][jq] = abs0;
+          s_len[g][jq] = len;
+        }
+        const int Lg = __shfl(incl, lbase + LPR - 1);   // this group's stream length (multiple of 4)
+        int maxL = Lg;
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) maxL = max(maxL, __shfl_xor(maxL, o));
+        maxL = __builtin_amdgcn_readfirstlane(maxL);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int p1 = s_pfx[g][1], p2 = s_pfx[g][2], p3 = s_pfx[g][3], p4 = s_pfx[g][4];
+        const uint32_t slice_lo = (uint32_t)(p << pshift) * slice_w;
+        const char* Tp = Tb + (size_t)slice_lo * row_bytes;
+        for (int base = 0; base < maxL; base += NP_S4S_CAP) {
+          // ---- stage the window [base, base + CAP): two bursts of NST/2 independent code loads per lane
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint32_t cv[NST / 2];
+#pragma unroll
+            for (int i = 0; i < NST / 2; ++i) {
+              const int pos = base + jq + LPR * (h * (NST / 2) + i);
+              const int slot = (pos >= p1) + (pos >= p2) + (pos >= p3) + (pos >= p4);
+              const int idx = min(pos - s_pfx[g][slot], max(s_len[g][slot] - 1, 0));
+              int64_t a = s_abs[g][slot] + (int64_t)max(idx, 0);
+              a = (pos < Lg) ? min(a, T - 1) : 0;
+              cv[i] = codes[a];
+            }
+#pragma unroll
+            for (int i = 0; i < NST / 2; ++i) {
+              const int w = jq + LPR * (h * (NST / 2) + i);   // position inside the window
+              const int pos = base + w;
+              const bool valid = pos < Lg;
+              const int slot = (pos >= p1) + (pos >= p2) + (pos >= p3) + (pos >= p4);
+              s_codes[g][w] = valid ? (uint16_t)(cv[i] - slice_lo) : (uint16_t)0;
+              if ((pos & 3) == 0) s_slot[g][w >> 2] = valid ? (uint8_t)slot : (uint8_t)NP_S4S_MAXD;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // ---- walk it: 4 positions = one document
+          const int nwin = min(NP_S4S_CAP, maxL - base);
+          for (int t0 = 0; t0 < nwin; t0 += 8) {
+            const bool two = t0 + 4 < nwin;   // wave-uniform
+            const uint2 ca = *reinterpret_cast<const uint2*>(&s_codes[g][t0]);
+            const int sa = (int)s_slot[g][t0 >> 2];
+            float4 v[8];
+            v[0] = *reinterpret_cast<const float4*>(Tp + ((ca.x & 0xFFFFu) * row_bytes + col_bytes));
+            v[1] = *reinterpret_cast<const float4*>(Tp + ((ca.x >> 16) * row_bytes + col_bytes));
+            v[2] = *reinterpret_cast<const float4*>(Tp + ((ca.y & 0xFFFFu) * row_bytes + col_bytes));
+            v[3] = *reinterpret_cast<const float4*>(Tp + ((ca.y >> 16) * row_bytes + col_bytes));
+            int sb = NP_S4S_MAXD;
+            if (two) {
+              const uint2 cb = *reinterpret_cast<const uint2*>(&s_codes[g][t0 + 4]);
+              sb = (int)s_slot[g][(t0 + 4) >> 2];
+              v[4] = *reinterpret_cast<const float4*>(Tp + ((cb.x & 0xFFFFu) * row_bytes + col_bytes));
+              v[5] = *reinterpret_cast<const float4*>(Tp + ((cb.x >> 16) * row_bytes + col_bytes));
+              v[6] = *reinterpret_cast<const float4*>(Tp + ((cb.y & 0xFFFFu) * row_bytes + col_bytes));
+              v[7] = *reinterpret_cast<const float4*>(Tp + ((cb.y >> 16) * row_bytes + col_bytes));
+            } else {
+#pragma unroll
+              for (int u = 4; u < 8; ++u) v[u] = make_float4(NP_NEG_INF, NP_NEG_INF, NP_NEG_INF, NP_NEG_INF);
+            }
+            s4_fence<8>(v);
+            float4 ma = s_state[sa][tid];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              ma.x = fmaxf(ma.x, v[u].x);
+              ma.y = fmaxf(ma.y, v[u].y);
+              ma.z = fmaxf(ma.z, v[u].z);
+              ma.w = fmaxf(ma.w, v[u].w);
+            }
+            s_state[sa][tid] = ma;
+            float4 mb = s_state[sb][tid];   // after the store above: sa may equal sb
+#pragma unroll
+            for (int u = 4; u < 8; ++u) {
+              mb.x = fmaxf(mb.x, v[u].x);
+              mb.y = fmaxf(mb.y, v[u].y);
+              mb.z = fmaxf(mb.z, v[u].z);
+              mb.w = fmaxf(mb.w, v[u].w);
+            }
+            s_state[sb][tid] = mb;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();   // the next round / phase overwrites the window and the tables
+        }
+      }
+      // q-ordered sums (search.rs:308-321), every lane of the group redundantly
+      for (int k = 0; k < d; ++k) {
+        const int64_t i = tile0 + (int64_t)k * NG + gid;
+        const float4 m = s_state[k][tid];
+        float score = 0.f;
+        for (int jj = 0; 4 * jj < lq; ++jj) {
+          const float a0 = __shfl(m.x, lbase + jj), a1 = __shfl(m.y, lbase + jj);
+          const float a2 = __shfl(m.z, lbase + jj), a3 = __shfl(m.w, lbase + jj);
+          if (a0 > NP_NEG_INF) score += a0;
+          if (4 * jj + 1 < lq && a1 > NP_NEG_INF) score += a1;
+          if (4 * jj + 2 < lq && a2 > NP_NEG_INF) score += a2;
+          if (4 * jj + 3 < lq && a3 > NP_NEG_INF) score += a3;
+        }
+        if (jq == 0 && i < n) approx[(int64_t)b * cand_stride + i] = s_end[k][g][7] ? score : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    toks += __shfl_xor(toks, o);
+    ucnt += __shfl_xor(ucnt, o);
+  }
+  if (lane == 0 && toks) {
+    atomicAdd(&ctr->n_cand_tokens, toks);
+    atomicAdd(&ctr->n_cand_codes, ucnt);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // block bitonic sort, descending, n = power of two, in LDS
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n, int tid, int nthreads) {

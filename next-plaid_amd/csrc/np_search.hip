@@ -383,14 +383,30 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
 
   // ---- S4
   if (!cs->empty_subset && ix->n_docs > 0) {
-    // NP_S4_MODE: 0 = all XCDs walk one query (approx_kernel), 1..4 = one XCD per query in 8/4/2/1 phases
+    // NP_S4_MODE: 0 = all XCDs walk one query (approx_kernel), 1..4 = one XCD per query in 8/4/2/1 phases,
+    // 5..8 = the same with every group streaming through its documents (approx_stream_kernel)
     const int s4_mode = env_int("NP_S4_MODE", 2), s4_minb = env_int("NP_S4_MINB", 8);
     const unsigned s4_nbx = (unsigned)env_int("NP_S4_NBX", 128);
-    if (s4_mode > 0 && ix->sliced_ok && B >= s4_minb) {
+    const uint32_t s4_slice_w = (uint32_t)((ix->K + 7) / 8);
+    const int s4_p = std::min(s4_mode > 4 ? s4_mode - 4 : s4_mode, 4);   // phases = 8 >> (s4_p - 1)
+    const bool s4_stream = s4_mode >= 5 && s4_mode <= 8 && ((uint64_t)s4_slice_w << (s4_mode - 5)) <= 65536ull;
+    if (s4_stream && ix->sliced_ok && B >= s4_minb) {
+      // streamed form (approx_stream_kernel): u16 code-in-slice needs a phase's centroid range <= 65536
+#define NP_LAUNCH_APPROX_S(LPR)                                                                                        \
+  approx_stream_kernel<LPR><<<8 * s4_nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(),   \
+                                                        cand_stride, w.n_cand.as<int32_t>(), B, ix->d_ucodes, ix->T,   \
+                                                        ix->d_useg, w.approx.as<float>(), s4_mode - 5, s4_slice_w,     \
+                                                        w.ctr.as<Counters>())
+      if (LQP <= 32) NP_LAUNCH_APPROX_S(8);
+      else if (LQP <= 64) NP_LAUNCH_APPROX_S(16);
+      else if (LQP <= 128) NP_LAUNCH_APPROX_S(32);
+      else NP_LAUNCH_APPROX_S(64);
+#undef NP_LAUNCH_APPROX_S
+    } else if (s4_mode > 0 && ix->sliced_ok && B >= s4_minb) {
 #define NP_LAUNCH_APPROX_X(LPR, SWZ)                                                                                   \
   approx_xcd_kernel<LPR, SWZ><<<8 * s4_nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(), \
                                                           cand_stride, w.n_cand.as<int32_t>(), B, ix->d_ucodes, ix->T,  \
-                                                          ix->d_useg, w.approx.as<float>(), s4_mode - 1,               \
+                                                          ix->d_useg, w.approx.as<float>(), s4_p - 1,                  \
                                                           w.ctr.as<Counters>())
       if (LQP <= 32) {
         if (env_int("NP_S4_SWZ", 1)) NP_LAUNCH_APPROX_X(8, true);

@@ -65,9 +65,10 @@ def test_stages_mid(mid):
             check_trace(hx, ox, qs[qi], p, what=f"thr={thr} q{qi}")
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_s4_kernel_variants_bit_exact(mid, mode, monkeypatch):
-    """S4 has two kernels (all XCDs on one query / one XCD per query in 8,4,2,1 phases over the centroid range);
+    """S4 has three kernels (all XCDs on one query / one XCD per query in 8,4,2,1 phases over the centroid range,
+    lockstep or streamed);
     the library reads NP_S4_MODE / NP_S4_MINB on every call.  Every variant must reproduce the oracle's
     approximate scores bit for bit -- also for one-query calls (MINB=1), ragged query lengths and the
     bpermute code broadcast."""
