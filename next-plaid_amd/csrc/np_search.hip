@@ -386,7 +386,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     // NP_S4_MODE: 0 = all XCDs walk one query (approx_kernel), 1..4 = one XCD per query in 8/4/2/1 phases,
     // 5..8 = the same with every group streaming through its documents (approx_stream_kernel)
     const int s4_mode = env_int("NP_S4_MODE", 2), s4_minb = env_int("NP_S4_MINB", 8);
-    const unsigned s4_nbx = (unsigned)env_int("NP_S4_NBX", 128);
+    const unsigned s4_nbx = (unsigned)std::min(std::max(env_int("NP_S4_NBX", 128), 8), 512);   // workgroups per XCD
     const uint32_t s4_slice_w = (uint32_t)((ix->K + 7) / 8);
     const int s4_p = std::min(s4_mode > 4 ? s4_mode - 4 : s4_mode, 4);   // phases = 8 >> (s4_p - 1)
     const bool s4_stream = s4_mode >= 5 && s4_mode <= 8 && ((uint64_t)s4_slice_w << (s4_mode - 5)) <= 65536ull;
