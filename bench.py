@@ -139,6 +139,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # initialisation, not warmup: every stream's workspace (and, sharded, its RCCL communicator) is created on first
+    # use; touch each once so that a small --warmup cannot push that one-time cost into the timed region
+    for i in range(nstr):
+        step(i)
+    barrier()
     for i in range(a.warmup):
         step(i)
     barrier()
