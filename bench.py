@@ -254,6 +254,9 @@ def main():
                   2: "f32 (split-bf16 hi/lo MFMA on the residual term of MaxSim, f32-class accuracy)",
                   3: "f32 + bf16 MaxSim"}[a.precision], "data": "synthetic",
         "streams": nstr,
+        # weak scaling here = the corpus grows with N (one 1M-doc shard per GPU) while every rank answers the same
+        # queries, so queries/s is expected to stay flat; the work rate that grows with N is documents searched per s
+        "docs_searched_per_s": round(qps * a.docs_per_gpu * world, 1),
         "config": {"workload": f"{a.docs_per_gpu * world} docs x {a.doc_len} tok x d128 (nbits=4), 2^{int(np.log2(a.centroids))} centroids, "
                                f"nprobe={a.nprobe}, batch={a.batch}x{a.query_tokens} tok, n_full_scores={a.n_full_scores}, "
                                f"t_cs={thr}, top_k={a.top_k}; {a.docs_per_gpu} docs per GPU shard",
