@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 1
+#define NP_ABI_VERSION 2
 
 typedef enum np_status {
   NP_OK = 0,
@@ -106,7 +106,8 @@ typedef struct np_stats {
   int64_t n_exact_tokens;/* tokens decompressed by S6 */
   int64_t n_cand_codes;  /* distinct (doc, code) pairs actually gathered by S4 (<= n_cand_tokens) */
   int32_t n_queries;
-  int32_t reserved;
+  int32_t n_rounds;      /* candidate-pool rounds (1 unless the batch's candidates overflowed workspace_bytes) */
+  int64_t n_survivors;   /* candidates that passed the S4 upper-bound filter and got an exact approximate score */
 } np_stats;
 
 /* ---- runtime ------------------------------------------------------------------------------ */
@@ -166,6 +167,13 @@ int np_hip_index_synth(const np_synth_spec* spec, const np_open_opts* opts, np_i
 int np_hip_index_export(const np_index* index, int64_t* doc_lengths, int64_t* codes, uint8_t* residuals,
                         int64_t* ivf, int32_t* ivf_lengths);
 int64_t np_hip_index_ivf_size(const np_index* index);
+
+/* Kernel-selection knobs (no reference counterpart).  They are read from the environment once, at open
+ * (NP_S4_MODE, NP_S4_MINB, NP_S4_NBX, NP_S4_SWZ, NP_S4_FILTER, NP_S6_XCD, NP_GEMM_CPW, NP_EXACT_ROWMAX); this call changes
+ * one ("s4_mode", "s4_minb", "s4_nbx", "s4_swz", "s4_filter", "s6_xcd", "gemm_cpw", "exact_rowmax") on a live handle for
+ * sweep tools and the kernel-variant parity tests.  Results are identical for every setting; not synchronised
+ * with concurrent searches. */
+int np_hip_index_tune(np_index* index, const char* name, int32_t value);
 
 void np_hip_index_close(np_index* index);               /* Drop for MmapIndex */
 int np_hip_index_info(const np_index* index, np_info* out); /* index.rs:1290-1312 */

@@ -41,7 +41,7 @@ struct SearchParameters {  // search.rs:26-69
   size_t n_ivf_probe = 8;
   size_t centroid_batch_size = 100000;
   std::optional<float> centroid_score_threshold = 0.4f;
-  int precision = 0;  // 0 = fp32 parity mode, 1 = bf16 MaxSim
+  int precision = 2;  // exact-MaxSim arithmetic (np_search_params.precision): 2 = split-bf16 QC-reuse, f32-class (default)
   np_search_params c() const {
     np_search_params p{};
     p.top_k = (int32_t)top_k;

@@ -9,6 +9,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 
 namespace np {
@@ -58,6 +59,21 @@ int normalise_opts(const np_open_opts* in, np_open_opts* o) {
   if (o->max_query_tokens <= 0) o->max_query_tokens = 64;
   if (o->workspace_bytes <= 0) o->workspace_bytes = (int64_t)8 << 30;
   return NP_OK;
+}
+
+void read_tuning_env(Tuning* t) {
+  auto env = [](const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+  };
+  t->s4_mode = std::min(std::max(env("NP_S4_MODE", t->s4_mode), 0), 8);
+  t->s4_minb = std::max(env("NP_S4_MINB", t->s4_minb), 1);
+  t->s4_nbx = std::min(std::max(env("NP_S4_NBX", t->s4_nbx), 8), 512);
+  t->s4_swz = env("NP_S4_SWZ", t->s4_swz) != 0;
+  t->s4_filter = env("NP_S4_FILTER", t->s4_filter) != 0;
+  t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
+  t->gemm_cpw = env("NP_GEMM_CPW", t->gemm_cpw) == 2 ? 2 : 1;
+  t->exact_rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
 }
 
 static int check_device(int dev) {
@@ -225,6 +241,10 @@ __global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim, int n
 }
 
 static int build_inv_norm(DeviceIndex* ix) {
+  if (ix->d_inv_norm) {
+    set_error("internal: inv_norm built twice");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
   NP_TRY(dev_alloc(&ix->d_inv_norm, (size_t)ix->T, &ix->device_bytes));
   if (ix->T > 0) {
     const int64_t nblk = (ix->T + 255) / 256;
@@ -323,11 +343,16 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
 
   ix->device = o.device;
   ix->opts = o;
+  read_tuning_env(&ix->tune);
   ix->N_total = h.num_documents_total;
   ix->n_emb_total = h.num_embeddings_total;
   ix->avg_doclen = h.avg_doclen;
   ix->doc_begin = sb;
   ix->n_docs = se - sb;
+  if (ix->n_docs >= ((int64_t)1 << 31)) {
+    set_error("Index load failed: a shard holds < 2^31 documents (got %lld); use more shards", (long long)ix->n_docs);
+    return NP_ERR_INDEX_LOAD;
+  }
   ix->K = h.K;
   ix->KP = (h.K + 63) / 64 * 64;
   ix->dim = h.dim;
@@ -452,8 +477,7 @@ __global__ void synth_lens_kernel(SynthP p, int64_t* lens) {
 
 // one wave per document
 __global__ void __launch_bounds__(256) synth_tokens_kernel(SynthP p, const int64_t* __restrict__ doc_off,
-                                                           uint32_t* __restrict__ codes, uint8_t* __restrict__ res,
-                                                           uint64_t* __restrict__ keys) {
+                                                           uint32_t* __restrict__ codes, uint8_t* __restrict__ res) {
   const int lane = threadIdx.x & 63;
   int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= p.n_docs) return;
@@ -471,7 +495,6 @@ __global__ void __launch_bounds__(256) synth_tokens_kernel(SynthP p, const int64
       code = (uint32_t)(((rt & 0xFFFFFFFFull) % p.K) >> ((rt >> 32) & 3));
     }
     codes[off + t] = code;
-    if (keys) keys[off + t] = ((uint64_t)code << 32) | (uint64_t)d;
   }
   const int nwords = len * p.nw;
   for (int w = lane; w < nwords; w += 64) {
@@ -487,13 +510,160 @@ __global__ void __launch_bounds__(256) synth_tokens_kernel(SynthP p, const int64
   }
 }
 
-__global__ void ivf_from_unique_kernel(const uint64_t* __restrict__ ukeys, int64_t n, uint32_t* __restrict__ ivf,
-                                       unsigned int* __restrict__ lens) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- IVF from the per-document distinct-code lists (index.rs:479-499: per centroid the ascending unique doc ids) ----
+// Pairs (code << 32 | shard-local doc) are emitted from ucodes/ulen for a contiguous document range, radix-sorted,
+// and scattered into the posting lists.  Ranges hold at most NP_IVF_SEG pairs, so every hipcub call sees a count
+// below 2^31 whatever the shard size (a 10M-document x 300-token shard has 3.0e9 tokens, ~0.7e9 pairs).
+#define NP_IVF_SEG ((int64_t)1 << 29)
+
+// one wave per document: pair position = (exclusive prefix of ulen) - seg_base
+__global__ void __launch_bounds__(256) ivf_emit_pairs_kernel(int64_t d0, int64_t d1, const int64_t* __restrict__ doc_off,
+                                                             const uint32_t* __restrict__ ucodes,
+                                                             const int32_t* __restrict__ ulen,
+                                                             const int64_t* __restrict__ upfx /* inclusive */,
+                                                             int64_t seg_base, uint64_t* __restrict__ keys) {
+  const int64_t d = d0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (d >= d1) return;
+  const int n = ulen[d];
+  const int64_t pos = upfx[d] - n - seg_base;
+  const int64_t off = doc_off[d];
+  for (int i = lane; i < n; i += 64) keys[pos + i] = ((uint64_t)ucodes[off + i] << 32) | (uint64_t)d;
+}
+
+// start[c] = first sorted pair whose code is >= c  (c = 0..K; start[K] = n)
+__global__ void ivf_code_starts_kernel(const uint64_t* __restrict__ sorted, int64_t n, int64_t K,
+                                       int64_t* __restrict__ start) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > K) return;
+  const uint64_t key = (uint64_t)c << 32;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  start[c] = lo;
+}
+
+// ivf[dst_base[code] + (i - start[code])] = doc
+__global__ void ivf_scatter_kernel(const uint64_t* __restrict__ sorted, int64_t n, const int64_t* __restrict__ start,
+                                   const int64_t* __restrict__ dst_base, uint32_t* __restrict__ ivf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint64_t k = ukeys[i];
-  ivf[i] = (uint32_t)(k & 0xFFFFFFFFull);
-  atomicAdd(&lens[(uint32_t)(k >> 32)], 1u);
+  const uint64_t k = sorted[i];
+  const uint32_t c = (uint32_t)(k >> 32);
+  ivf[dst_base[c] + (i - start[c])] = (uint32_t)(k & 0xFFFFFFFFull);
+}
+
+__global__ void ulen_to_i64_kernel(const int32_t* __restrict__ ulen, int64_t n, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ulen[i];
+}
+
+static int build_ivf_from_ucodes(DeviceIndex* ix) {
+  const int64_t K = ix->K, N = ix->n_docs;
+  std::vector<int64_t> ioff((size_t)K + 1, 0);
+  ix->ivf_size = 0;
+  int64_t* d_upfx = nullptr;
+  uint64_t *d_k1 = nullptr, *d_k2 = nullptr;
+  int64_t *d_start = nullptr, *d_base = nullptr;
+  void* d_temp = nullptr;
+  struct Free {
+    void** p[6];
+    ~Free() {
+      for (void** q : p) (void)hipFree(*q);
+    }
+  } fr{{(void**)&d_upfx, (void**)&d_k1, (void**)&d_k2, (void**)&d_start, (void**)&d_base, &d_temp}};
+  std::vector<int64_t> upfx((size_t)N);
+  if (N > 0) {
+    NP_TRY(dev_alloc(&d_upfx, (size_t)N, nullptr));
+    ulen_to_i64_kernel<<<(unsigned)((N + 255) / 256), 256>>>(ix->d_ulen, N, d_upfx);
+    size_t tb = 0;
+    NP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_upfx, d_upfx, (int)N));
+    NP_HIP(hipMalloc(&d_temp, std::max<size_t>(tb, 16)));
+    NP_HIP(hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_upfx, d_upfx, (int)N));
+    NP_HIP(hipMemcpy(upfx.data(), d_upfx, (size_t)N * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_temp);
+    d_temp = nullptr;
+  }
+  const int64_t total = N > 0 ? upfx[(size_t)N - 1] : 0;
+  // document ranges of at most NP_IVF_SEG pairs (a single document never exceeds 65535 distinct codes... any size fits)
+  std::vector<int64_t> seg_d0;
+  for (int64_t d = 0; d < N;) {
+    seg_d0.push_back(d);
+    const int64_t base = d > 0 ? upfx[(size_t)d - 1] : 0;
+    const int64_t e = std::upper_bound(upfx.begin() + d, upfx.end(), base + NP_IVF_SEG) - upfx.begin();
+    d = std::max<int64_t>(e, d + 1);
+  }
+  seg_d0.push_back(N);
+  const int nseg = (int)seg_d0.size() - 1;
+  int64_t max_pairs = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const int64_t b = seg_d0[s] > 0 ? upfx[(size_t)seg_d0[s] - 1] : 0, e = seg_d0[s + 1] > 0 ? upfx[(size_t)seg_d0[s + 1] - 1] : 0;
+    max_pairs = std::max(max_pairs, e - b);
+  }
+  if (max_pairs >= ((int64_t)1 << 31)) {
+    set_error("Index load failed: one document range holds %lld (code, doc) pairs", (long long)max_pairs);
+    return NP_ERR_INDEX_LOAD;
+  }
+  ix->ivf_size = total;
+  NP_TRY(dev_alloc(&ix->d_ivf, (size_t)total, &ix->device_bytes));
+  if (total > 0) {
+    int kbits = 1;
+    while (((int64_t)1 << kbits) < K) ++kbits;
+    NP_TRY(dev_alloc(&d_k1, (size_t)max_pairs, nullptr));
+    NP_TRY(dev_alloc(&d_k2, (size_t)max_pairs, nullptr));
+    NP_TRY(dev_alloc(&d_start, (size_t)K + 1, nullptr));
+    NP_TRY(dev_alloc(&d_base, (size_t)K + 1, nullptr));
+    size_t tb = 0;
+    NP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_k1, d_k2, (int)max_pairs, 0, 32 + kbits));
+    NP_HIP(hipMalloc(&d_temp, std::max<size_t>(tb, 16)));
+    std::vector<std::vector<int64_t>> seg_start((size_t)nseg, std::vector<int64_t>((size_t)K + 1));
+    auto sort_segment = [&](int s, int64_t* n_out) -> int {
+      const int64_t d0 = seg_d0[s], d1 = seg_d0[s + 1];
+      const int64_t base = d0 > 0 ? upfx[(size_t)d0 - 1] : 0, n = upfx[(size_t)d1 - 1] - base;
+      *n_out = n;
+      if (n == 0) return NP_OK;
+      ivf_emit_pairs_kernel<<<(unsigned)((d1 - d0 + 3) / 4), 256>>>(d0, d1, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
+                                                                   d_upfx, base, d_k1);
+      size_t tbs = tb;
+      NP_HIP(hipcub::DeviceRadixSort::SortKeys(d_temp, tbs, d_k1, d_k2, (int)n, 0, 32 + kbits));
+      ivf_code_starts_kernel<<<(unsigned)((K + 256) / 256), 256>>>(d_k2, n, K, d_start);
+      NP_HIP(hipGetLastError());
+      return NP_OK;
+    };
+    // pass 1: per-range code counts (a single range keeps its sorted pairs for the scatter below)
+    for (int s = 0; s < nseg; ++s) {
+      int64_t n = 0;
+      NP_TRY(sort_segment(s, &n));
+      if (n == 0) std::fill(seg_start[(size_t)s].begin(), seg_start[(size_t)s].end(), 0);
+      else NP_HIP(hipMemcpy(seg_start[(size_t)s].data(), d_start, ((size_t)K + 1) * 8, hipMemcpyDeviceToHost));
+    }
+    for (int64_t c = 0; c < K; ++c) {
+      int64_t len = 0;
+      for (int s = 0; s < nseg; ++s) len += seg_start[(size_t)s][(size_t)c + 1] - seg_start[(size_t)s][(size_t)c];
+      ioff[(size_t)c + 1] = ioff[(size_t)c] + len;
+    }
+    // pass 2: scatter each range's lists behind the earlier ranges' (ranges are ascending in doc id)
+    std::vector<int64_t> base_c(ioff.begin(), ioff.end());
+    for (int s = 0; s < nseg; ++s) {
+      int64_t n = 0;
+      if (nseg > 1) NP_TRY(sort_segment(s, &n));
+      else n = total;
+      if (n > 0) {
+        NP_HIP(hipMemcpy(d_base, base_c.data(), ((size_t)K + 1) * 8, hipMemcpyHostToDevice));
+        ivf_scatter_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d_k2, n, d_start, d_base, ix->d_ivf);
+        NP_HIP(hipGetLastError());
+        NP_HIP(hipDeviceSynchronize());
+      }
+      for (int64_t c = 0; c < K; ++c) base_c[(size_t)c] += seg_start[(size_t)s][(size_t)c + 1] - seg_start[(size_t)s][(size_t)c];
+    }
+  }
+  NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
+  NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
+  NP_HIP(hipDeviceSynchronize());
+  return NP_OK;
 }
 
 static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, DeviceIndex** out) {
@@ -506,7 +676,7 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     return NP_ERR_INVALID_ARGUMENT;
   }
   NP_TRY(check_geometry(s->num_centroids, s->dim, s->nbits, s->num_docs));
-  if (s->doc_len_min < 0 || s->doc_len_max < s->doc_len_min || s->doc_len_max > 65535 || s->n_topics <= 0 ||
+  if (s->doc_len_min < 0 || s->doc_len_max < s->doc_len_min || s->doc_len_max > NP_UNIQ_MAX || s->n_topics <= 0 ||
       s->dim * s->nbits / 8 > 128) {
     set_error("Invalid configuration: synth doc_len/n_topics/packed width out of range");
     return NP_ERR_INVALID_ARGUMENT;
@@ -518,38 +688,31 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
   }
   np_index* nix = new np_index();
   DeviceIndex* ix = nix;
-  uint64_t* d_keys = nullptr;
-  uint64_t* d_keys2 = nullptr;
   void* d_temp = nullptr;
-  int64_t* d_nsel = nullptr;
-  unsigned int* d_lens32 = nullptr;
   struct Cleanup {
     np_index* p;
-    uint64_t** a;
-    uint64_t** b;
     void** c;
-    int64_t** d;
-    unsigned int** e;
     ~Cleanup() {
-      (void)hipFree(*a);
-      (void)hipFree(*b);
       (void)hipFree(*c);
-      (void)hipFree(*d);
-      (void)hipFree(*e);
       if (p) {
         destroy_device_index(p);
         delete p;
       }
     }
-  } cleanup{nix, &d_keys, &d_keys2, &d_temp, &d_nsel, &d_lens32};
+  } cleanup{nix, &d_temp};
 
   int64_t sb, se;
   shard_range(s->num_docs, o.shard_rank, o.shard_count, &sb, &se);
   ix->device = o.device;
   ix->opts = o;
+  read_tuning_env(&ix->tune);
   ix->N_total = s->num_docs;
   ix->doc_begin = sb;
   ix->n_docs = se - sb;
+  if (ix->n_docs >= ((int64_t)1 << 31)) {
+    set_error("synth: a shard holds < 2^31 documents (got %lld); use more shards", (long long)ix->n_docs);
+    return NP_ERR_INVALID_ARGUMENT;
+  }
   ix->K = s->num_centroids;
   ix->KP = (ix->K + 63) / 64 * 64;
   ix->dim = s->dim;
@@ -594,51 +757,16 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     }
   }
   NP_HIP(hipMemcpy(&ix->T, ix->d_doc_offsets + ix->n_docs, sizeof(int64_t), hipMemcpyDeviceToHost));
-  if (ix->T >= ((int64_t)1 << 31)) {
-    set_error("synth: shard holds %lld tokens; the in-HBM IVF build handles < 2^31 per shard (use more shards)",
-              (long long)ix->T);
+  if (ix->T >= ((int64_t)1 << 40)) {   // candidate records carry a 40-bit token offset
+    set_error("synth: shard holds %lld tokens; a shard addresses < 2^40 tokens (use more shards)", (long long)ix->T);
     return NP_ERR_INVALID_ARGUMENT;
   }
   ix->n_emb_total = 0;  // filled below for unsharded corpora; sharded: avg-based estimate
   NP_TRY(dev_alloc(&ix->d_codes, (size_t)ix->T, &ix->device_bytes));
   NP_TRY(dev_alloc(&ix->d_residuals, (size_t)ix->T * ix->pd, &ix->device_bytes));
-  NP_TRY(dev_alloc(&d_keys, (size_t)ix->T, nullptr));
   if (ix->n_docs > 0)
-    synth_tokens_kernel<<<(unsigned)((ix->n_docs + 3) / 4), 256>>>(p, ix->d_doc_offsets, ix->d_codes, ix->d_residuals,
-                                                                   d_keys);
+    synth_tokens_kernel<<<(unsigned)((ix->n_docs + 3) / 4), 256>>>(p, ix->d_doc_offsets, ix->d_codes, ix->d_residuals);
   NP_HIP(hipGetLastError());
-
-  // IVF: sort (code, doc) pairs, unique, split (index.rs:479-499)
-  NP_TRY(dev_alloc(&d_keys2, (size_t)ix->T, nullptr));
-  NP_TRY(dev_alloc(&d_nsel, 1, nullptr));
-  NP_TRY(dev_alloc(&d_lens32, (size_t)ix->K, nullptr));
-  NP_HIP(hipMemset(d_lens32, 0, (size_t)ix->K * 4));
-  NP_HIP(hipMemset(d_nsel, 0, 8));
-  int64_t n_unique = 0;
-  if (ix->T > 0) {
-    int kbits = 1;
-    while (((int64_t)1 << kbits) < ix->K) ++kbits;
-    size_t tb1 = 0, tb2 = 0;
-    hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, d_keys, d_keys2, (int)ix->T, 0, 32 + kbits);
-    hipcub::DeviceSelect::Unique(nullptr, tb2, d_keys2, d_keys, d_nsel, (int)ix->T);
-    size_t tb = std::max(tb1, tb2);
-    NP_HIP(hipMalloc(&d_temp, std::max<size_t>(tb, 16)));
-    NP_HIP(hipcub::DeviceRadixSort::SortKeys(d_temp, tb1, d_keys, d_keys2, (int)ix->T, 0, 32 + kbits));
-    NP_HIP(hipcub::DeviceSelect::Unique(d_temp, tb2, d_keys2, d_keys, d_nsel, (int)ix->T));
-    NP_HIP(hipDeviceSynchronize());
-    // d_nsel was declared int64 for alignment; hipcub wrote a 64-bit? it writes NumSelectedT = *d_nsel type
-    NP_HIP(hipMemcpy(&n_unique, d_nsel, sizeof(int64_t), hipMemcpyDeviceToHost));
-  }
-  ix->ivf_size = n_unique;
-  NP_TRY(dev_alloc(&ix->d_ivf, (size_t)n_unique, &ix->device_bytes));
-  if (n_unique > 0)
-    ivf_from_unique_kernel<<<(unsigned)((n_unique + 255) / 256), 256>>>(d_keys, n_unique, ix->d_ivf, d_lens32);
-  std::vector<unsigned int> lens((size_t)ix->K);
-  NP_HIP(hipMemcpy(lens.data(), d_lens32, (size_t)ix->K * 4, hipMemcpyDeviceToHost));
-  std::vector<int64_t> ioff((size_t)ix->K + 1, 0);
-  for (int64_t c = 0; c < ix->K; ++c) ioff[c + 1] = ioff[c] + lens[c];
-  NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
-  NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
   NP_HIP(hipDeviceSynchronize());
 
   // whole-corpus token count: exact when unsharded or fixed-length, else extrapolated
@@ -648,7 +776,7 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     ix->n_emb_total = ix->n_docs > 0 ? (int64_t)((double)ix->T / (double)ix->n_docs * (double)s->num_docs) : 0;
   ix->avg_doclen = s->num_docs > 0 ? (double)ix->n_emb_total / (double)s->num_docs : 0.0;
   NP_TRY(build_unique_codes(ix));
-  NP_TRY(build_inv_norm(ix));
+  NP_TRY(build_ivf_from_ucodes(ix));   // index.rs:479-499
   NP_TRY(build_inv_norm(ix));
   cleanup.p = nullptr;
   *out = ix;
@@ -752,6 +880,29 @@ int np_hip_index_synth(const np_synth_spec* spec, const np_open_opts* opts, np_i
 }
 
 int64_t np_hip_index_ivf_size(const np_index* index) { return index ? index->ivf_size : 0; }
+
+int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
+  clear_error();
+  if (!ix || !name) {
+    set_error("np_hip_index_tune: NULL argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  Tuning& t = ix->tune;
+  const std::string n(name);
+  if (n == "s4_mode") t.s4_mode = std::min(std::max(value, 0), 8);
+  else if (n == "s4_minb") t.s4_minb = std::max(value, 1);
+  else if (n == "s4_nbx") t.s4_nbx = std::min(std::max(value, 8), 512);
+  else if (n == "s4_swz") t.s4_swz = value != 0;
+  else if (n == "s4_filter") t.s4_filter = value != 0;
+  else if (n == "s6_xcd") t.s6_xcd = value != 0;
+  else if (n == "gemm_cpw") t.gemm_cpw = value == 2 ? 2 : 1;
+  else if (n == "exact_rowmax") t.exact_rowmax = value != 0;
+  else {
+    set_error("np_hip_index_tune: unknown knob '%s'", name);
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  return NP_OK;
+}
 
 int np_hip_index_export(const np_index* ix, int64_t* doc_lengths, int64_t* codes, uint8_t* residuals, int64_t* ivf,
                         int32_t* ivf_lengths) {

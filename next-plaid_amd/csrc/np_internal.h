@@ -96,6 +96,20 @@ struct Context {
   uint64_t last_use = 0;   // acquisition stamp: idle contexts are handed out least-recently-used first
 };
 
+// Kernel-selection knobs.  Read from the environment ONCE, at index open (NP_S4_MODE, NP_S4_MINB, NP_S4_NBX,
+// NP_S4_SWZ, NP_S4_FILTER, NP_S6_XCD, NP_GEMM_CPW, NP_EXACT_ROWMAX); np_hip_index_tune() changes them on a live handle
+// for sweep tools and the kernel-variant parity tests.  Every setting produces identical results.
+struct Tuning {
+  int s4_mode = 2;       // 0 approx_kernel; 1..4 approx_xcd_kernel with 8/4/2/1 phases; 5..8 approx_stream_kernel
+  int s4_minb = 8;       // smallest batch that takes the per-XCD kernels
+  int s4_nbx = 128;      // workgroups per XCD
+  int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
+  int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
+  int s6_xcd = 1;        // one XCD per query in S6
+  int gemm_cpw = 1;      // centroid fragments per wave in S1
+  int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
+};
+
 struct DeviceIndex {
   int device = 0;
   int64_t N_total = 0, n_emb_total = 0;
@@ -120,6 +134,7 @@ struct DeviceIndex {
   int64_t ivf_size = 0;
   size_t device_bytes = 0;
   np_open_opts opts{};
+  Tuning tune;
   // context pool
   mutable std::mutex mu;
   mutable std::condition_variable cv;
@@ -131,6 +146,7 @@ struct DeviceIndex {
 int build_device_index(const HostIndex& h, const np_open_opts* opts, DeviceIndex** out);
 void destroy_device_index(DeviceIndex* ix);
 int normalise_opts(const np_open_opts* in, np_open_opts* out);
+void read_tuning_env(Tuning* t);
 void shard_range(int64_t n_total, int rank, int count, int64_t* b, int64_t* e);
 
 // np_search.hip

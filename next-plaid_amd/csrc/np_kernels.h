@@ -45,6 +45,8 @@ __device__ __forceinline__ int mfma_row(int r, int kk) { return (r & 3) + 8 * (r
 
 struct Counters {  // per-call work counters (np_stats)
   unsigned long long n_cells, n_ivf_ids, n_candidates, n_cand_tokens, n_exact_docs, n_exact_tokens, n_cand_codes;
+  unsigned long long n_rounds;     // candidate-pool rounds the slice needed (max over slices)
+  unsigned long long n_survivors;  // candidates that passed the S4 upper-bound filter (= n_candidates when it is off)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -363,16 +365,31 @@ __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
           uint32_t tau, rem;
           wave_select_mark(nslots, n_probe, keys, tau, rem);
           if (lane == 0) tauq[tq] = tau ? tau - 1u : 0u;
-          uint32_t taken = 0;  // ties at the cut (unspecified in the reference): first `rem` in slot order
+          // ties at the cut: select_nth_unstable leaves them unspecified (search.rs:405-409); the batched path's
+          // heaps keep the LOWEST centroid ids (entries are (Reverse(score), id), search.rs:164-199), so both
+          // paths take the `rem` smallest ids among the equal scores
+          uint32_t neq = 0;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) neq += (uint32_t)__popcll(__ballot(j < nslots && keys[j] == tau && tau != 0));
 #pragma unroll
           for (int j = 0; j < 32; ++j) {
             if (j < nslots) {
               const bool gt = keys[j] > tau && keys[j] != 0;
               const bool eq = keys[j] == tau && tau != 0;
-              const unsigned long long bal = __ballot(eq);
-              const uint32_t before = taken + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-              if (gt || (eq && before < rem)) atomicOr(&bits[cids[j] >> 5], 1u << (cids[j] & 31));
-              taken += (uint32_t)__popcll(bal);
+              if (gt || (eq && neq <= rem)) atomicOr(&bits[cids[j] >> 5], 1u << (cids[j] & 31));
+            }
+          }
+          if (neq > rem) {
+            uint32_t last = 0;
+            for (uint32_t r = 0; r < rem; ++r) {
+              uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+              for (int j = 0; j < 32; ++j)
+                if (j < nslots && keys[j] == tau && tau != 0 && (r == 0 || cids[j] > last)) m = min(m, cids[j]);
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+              if (lane == 0) atomicOr(&bits[m >> 5], 1u << (m & 31));
+              last = m;
             }
           }
         } else {
@@ -408,21 +425,33 @@ __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
           const uint32_t gt = count_ge(prefix, true);
           const uint32_t rem = n_probe > gt ? n_probe - gt : 0u;
           if (lane == 0) tauq[tq] = prefix ? prefix - 1u : 0u;
-          uint32_t taken = 0;
+          uint32_t taken = 0;   // ties before this block of 64 groups; inside it they rank by (group, member) = ascending id
           for (int64_t g0 = 0; g0 < G; g0 += 64) {
             const int64_t g = g0 + lane;
             const bool gv = g < G && gm[g * LQP + tq] >= taug;
             const uint32_t em = gv ? (p.elig ? p.elig[g] : 0xFFFFFFFFu) : 0u;
+            uint32_t eqm = 0, gtm = 0;
             for (int i = 0; i < 32; ++i) {
               const int64_t c = g * 32 + i;
               const bool ok = gv && c < p.K && ((em >> i) & 1u);
               const uint32_t k1 = ok ? okey(col[c * LQP]) + 1u : 0u;
-              const bool eq = ok && k1 == prefix && prefix != 0;
-              const unsigned long long bal = __ballot(eq);
-              const uint32_t before = taken + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-              if (ok && (k1 > prefix || (eq && before < rem))) atomicOr(&bits[c >> 5], 1u << (c & 31));
-              taken += (uint32_t)__popcll(bal);
+              if (ok && k1 > prefix) gtm |= 1u << i;
+              if (ok && k1 == prefix && prefix != 0) eqm |= 1u << i;
             }
+            uint32_t incl = (uint32_t)__popc(eqm);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+              if (lane >= o) incl += v;
+            }
+            uint32_t rank = taken + incl - (uint32_t)__popc(eqm);
+            uint32_t take = gtm;
+            for (uint32_t m = eqm; m; m &= m - 1) {
+              if (rank < rem) take |= m & (0u - m);
+              ++rank;
+            }
+            if (take) atomicOr(&bits[g], take);
+            taken += (uint32_t)__shfl((int)incl, 63);
           }
         }
       }
@@ -654,16 +683,68 @@ __global__ void __launch_bounds__(256) count_chunks_kernel(const uint32_t* __res
   if (threadIdx.x == 0) chunk_counts[(int64_t)b * nchunks + ch] = s_cnt;
 }
 
+// Candidate pool.  The candidate arrays (doc id, 16-B meta record, approximate score) are ONE pool of P entries per
+// workspace instead of B x n_docs strides: query b's candidates occupy [cand_base[b], cand_base[b] + n_cand[b]).
+// A batch whose candidates do not fit the pool together is processed in ROUNDS: plan_rounds_kernel packs the
+// queries first-fit in order (a query never exceeds n_docs <= P entries), S3-compaction / S4 / S5 then run once
+// per round on the queries of that round (round_of[b]); the host enqueues the worst-case number of rounds and the
+// kernels of a round nobody was assigned to exit at once.
+struct RoundPlan {
+  int32_t* n_cand;      // [B]
+  int64_t* cand_base;   // [B] first pool entry of query b (inside its round)
+  int32_t* round_of;    // [B]
+  int32_t* round_tab;   // [2 * max_rounds]: first query, one-past-last query of each round; [2*max_rounds] = n_rounds
+};
+
+__global__ void __launch_bounds__(256) plan_rounds_kernel(const int32_t* __restrict__ chunk_counts, int nchunks, int B,
+                                                          int64_t pool, int max_rounds, RoundPlan rp, Counters* ctr) {
+  __shared__ int s_n[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = wave; b < B; b += 4) {
+    int c = 0;
+    for (int j = lane; j < nchunks; j += 64) c += chunk_counts[(int64_t)b * nchunks + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) s_n[b] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int64_t cur = 0;
+    unsigned long long total = 0;
+    int r = 0;
+    for (int i = 0; i < 2 * max_rounds; ++i) rp.round_tab[i] = 0;
+    rp.round_tab[0] = 0;
+    for (int b = 0; b < B; ++b) {
+      const int n = s_n[b];
+      if (cur + n > pool && r + 1 < max_rounds) {   // close the round (the host's max_rounds bound is never hit)
+        rp.round_tab[2 * r + 1] = b;
+        ++r;
+        rp.round_tab[2 * r] = b;
+        cur = 0;
+      }
+      rp.n_cand[b] = (cur + n > pool) ? (int)max((int64_t)0, pool - cur) : n;
+      rp.cand_base[b] = cur;
+      rp.round_of[b] = r;
+      cur += rp.n_cand[b];
+      total += (unsigned long long)rp.n_cand[b];
+    }
+    rp.round_tab[2 * r + 1] = B;
+    rp.round_tab[2 * max_rounds] = r + 1;
+    atomicAdd(&ctr->n_candidates, total);
+    atomicMax(&ctr->n_rounds, (unsigned long long)(r + 1));
+  }
+}
+
 // writes ascending doc ids; thread t owns words [4t, 4t+4) of the chunk so the order is preserved
 __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict__ docbits, int64_t NW, int nchunks,
                                                       const int32_t* __restrict__ chunk_counts,
-                                                      uint32_t* __restrict__ cand, int64_t cand_stride,
+                                                      uint32_t* __restrict__ cand, RoundPlan rp, int round,
                                                       const int64_t* __restrict__ doc_off,
-                                                      const int32_t* __restrict__ ulen, uint4* __restrict__ cand_meta,
-                                                      int32_t* __restrict__ n_cand, Counters* ctr) {
+                                                      const int32_t* __restrict__ ulen, uint4* __restrict__ cand_meta) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (rp.round_of[b] != round) return;
   const int32_t* cc = chunk_counts + (int64_t)b * nchunks;
   {
     int part = 0;
@@ -698,8 +779,9 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
   int woff = 0;
   for (int k = 0; k < wave; ++k) woff += s_wave[k];
   int pos = base + woff + incl - cnt;
-  uint32_t* out = cand + (int64_t)b * cand_stride;
-  uint4* outm = cand_meta + (int64_t)b * cand_stride;
+  const int limit = rp.n_cand[b];
+  uint32_t* out = cand + rp.cand_base[b];
+  uint4* outm = cand_meta + rp.cand_base[b];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     uint32_t m = w[k];
@@ -709,25 +791,12 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
       const uint32_t d = (uint32_t)((w0 + k) * 32 + bit);
       const int64_t o = doc_off[d];
       const uint32_t dl = (uint32_t)(doc_off[d + 1] - o);   // w = offset bits 32..39 | doc length << 8
-      outm[pos] = make_uint4(d, (uint32_t)ulen[d], (uint32_t)(o & 0xFFFFFFFFll), (uint32_t)((o >> 32) & 0xFF) | (dl << 8));
-      out[pos++] = d;
+      if (pos < limit) {
+        outm[pos] = make_uint4(d, (uint32_t)ulen[d], (uint32_t)(o & 0xFFFFFFFFll), (uint32_t)((o >> 32) & 0xFF) | (dl << 8));
+        out[pos] = d;
+      }
+      ++pos;
     }
-  }
-  if (ch == nchunks - 1 && tid == 255) {
-    const int total = base + woff + incl;
-    n_cand[b] = total;
-    atomicAdd(&ctr->n_candidates, (unsigned long long)total);
-  }
-}
-
-__global__ void cand_prefix_kernel(const int32_t* __restrict__ n_cand, int B, int64_t* __restrict__ prefix) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int64_t s = 0;
-    for (int b = 0; b < B; ++b) {
-      prefix[b] = s;
-      s += n_cand[b];
-    }
-    prefix[B] = s;
   }
 }
 
@@ -817,8 +886,8 @@ __device__ __forceinline__ void s4_chunk(const char* __restrict__ Tb, uint32_t r
 template <int LPR>        // lanes per QCT row: 4*LPR >= LQP, power of two in {8,16,32,64}
 __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
                                                      const int32_t* __restrict__ qoff,
-                                                     const uint4* __restrict__ cand_meta, int64_t cand_stride,
-                                                     const int64_t* __restrict__ prefix, int B,
+                                                     const uint4* __restrict__ cand_meta, const int32_t* __restrict__ n_cand,
+                                                     RoundPlan rp, int round, int max_rounds,
                                                      const uint32_t* __restrict__ codes, float* __restrict__ approx,
                                                      Counters* ctr) {
   constexpr int RPI = 64 / LPR;            // rows (codes) per gather instruction
@@ -829,8 +898,15 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
   __shared__ float s_rows[4][DPF * RW];    // per wave: combined per-token maxima of the last DPF documents
   __shared__ int64_t s_out[4][DPF];        // their output positions
   __shared__ int s_olq[4][DPF];            // and query lengths
-  for (int k = threadIdx.x; k <= B; k += 256) s_prefix[k] = prefix[k];
-  for (int k = threadIdx.x; k < B; k += 256) s_lq[k] = qoff[k + 1] - qoff[k];
+  // queries [rb, re) of this round; their pool positions are a running prefix (cand_base), so candidate w of the
+  // round IS pool entry w
+  if (round >= rp.round_tab[2 * max_rounds]) return;
+  const int rb = rp.round_tab[2 * round], B = rp.round_tab[2 * round + 1] - rb;
+  for (int k = threadIdx.x; k < B; k += 256) {
+    s_prefix[k] = rp.cand_base[rb + k];
+    s_lq[k] = qoff[rb + k + 1] - qoff[rb + k];
+  }
+  if (threadIdx.x == 0) s_prefix[B] = B > 0 ? rp.cand_base[rb + B - 1] + n_cand[rb + B - 1] : 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jq = lane & (LPR - 1), grp = lane / LPR;   // this lane holds q = 4*jq .. 4*jq+3 of row `grp`
@@ -873,28 +949,27 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
   };
   if (w0 < total) {
     locate(w0, b1, i1);
-    m1 = cand_meta[(int64_t)b1 * cand_stride + i1];
+    m1 = cand_meta[w0];
   }
   if (w0 + nw < total) {
     locate(w0 + nw, b2, i2);
-    m2 = cand_meta[(int64_t)b2 * cand_stride + i2];
+    m2 = cand_meta[w0 + nw];
   }
   if (w0 < total) fetch_codes(m1);
   int nbuf = 0;
   for (int64_t w = w0; w < total; w += nw) {
     const uint4 m0 = m1;
     const int b0 = b1;
-    const int64_t i0 = i1;
     const uint32_t creg0 = c1, creg1 = c1b;
     m1 = m2; b1 = b2; i1 = i2;
     if (w + 2 * nw < total) {
       locate(w + 2 * nw, b2, i2);
-      m2 = cand_meta[(int64_t)b2 * cand_stride + i2];
+      m2 = cand_meta[w + 2 * nw];
     }
     if (w + nw < total) fetch_codes(m1);
     const int64_t off = (int64_t)m0.z | ((int64_t)(m0.w & 0xFF) << 32);
     const int len = (int)m0.y;
-    const char* Tb = reinterpret_cast<const char*>(QCT + (int64_t)b0 * KP * LQP);
+    const char* Tb = reinterpret_cast<const char*>(QCT + (int64_t)(rb + b0) * KP * LQP);
     toks += (unsigned long long)(m0.w >> 8);
     ucodes += (unsigned long long)len;
     float mx = NP_NEG_INF, my = NP_NEG_INF, mz = NP_NEG_INF, mw = NP_NEG_INF;
@@ -930,7 +1005,7 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
       r[0] = mx; r[1] = my; r[2] = mz; r[3] = mw;
     }
     if (lane == 0) {
-      s_out[wave][nbuf] = (int64_t)b0 * cand_stride + i0;
+      s_out[wave][nbuf] = w;
       s_olq[wave][nbuf] = s_lq[b0];
     }
     if (++nbuf == DPF) {
@@ -965,8 +1040,9 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
 template <int LPR, bool SWZ>
 __global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
                                                          const int32_t* __restrict__ qoff,
-                                                         const uint4* __restrict__ cand_meta, int64_t cand_stride,
-                                                         const int32_t* __restrict__ n_cand, int B,
+                                                         const uint4* __restrict__ cand_meta,
+                                                         const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
+                                                         int max_rounds,
                                                          const uint32_t* __restrict__ codes, int64_t T,
                                                          const uint4* __restrict__ useg, float* __restrict__ approx,
                                                          int pshift, Counters* ctr) {
@@ -988,11 +1064,14 @@ __global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict
   const int lbase = grp * LPR;
   unsigned long long toks = 0, ucnt = 0;
 
-  for (int b = x; b < B; b += 8) {
+  if (round >= rp.round_tab[2 * max_rounds]) return;
+  const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
+  for (int b = rb + x; b < re; b += 8) {
     const int64_t n = n_cand[b];
     const char* Tb = reinterpret_cast<const char*>(QCT + (int64_t)b * KP * LQP);
     const int lq = qoff[b + 1] - qoff[b];
-    const uint4* metab = cand_meta + (int64_t)b * cand_stride;
+    const int64_t pbase = rp.cand_base[b];
+    const uint4* metab = cand_meta + pbase;
     for (int64_t tile0 = 0; tile0 < n; tile0 += NG * NP_S4X_MAXD) {
       const int d = (int)min((int64_t)NP_S4X_MAXD, (n - tile0 + NG - 1) / NG);
       __syncthreads();   // previous tile's LDS slots are free
@@ -1108,7 +1187,7 @@ __global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict
           if (4 * jj + 2 < lq && a2 > NP_NEG_INF) score += a2;
           if (4 * jj + 3 < lq && a3 > NP_NEG_INF) score += a3;
         }
-        if (jq == 0 && i < n) approx[(int64_t)b * cand_stride + i] = s_end[k][g][7] ? score : 0.f;
+        if (jq == 0 && i < n) approx[pbase + i] = s_end[k][g][7] ? score : 0.f;
       }
     }
   }
@@ -1141,8 +1220,9 @@ __global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict
 template <int LPR>
 __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __restrict__ QCT, int64_t KP, int LQP,
                                                             const int32_t* __restrict__ qoff,
-                                                            const uint4* __restrict__ cand_meta, int64_t cand_stride,
-                                                            const int32_t* __restrict__ n_cand, int B,
+                                                            const uint4* __restrict__ cand_meta,
+                                                            const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
+                                                            int max_rounds,
                                                             const uint32_t* __restrict__ codes, int64_t T,
                                                             const uint4* __restrict__ useg, float* __restrict__ approx,
                                                             int pshift, uint32_t slice_w, Counters* ctr) {
@@ -1169,11 +1249,14 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
   const int lbase = grp * LPR;
   unsigned long long toks = 0, ucnt = 0;
 
-  for (int b = x; b < B; b += 8) {
+  if (round >= rp.round_tab[2 * max_rounds]) return;
+  const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
+  for (int b = rb + x; b < re; b += 8) {
     const int64_t n = n_cand[b];
     const char* Tb = reinterpret_cast<const char*>(QCT + (int64_t)b * KP * LQP);
     const int lq = qoff[b + 1] - qoff[b];
-    const uint4* metab = cand_meta + (int64_t)b * cand_stride;
+    const int64_t pbase = rp.cand_base[b];
+    const uint4* metab = cand_meta + pbase;
     for (int64_t tile0 = 0; tile0 < n; tile0 += NG * NP_S4S_MAXD) {
       const int d = (int)min((int64_t)NP_S4S_MAXD, (n - tile0 + NG - 1) / NG);
       __syncthreads();   // previous tile's LDS slots are free
@@ -1313,7 +1396,7 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
           if (4 * jj + 2 < lq && a2 > NP_NEG_INF) score += a2;
           if (4 * jj + 3 < lq && a3 > NP_NEG_INF) score += a3;
         }
-        if (jq == 0 && i < n) approx[(int64_t)b * cand_stride + i] = s_end[k][g][7] ? score : 0.f;
+        if (jq == 0 && i < n) approx[pbase + i] = s_end[k][g][7] ? score : 0.f;
       }
     }
   }
@@ -1356,9 +1439,11 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n, int tid, i
 // key64 = okey(approx) << 32 | (0xFFFFFFFF - global_doc_id)
 // ---------------------------------------------------------------------------------------------
 struct SelectP {
-  const float* approx;
-  const uint32_t* cand;
-  int64_t cand_stride;
+  const float* approx;      // [pool]
+  const uint32_t* cand;     // [pool] shard-local doc ids
+  int cand_step;            // u32 words between consecutive doc ids (1 = id array, 4 = the x field of 16-B records)
+  RoundPlan rp;
+  int round;
   const int32_t* n_cand;
   int64_t doc_begin;
   int n_sel;    // min(n_full_scores, max(n_full_scores/4, top_k))
@@ -1374,9 +1459,11 @@ __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
   __shared__ uint32_t s_prefix, s_rem, s_ngt, s_eqbase;
   __shared__ uint32_t s_wtot[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.rp.round_of[b] != p.round) return;
   const int n = p.n_cand[b];
-  const float* ap = p.approx + (int64_t)b * p.cand_stride;
-  const uint32_t* cd = p.cand + (int64_t)b * p.cand_stride;
+  const float* ap = p.approx + p.rp.cand_base[b];
+  const uint32_t* cd = p.cand + p.rp.cand_base[b] * p.cand_step;
+  const int cstep = p.cand_step;
   const int nsel = min(p.n_sel, n);
   for (int i = tid; i < p.NSELP; i += 1024) s_sel[i] = 0;
   if (tid == 0) { s_ngt = 0; s_eqbase = 0; }
@@ -1384,7 +1471,7 @@ __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
   if (nsel > 0) {
     if (n <= nsel) {
       for (int i = tid; i < n; i += 1024)
-        s_sel[i] = ((uint64_t)okey(ap[i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + cd[i]));
+        s_sel[i] = ((uint64_t)okey(ap[i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + cd[(int64_t)i * cstep]));
     } else {
       if (tid == 0) { s_prefix = 0; s_rem = (uint32_t)nsel; }
       __syncthreads();
@@ -1426,7 +1513,7 @@ __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
         for (int k = 0; k < wave; ++k) before += s_wtot[k];
         const uint32_t rank = before + wrank;
         const uint64_t comp =
-            ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + (in ? cd[i] : 0u)));
+            ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + (in ? cd[(int64_t)i * cstep] : 0u)));
         if (gt) s_sel[atomicAdd(&s_ngt, 1u)] = comp;
         if (eq && rank < rem) s_sel[ngt_total + rank] = comp;
         __syncthreads();

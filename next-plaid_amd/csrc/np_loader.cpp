@@ -2,7 +2,7 @@
 //
 // Replaces the file-parsing half of MmapIndex::load (next-plaid/src/index.rs:1026-1139):
 //   metadata.json                      index.rs:104-155   (num_documents inferred from doclens if 0)
-//   centroids.npy, bucket_weights.npy  codec.rs:548-612
+//   centroids.npy, bucket_weights.npy  codec.rs:548-612 ('<f4'; fast-plaid's '<f2' is widened, mmap.rs:1757-1778)
 //   ivf.npy (<i8), ivf_lengths.npy (<i4; fast-plaid writes <i8, mmap.rs:1780-1789)
 //   doclens.{i}.json, {i}.codes.npy (<i8), {i}.residuals.npy (|u1 or <u1, mmap.rs:1791-1808)
 // NPY v1.0 / v2.0 headers as parsed by mmap.rs:659-749.  The merged_*.npy caches are NOT used:
@@ -19,6 +19,8 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+#include <algorithm>
 
 namespace np {
 
@@ -198,6 +200,70 @@ static int open_npy(const std::string& path, HostIndex* hi, Npy* out, const char
   return NP_OK;
 }
 
+// IEEE half -> float (what the reference's convert_f16_to_f32_npy does with half::f16::to_f32, mmap.rs:1760-1778)
+static float half_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else {  // subnormal: renormalise
+      int e = -1;
+      do {
+        ++e;
+        man <<= 1;
+      } while (!(man & 0x400u));
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7F800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+// f32 array that fast-plaid may have written as '<f2' (mmap.rs:1757-1778 converts those files to '<f4' on load;
+// here the widened copy lives in an owned buffer and the file is left untouched).
+static int open_npy_f32(const std::string& path, HostIndex* hi, Npy* out, size_t want_ndim, const float** data) {
+  const uint8_t* m;
+  size_t len;
+  NP_TRY(map_file(path, hi, &m, &len, NP_ERR_INDEX_LOAD));
+  NP_TRY(parse_npy(path, m, len, out));
+  if (out->fortran && out->shape.size() > 1) {
+    set_error("fortran_order NPY not supported: %s", path.c_str());
+    return NP_ERR_INDEX_LOAD;
+  }
+  const int es = elem_size(out->descr);
+  if (out->descr.size() < 3 || out->descr[1] != 'f' || (es != 4 && es != 2) || out->descr[0] == '>') {
+    set_error("Unexpected dtype '%s' in %s", out->descr.c_str(), path.c_str());
+    return NP_ERR_INDEX_LOAD;
+  }
+  if (out->shape.size() != want_ndim) {
+    set_error("Unexpected rank %zu in %s", out->shape.size(), path.c_str());
+    return NP_ERR_SHAPE;
+  }
+  if ((size_t)out->count() * (size_t)es > out->data_bytes) {
+    set_error("NPY file size too small for %lld elements: %s", (long long)out->count(), path.c_str());
+    return NP_ERR_INDEX_LOAD;
+  }
+  if (es == 4) {
+    *data = (const float*)out->data;
+    return NP_OK;
+  }
+  hi->owned.emplace_back((size_t)std::max<int64_t>(out->count(), 1) * 4);
+  float* o = (float*)hi->owned.back().data();
+  for (int64_t i = 0; i < out->count(); ++i) {
+    uint16_t h;
+    memcpy(&h, out->data + 2 * i, 2);
+    o[i] = half_to_float(h);
+  }
+  *data = o;
+  return NP_OK;
+}
+
 // ---- JSON (only what metadata.json / doclens.N.json need) ---------------------------------------
 static bool json_number(const std::string& j, const char* key, double* out) {
   std::string k = std::string("\"") + key + "\"";
@@ -274,10 +340,9 @@ int load_index_dir(const char* dir, HostIndex* hi) {
   hi->avg_doclen = json_number(meta, "avg_doclen", &v) ? v : 0.0;
 
   Npy cen, bw, ivf, ivl;
-  NP_TRY(open_npy(base + "centroids.npy", hi, &cen, "f", 4, 2));
+  NP_TRY(open_npy_f32(base + "centroids.npy", hi, &cen, 2, &hi->centroids));
   hi->K = cen.shape[0];
   hi->dim = (int32_t)cen.shape[1];
-  hi->centroids = (const float*)cen.data;
   {
     struct stat st;
     if (stat((base + "bucket_weights.npy").c_str(), &st) != 0) {  // codec.rs:428-431
@@ -285,12 +350,11 @@ int load_index_dir(const char* dir, HostIndex* hi) {
       return NP_ERR_CODEC;
     }
   }
-  NP_TRY(open_npy(base + "bucket_weights.npy", hi, &bw, "f", 4, 1));
+  NP_TRY(open_npy_f32(base + "bucket_weights.npy", hi, &bw, 1, &hi->bucket_weights));
   if (bw.shape[0] != (1 << hi->nbits)) {
     set_error("Codec error: bucket_weights has %lld entries, expected %d", (long long)bw.shape[0], 1 << hi->nbits);
     return NP_ERR_CODEC;
   }
-  hi->bucket_weights = (const float*)bw.data;
   NP_TRY(open_npy(base + "ivf.npy", hi, &ivf, "i", 8, 1));
   hi->ivf = (const int64_t*)ivf.data;
   hi->ivf_size = ivf.shape[0];

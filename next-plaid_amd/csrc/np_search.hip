@@ -13,23 +13,19 @@
 
 namespace np {
 
-static inline int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
-
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
-      prefix, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset, subset_bits,
-      elig, misc, cut;
+      cand_base, round_of, round_tab, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
+      subset_bits, elig, misc, cut;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
   bool done_valid = false;
   void release_all() {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &prefix, &sel_keys, &sel_doc, &nsel, &exact, &out_ids,
-                     &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc, &cut};
+                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &sel_keys, &sel_doc,
+                     &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
+                     &cut};
     for (DevBuf* b : all) b->release();
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
@@ -118,6 +114,7 @@ struct CallState {
   np_search_params prm{};
   bool empty_subset = false;
   bool timed = false;
+  bool trace = false;   // debug_trace: every candidate keeps its exact approximate score
 };
 
 static int next_pow2(int v) {
@@ -170,10 +167,48 @@ static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_sear
   return NP_OK;
 }
 
-static int64_t per_query_bytes(const DeviceIndex* ix, int LQP) {
-  const int64_t NW = (ix->n_docs + 31) / 32;
-  return ix->KP * LQP * 4 + (ix->KP / 32) * LQP * 4 + ix->KP * 9 + NW * 4 + std::max<int64_t>(ix->n_docs, 1) * 8 +
-         (int64_t)ix->dim * LQP * 6 + 65536;
+// ---- workspace plan: one expression set for slicing AND for the reserve() calls ---------------------------------
+// Per-query scratch that scales with the batch (score table, probe bitmaps, doc bitmap, selection) and the
+// candidate pool (NP_POOL_ENTRY bytes per entry: doc id + 16-B record + approximate score), which is sized by the
+// budget, not by n_docs: B x n_docs entries only when that fits workspace_bytes, otherwise what is left of the
+// budget after the per-query scratch (never less than 2 x n_docs entries, one query's worst case twice).
+#define NP_POOL_ENTRY 24
+struct WsPlan {
+  int S = 1;            // queries per slice
+  int64_t pool = 1;     // candidate-pool entries
+  int max_rounds = 1;   // rounds the host enqueues for one slice (worst case; extra rounds exit immediately)
+};
+
+static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int top_k) {
+  const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
+  const int64_t nchunks = (NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS;
+  return KP * LQP * 4                      // QCT
+         + G * LQP * 4 + G * 4             // gmax, cellbits
+         + KP * 8                          // cells_tmp, cells
+         + (int64_t)LQP * 4                // tauq
+         + std::max<int64_t>(NW, 1) * 4    // docbits
+         + std::max<int64_t>(nchunks, 1) * 4
+         + (int64_t)ix->dim * LQP * 8      // Qt, Qb, Qbl
+         + (int64_t)std::max(n_sel, 1) * 16 + (int64_t)std::max(top_k, 1) * 20 + 64;
+}
+
+static WsPlan plan_workspace(const DeviceIndex* ix, int B, int LQP, const np_search_params* prm) {
+  WsPlan w;
+  const int64_t budget = ix->opts.workspace_bytes;
+  const int64_t pq = std::max<int64_t>(per_query_bytes(ix, LQP, n_sel_of(prm), prm->top_k), 1);
+  const int64_t nd = std::max<int64_t>(ix->n_docs, 1);
+  const int cap = (int)std::min<int64_t>(std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB), std::max(B, 1));
+  int64_t S = std::min<int64_t>(cap, std::max<int64_t>(1, (budget * 3 / 4) / pq));   // keep >= 1/4 of the budget for the pool
+  // if every query's worst case fits next to the scratch, take it (no rounds at all)
+  while (S > 1 && S * pq + 2 * nd * NP_POOL_ENTRY > budget) --S;
+  w.S = (int)S;
+  const int64_t worst = S * nd;
+  int64_t pool = (budget - S * pq) / NP_POOL_ENTRY;
+  pool = std::min(worst, std::max(pool, std::min<int64_t>(2, S) * nd));
+  w.pool = std::max<int64_t>(pool, 1);
+  // first-fit packing in query order: every closed round holds more than pool - n_docs entries
+  w.max_rounds = (worst <= w.pool) ? 1 : (int)std::min<int64_t>(S, worst / (w.pool - nd + 1) + 1);
+  return w;
 }
 
 template <int DIM>
@@ -181,8 +216,7 @@ static void launch_gemm(hipStream_t st, const DeviceIndex* ix, const float* Qt, 
                         uint32_t* gmax) {
   // one 32-centroid fragment per wave: 128 centroids per block, ~2 blocks per CU co-resident, so one wave's
   // epilogue (stores, key maxima) hides under another wave's MFMAs.  KP is a multiple of 64.
-  static const int cpw = getenv("NP_GEMM_CPW") ? atoi(getenv("NP_GEMM_CPW")) : 1;
-  if (cpw == 2) {
+  if (ix->tune.gemm_cpw == 2) {
     const unsigned blocks = (unsigned)((ix->KP / 64 + 3) / 4);
     qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax);
   } else {
@@ -192,7 +226,7 @@ static void launch_gemm(hipStream_t st, const DeviceIndex* ix, const float* Qt, 
 }
 
 template <int DIM, int NBITS, int NQT>
-static int launch_exact(hipStream_t st, const ExactP& p, int B, int precision) {
+static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, int B, int precision) {
   const unsigned gx = (unsigned)((p.n_sel + 4 * NP_EXACT_DPW - 1) / (4 * NP_EXACT_DPW));
   if (gx == 0 || B == 0) return NP_OK;
   if (precision == 0) {
@@ -204,11 +238,10 @@ static int launch_exact(hipStream_t st, const ExactP& p, int B, int precision) {
   } else if (precision == 1 || precision == 2) {
     // Lq <= 64: transposed form (4 float4 QC loads per tile, no per-row shuffles); longer queries keep the
     // row-max form, whose running maxima need one register per query tile instead of sixteen
-    static const bool rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
-    if (NQT <= 2 && !rowmax) {
+    if (NQT <= 2 && !ix->tune.exact_rowmax) {
       ExactP px = p;
       dim3 grid(gx, B);
-      if (B >= 8 && env_int("NP_S6_XCD", 1)) {   // one XCD per query (see exact_qct_kernel)
+      if (B >= 8 && ix->tune.s6_xcd) {   // one XCD per query (see exact_qct_kernel)
         px.xcd_B = B;
         px.gx = (int)gx;
         grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
@@ -226,16 +259,63 @@ static int launch_exact(hipStream_t st, const ExactP& p, int B, int precision) {
 }
 
 template <int DIM, int NBITS>
-static int launch_exact_qt(hipStream_t st, const ExactP& p, int B, int precision) {
-  if (p.LQP <= 32) return launch_exact<DIM, NBITS, 1>(st, p, B, precision);
-  if (p.LQP <= 64) return launch_exact<DIM, NBITS, 2>(st, p, B, precision);
-  return launch_exact<DIM, NBITS, NP_MAX_QT>(st, p, B, precision);
+static int launch_exact_qt(hipStream_t st, const DeviceIndex* ix, const ExactP& p, int B, int precision) {
+  if (p.LQP <= 32) return launch_exact<DIM, NBITS, 1>(st, ix, p, B, precision);
+  if (p.LQP <= 64) return launch_exact<DIM, NBITS, 2>(st, ix, p, B, precision);
+  return launch_exact<DIM, NBITS, NP_MAX_QT>(st, ix, p, B, precision);
 }
 
 template <int DIM>
-static int launch_exact_nb(hipStream_t st, const ExactP& p, int B, int precision, int nbits) {
-  if (nbits == 2) return launch_exact_qt<DIM, 2>(st, p, B, precision);
-  return launch_exact_qt<DIM, 4>(st, p, B, precision);
+static int launch_exact_nb(hipStream_t st, const DeviceIndex* ix, const ExactP& p, int B, int precision, int nbits) {
+  if (nbits == 2) return launch_exact_qt<DIM, 2>(st, ix, p, B, precision);
+  return launch_exact_qt<DIM, 4>(st, ix, p, B, precision);
+}
+
+// S4 for the queries of one round: exact f32 approximate scores of `n[b]` records at meta[cand_base[b]...]
+static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, const int32_t* d_qoff, int B, int LQP,
+                          const uint4* meta, const int32_t* n, const RoundPlan& rp, int round, int max_rounds) {
+  const Tuning& t = ix->tune;
+  const int64_t KP = ix->KP;
+  // s4_mode: 0 = all XCDs walk one query (approx_kernel), 1..4 = one XCD per query in 8/4/2/1 phases,
+  // 5..8 = the same with every group streaming through its documents (approx_stream_kernel)
+  const unsigned nbx = (unsigned)t.s4_nbx;   // workgroups per XCD
+  const uint32_t slice_w = (uint32_t)((ix->K + 7) / 8);
+  const int s4_p = std::min(t.s4_mode > 4 ? t.s4_mode - 4 : t.s4_mode, 4);   // phases = 8 >> (s4_p - 1)
+  const bool stream = t.s4_mode >= 5 && t.s4_mode <= 8 && ((uint64_t)slice_w << (t.s4_mode - 5)) <= 65536ull;
+  if (stream && ix->sliced_ok && B >= t.s4_minb) {
+    // streamed form (approx_stream_kernel): u16 code-in-slice needs a phase's centroid range <= 65536
+#define NP_LAUNCH_APPROX_S(LPR)                                                                                       \
+  approx_stream_kernel<LPR><<<8 * nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round,          \
+                                                     max_rounds, ix->d_ucodes, ix->T, ix->d_useg, w.approx.as<float>(), \
+                                                     t.s4_mode - 5, slice_w, w.ctr.as<Counters>())
+    if (LQP <= 32) NP_LAUNCH_APPROX_S(8);
+    else if (LQP <= 64) NP_LAUNCH_APPROX_S(16);
+    else if (LQP <= 128) NP_LAUNCH_APPROX_S(32);
+    else NP_LAUNCH_APPROX_S(64);
+#undef NP_LAUNCH_APPROX_S
+  } else if (t.s4_mode > 0 && ix->sliced_ok && B >= t.s4_minb) {
+#define NP_LAUNCH_APPROX_X(LPR, SWZ)                                                                                  \
+  approx_xcd_kernel<LPR, SWZ><<<8 * nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round,        \
+                                                       max_rounds, ix->d_ucodes, ix->T, ix->d_useg,                   \
+                                                       w.approx.as<float>(), s4_p - 1, w.ctr.as<Counters>())
+    if (LQP <= 32) {
+      if (t.s4_swz) NP_LAUNCH_APPROX_X(8, true);
+      else NP_LAUNCH_APPROX_X(8, false);
+    } else if (LQP <= 64) NP_LAUNCH_APPROX_X(16, false);
+    else if (LQP <= 128) NP_LAUNCH_APPROX_X(32, false);
+    else NP_LAUNCH_APPROX_X(64, false);
+#undef NP_LAUNCH_APPROX_X
+  } else {
+    const unsigned grid = 768;
+#define NP_LAUNCH_APPROX(LPR)                                                                                          \
+  approx_kernel<LPR><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round, max_rounds,         \
+                                           ix->d_ucodes, w.approx.as<float>(), w.ctr.as<Counters>())
+    if (LQP <= 32) NP_LAUNCH_APPROX(8);
+    else if (LQP <= 64) NP_LAUNCH_APPROX(16);
+    else if (LQP <= 128) NP_LAUNCH_APPROX(32);
+    else NP_LAUNCH_APPROX(64);
+#undef NP_LAUNCH_APPROX
+  }
 }
 
 // S1..S5 for queries [0,B) whose rows live in d_q (absolute offsets d_qoff/h_qoff).
@@ -258,14 +338,21 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
               maxLq);
     return NP_ERR_SHAPE;
   }
+  if ((uint64_t)ix->KP * (uint64_t)LQP * 4ull >= (1ull << 32)) {   // S4 / S6 address one query's table with 32-bit byte offsets
+    set_error("Shape error: %lld centroids x %d query tokens exceed the 4 GiB per-query score table of the HIP path",
+              (long long)ix->K, LQP);
+    return NP_ERR_SHAPE;
+  }
   cs->LQP = LQP;
   cs->n_sel = n_sel_of(&prm);
   cs->NSELP = next_pow2(std::max(cs->n_sel, 1));
   cs->empty_subset = (subset_len == 0);
   const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
-  const int64_t cand_stride = std::max<int64_t>(ix->n_docs, 1);
   const int nchunks = (int)((NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS);
   const int nsel1 = std::max(cs->n_sel, 1), topk1 = std::max(prm.top_k, 1);
+  const WsPlan plan = plan_workspace(ix, B, LQP, &prm);
+  const int64_t pool = std::min<int64_t>(plan.pool, (int64_t)std::max(B, 1) * std::max<int64_t>(ix->n_docs, 1));
+  const int max_rounds = std::max(1, std::min(plan.max_rounds, std::max(B, 1)));
 
   NP_TRY(w.Qt.reserve((size_t)B * ix->dim * LQP * 4));
   NP_TRY(w.Qb.reserve((size_t)B * ix->dim * LQP * 2));
@@ -279,11 +366,13 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.n_cells.reserve((size_t)B * 4));
   NP_TRY(w.docbits.reserve((size_t)B * std::max<int64_t>(NW, 1) * 4));
   NP_TRY(w.chunk_counts.reserve((size_t)B * std::max(nchunks, 1) * 4));
-  NP_TRY(w.cand.reserve((size_t)B * cand_stride * 4));
-  NP_TRY(w.cand_meta.reserve((size_t)B * cand_stride * 16));
-  NP_TRY(w.approx.reserve((size_t)B * cand_stride * 4));
+  NP_TRY(w.cand.reserve((size_t)pool * 4));
+  NP_TRY(w.cand_meta.reserve((size_t)pool * 16));
+  NP_TRY(w.approx.reserve((size_t)pool * 4));
   NP_TRY(w.n_cand.reserve((size_t)B * 4));
-  NP_TRY(w.prefix.reserve((size_t)(B + 1) * 8));
+  NP_TRY(w.cand_base.reserve((size_t)B * 8));
+  NP_TRY(w.round_of.reserve((size_t)B * 4));
+  NP_TRY(w.round_tab.reserve((size_t)(2 * max_rounds + 1) * 4));
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
   NP_TRY(w.nsel.reserve((size_t)B * 4));
@@ -365,89 +454,57 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));
 
-  // ---- S3
-  if (!cs->empty_subset && ix->n_docs > 0) {
+  // ---- S3: posting-list union (bitmap), per-chunk counts, round plan
+  RoundPlan rp;
+  rp.n_cand = w.n_cand.as<int32_t>();
+  rp.cand_base = w.cand_base.as<int64_t>();
+  rp.round_of = w.round_of.as<int32_t>();
+  rp.round_tab = w.round_tab.as<int32_t>();
+  const bool have_cands = !cs->empty_subset && ix->n_docs > 0;
+  if (have_cands) {
     mark_candidates_kernel<<<dim3(128, B), 256, 0, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
                                                          ix->d_ivf_offsets, ix->d_ivf,
                                                          have_subset ? w.subset_bits.as<uint32_t>() : nullptr, NW,
                                                          w.docbits.as<uint32_t>(), w.ctr.as<Counters>());
     count_chunks_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
                                                           w.chunk_counts.as<int32_t>());
-    compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
-                                                     w.chunk_counts.as<int32_t>(), w.cand.as<uint32_t>(), cand_stride,
-                                                     ix->d_doc_offsets, ix->d_ulen, w.cand_meta.as<uint4>(),
-                                                     w.n_cand.as<int32_t>(), w.ctr.as<Counters>());
+    plan_rounds_kernel<<<1, 256, 0, st>>>(w.chunk_counts.as<int32_t>(), nchunks, B, pool, max_rounds, rp,
+                                          w.ctr.as<Counters>());
   }
-  cand_prefix_kernel<<<1, 64, 0, st>>>(w.n_cand.as<int32_t>(), B, w.prefix.as<int64_t>());
-  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
-
-  // ---- S4
-  if (!cs->empty_subset && ix->n_docs > 0) {
-    // NP_S4_MODE: 0 = all XCDs walk one query (approx_kernel), 1..4 = one XCD per query in 8/4/2/1 phases,
-    // 5..8 = the same with every group streaming through its documents (approx_stream_kernel)
-    const int s4_mode = env_int("NP_S4_MODE", 2), s4_minb = env_int("NP_S4_MINB", 8);
-    const unsigned s4_nbx = (unsigned)std::min(std::max(env_int("NP_S4_NBX", 128), 8), 512);   // workgroups per XCD
-    const uint32_t s4_slice_w = (uint32_t)((ix->K + 7) / 8);
-    const int s4_p = std::min(s4_mode > 4 ? s4_mode - 4 : s4_mode, 4);   // phases = 8 >> (s4_p - 1)
-    const bool s4_stream = s4_mode >= 5 && s4_mode <= 8 && ((uint64_t)s4_slice_w << (s4_mode - 5)) <= 65536ull;
-    if (s4_stream && ix->sliced_ok && B >= s4_minb) {
-      // streamed form (approx_stream_kernel): u16 code-in-slice needs a phase's centroid range <= 65536
-#define NP_LAUNCH_APPROX_S(LPR)                                                                                        \
-  approx_stream_kernel<LPR><<<8 * s4_nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(),   \
-                                                        cand_stride, w.n_cand.as<int32_t>(), B, ix->d_ucodes, ix->T,   \
-                                                        ix->d_useg, w.approx.as<float>(), s4_mode - 5, s4_slice_w,     \
-                                                        w.ctr.as<Counters>())
-      if (LQP <= 32) NP_LAUNCH_APPROX_S(8);
-      else if (LQP <= 64) NP_LAUNCH_APPROX_S(16);
-      else if (LQP <= 128) NP_LAUNCH_APPROX_S(32);
-      else NP_LAUNCH_APPROX_S(64);
-#undef NP_LAUNCH_APPROX_S
-    } else if (s4_mode > 0 && ix->sliced_ok && B >= s4_minb) {
-#define NP_LAUNCH_APPROX_X(LPR, SWZ)                                                                                   \
-  approx_xcd_kernel<LPR, SWZ><<<8 * s4_nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(), \
-                                                          cand_stride, w.n_cand.as<int32_t>(), B, ix->d_ucodes, ix->T,  \
-                                                          ix->d_useg, w.approx.as<float>(), s4_p - 1,                  \
-                                                          w.ctr.as<Counters>())
-      if (LQP <= 32) {
-        if (env_int("NP_S4_SWZ", 1)) NP_LAUNCH_APPROX_X(8, true);
-        else NP_LAUNCH_APPROX_X(8, false);
-      } else if (LQP <= 64) NP_LAUNCH_APPROX_X(16, false);
-      else if (LQP <= 128) NP_LAUNCH_APPROX_X(32, false);
-      else NP_LAUNCH_APPROX_X(64, false);
-#undef NP_LAUNCH_APPROX_X
-    } else {
-      const unsigned grid = 768;
-#define NP_LAUNCH_APPROX(LPR)                                                                                      \
-  approx_kernel<LPR><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, w.cand_meta.as<uint4>(), cand_stride, \
-                                           w.prefix.as<int64_t>(), B, ix->d_ucodes, w.approx.as<float>(),           \
-                                           w.ctr.as<Counters>())
-      if (LQP <= 32) NP_LAUNCH_APPROX(8);
-      else if (LQP <= 64) NP_LAUNCH_APPROX(16);
-      else if (LQP <= 128) NP_LAUNCH_APPROX(32);
-      else NP_LAUNCH_APPROX(64);
-#undef NP_LAUNCH_APPROX
+  SelectP sp;
+  sp.approx = w.approx.as<float>();
+  sp.cand = w.cand.as<uint32_t>();
+  sp.cand_step = 1;
+  sp.rp = rp;
+  sp.n_cand = w.n_cand.as<int32_t>();
+  sp.doc_begin = ix->doc_begin;
+  sp.n_sel = cs->n_sel;
+  sp.NSELP = cs->NSELP;
+  sp.sel_keys = w.sel_keys.as<uint64_t>();
+  sp.sel_doc = w.sel_doc.as<uint32_t>();
+  sp.nsel_out = w.nsel.as<int32_t>();
+  const size_t sel_lds = (size_t)cs->NSELP * 8;
+  if (cs->n_sel > 0 && sel_lds > 48 * 1024)
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+  // ---- per round: S3 compaction -> S4 -> S5 (stage events bracket round 0, which holds the whole batch unless
+  // the candidates overflow the pool; later rounds are charged to S5)
+  for (int r = 0; r < (have_cands ? max_rounds : 0); ++r) {
+    compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
+                                                     w.chunk_counts.as<int32_t>(), w.cand.as<uint32_t>(), rp, r,
+                                                     ix->d_doc_offsets, ix->d_ulen, w.cand_meta.as<uint4>());
+    if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
+    if (ix->T > 0)
+      launch_approx(st, ix, w, d_qoff, B, LQP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r, max_rounds);
+    if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
+    if (cs->n_sel > 0) {
+      sp.round = r;
+      select_kernel<<<B, 1024, sel_lds, st>>>(sp);
     }
   }
-  if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
-
-  // ---- S5
-  if (cs->n_sel > 0) {
-    SelectP sp;
-    sp.approx = w.approx.as<float>();
-    sp.cand = w.cand.as<uint32_t>();
-    sp.cand_stride = cand_stride;
-    sp.n_cand = w.n_cand.as<int32_t>();
-    sp.doc_begin = ix->doc_begin;
-    sp.n_sel = cs->n_sel;
-    sp.NSELP = cs->NSELP;
-    sp.sel_keys = w.sel_keys.as<uint64_t>();
-    sp.sel_doc = w.sel_doc.as<uint32_t>();
-    sp.nsel_out = w.nsel.as<int32_t>();
-    const size_t lds = (size_t)cs->NSELP * 8;
-    if (lds > 48 * 1024)
-      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    select_kernel<<<B, 1024, lds, st>>>(sp);
+  if (cs->timed && !have_cands) {
+    NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
+    NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[5], st));
   NP_HIP(hipGetLastError());
@@ -486,10 +543,10 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.xcd_B = 0;
     ep.gx = 0;
     switch (ix->dim) {
-      case 32: NP_TRY((launch_exact_nb<32>(st, ep, B, cs->prm.precision, ix->nbits))); break;
-      case 64: NP_TRY((launch_exact_nb<64>(st, ep, B, cs->prm.precision, ix->nbits))); break;
-      case 96: NP_TRY((launch_exact_nb<96>(st, ep, B, cs->prm.precision, ix->nbits))); break;
-      default: NP_TRY((launch_exact_nb<128>(st, ep, B, cs->prm.precision, ix->nbits))); break;
+      case 32: NP_TRY((launch_exact_nb<32>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
+      case 64: NP_TRY((launch_exact_nb<64>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
+      case 96: NP_TRY((launch_exact_nb<96>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
+      default: NP_TRY((launch_exact_nb<128>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
     }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[6], st));
@@ -522,8 +579,8 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
 static int begin_use(CallState* cs, void* user_stream) {
   Context* c = cs->ctx;
   cs->stream = user_stream ? (hipStream_t)user_stream : c->stream;
-  if (c->ws->done_valid && cs->stream != c->stream) NP_HIP(hipStreamWaitEvent(cs->stream, c->ws->done, 0));
-  if (c->ws->done_valid && cs->stream == c->stream) NP_HIP(hipStreamWaitEvent(cs->stream, c->ws->done, 0));
+  // the workspace's previous use (on whatever stream) must have finished before this one touches it
+  if (c->ws->done_valid) NP_HIP(hipStreamWaitEvent(cs->stream, c->ws->done, 0));
   return NP_OK;
 }
 static int end_use(CallState* cs) {
@@ -532,21 +589,33 @@ static int end_use(CallState* cs) {
   c->ws->done_valid = true;
   return NP_OK;
 }
+// Every exit path of a call that touched a workspace records its `done` event (a failed call may already have
+// queued work on the stream) and only then hands the context back.
+struct UseGuard {
+  const DeviceIndex* ix;
+  CallState* cs;
+  bool began = false;
+  ~UseGuard() {
+    if (began && cs->stream) (void)end_use(cs);
+    if (cs->ctx) release_context(ix, cs->ctx);
+  }
+};
 
-static int slice_size(const DeviceIndex* ix, const int32_t* h_qoff, int B) {
+static int lqp_of(const int32_t* h_qoff, int B) {
   int maxLq = 1;
   for (int b = 0; b < B; ++b) maxLq = std::max(maxLq, h_qoff[b + 1] - h_qoff[b]);
-  const int LQP = std::min((maxLq + 31) / 32 * 32, 32 * NP_MAX_QT);
-  int64_t s = ix->opts.workspace_bytes / std::max<int64_t>(per_query_bytes(ix, LQP), 1);
-  s = std::max<int64_t>(1, std::min<int64_t>(s, std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB)));
-  return (int)std::min<int64_t>(s, std::max(B, 1));
+  return std::min((maxLq + 31) / 32 * 32, 32 * NP_MAX_QT);
+}
+
+static int slice_size(const DeviceIndex* ix, const int32_t* h_qoff, int B, const np_search_params* prm) {
+  return std::max(1, std::min(plan_workspace(ix, B, lqp_of(h_qoff, B), prm).S, std::max(B, 1)));
 }
 
 // Whole batch on device buffers, sliced.  No host synchronisation.
 static int run_device(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
                       const int32_t* h_qoff, int B, const np_search_params* prm, const int64_t* d_subset,
                       int64_t subset_len, int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts) {
-  const int S = slice_size(ix, h_qoff, B);
+  const int S = slice_size(ix, h_qoff, B, prm);
   for (int s0 = 0; s0 < B; s0 += S) {
     cs->B = std::min(S, B - s0);
     cs->prm = *prm;
@@ -574,6 +643,10 @@ int np_hip_search_batch_device(const np_index* ix, const float* d_queries, const
   if (B == 0) return NP_OK;
   if (!d_queries || !d_q_tok_offsets || !h_q_tok_offsets || !d_out_counts || (params->top_k > 0 && (!d_out_ids || !d_out_scores))) {
     set_error("Search failed: NULL buffer");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (subset_len > 0 && !d_subset) {
+    set_error("Search failed: subset_len > 0 but subset is NULL");
     return NP_ERR_INVALID_ARGUMENT;
   }
   DeviceGuard g(ix->device);
@@ -615,13 +688,10 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
   DeviceGuard g(ix->device);
   CallState cs;
   NP_TRY(acquire_context(ix, &cs.ctx));
-  struct Rel {
-    const np_index* ix;
-    Context* c;
-    ~Rel() { release_context(ix, c); }
-  } rel{ix, cs.ctx};
+  UseGuard guard{ix, &cs};
   Workspace& w = *cs.ctx->ws;
   NP_TRY(begin_use(&cs, nullptr));
+  guard.began = true;
   hipStream_t st = cs.stream;
   const int64_t ntok = q_tok_offsets[B];
   const int topk = params->top_k;
@@ -641,7 +711,7 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
   if (subset_len > 0) NP_HIP(hipMemcpyAsync(w.subset.p, subset, (size_t)subset_len * 8, hipMemcpyHostToDevice, st));
 
   // slices: each slice's outputs go to its rows of the batch-wide output buffers
-  const int S = slice_size(ix, q_tok_offsets, B);
+  const int S = slice_size(ix, q_tok_offsets, B, params);
   np_stats acc;
   memset(&acc, 0, sizeof acc);
   char* pin = (char*)w.h_pin;
@@ -681,6 +751,8 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
       acc.n_exact_docs += (int64_t)h_ctr->n_exact_docs;
       acc.n_exact_tokens += (int64_t)h_ctr->n_exact_tokens;
       acc.n_cand_codes += (int64_t)h_ctr->n_cand_codes;
+      acc.n_survivors += (int64_t)h_ctr->n_survivors;
+      acc.n_rounds = std::max(acc.n_rounds, (int32_t)h_ctr->n_rounds);
     }
   }
   if (topk > 0) {
@@ -718,7 +790,11 @@ int np_hip_search_phase_a(const np_index* ix, const float* d_queries, const int3
     set_error("Search failed: NULL buffer");
     return NP_ERR_INVALID_ARGUMENT;
   }
-  if (B > slice_size(ix, h_q_tok_offsets, B)) {
+  if (subset_len > 0 && !d_subset) {
+    set_error("Search failed: subset_len > 0 but subset is NULL");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B > slice_size(ix, h_q_tok_offsets, B, params)) {
     set_error("Search failed: a sharded call must fit one workspace slice (B=%d); raise workspace_bytes/max_batch", B);
     return NP_ERR_SEARCH;
   }
@@ -894,13 +970,10 @@ int np_hip_debug_trace(const np_index* ix, const float* query, int32_t n_tokens,
   DeviceGuard g(ix->device);
   CallState cs;
   NP_TRY(acquire_context(ix, &cs.ctx));
-  struct Rel {
-    const np_index* ix;
-    Context* c;
-    ~Rel() { release_context(ix, c); }
-  } rel{ix, cs.ctx};
+  UseGuard guard{ix, &cs};
   Workspace& w = *cs.ctx->ws;
   NP_TRY(begin_use(&cs, nullptr));
+  guard.began = true;
   hipStream_t st = cs.stream;
   int32_t h_off[2] = {0, n_tokens};
   NP_TRY(w.q.reserve((size_t)std::max(n_tokens, 1) * dim * 4));
@@ -911,6 +984,7 @@ int np_hip_debug_trace(const np_index* ix, const float* query, int32_t n_tokens,
   if (subset_len > 0) NP_HIP(hipMemcpyAsync(w.subset.p, subset, (size_t)subset_len * 8, hipMemcpyHostToDevice, st));
   cs.B = 1;
   cs.prm = *params;
+  cs.trace = true;
   NP_TRY(phase_a(ix, &cs, w.q.as<float>(), w.qoff.as<int32_t>(), h_off, subset_len > 0 ? w.subset.as<int64_t>() : nullptr,
                  subset_len));
   NP_TRY(phase_b(ix, &cs, w.qoff.as<int32_t>(), nullptr, w.out_ids.as<int64_t>(), w.out_scores.as<float>(),
@@ -976,17 +1050,14 @@ int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_
   DeviceGuard g(ix->device);
   CallState cs;
   NP_TRY(acquire_context(ix, &cs.ctx));
-  struct Rel {
-    const np_index* ix;
-    Context* c;
-    ~Rel() { release_context(ix, c); }
-  } rel{ix, cs.ctx};
+  UseGuard guard{ix, &cs};
   Workspace& w = *cs.ctx->ws;
   NP_TRY(begin_use(&cs, nullptr));
+  guard.began = true;
   hipStream_t st = cs.stream;
   const int LQP = 32;
   const int64_t KP = ix->KP, G = KP >> 5;
-  int64_t S = ix->opts.workspace_bytes / std::max<int64_t>(per_query_bytes(ix, LQP), 1);
+  int64_t S = ix->opts.workspace_bytes / std::max<int64_t>(per_query_bytes(ix, LQP, 1, 1), 1);
   S = std::max<int64_t>(1, std::min<int64_t>(S, std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB)));
   S = std::min<int64_t>(S, (n_tokens + LQP - 1) / LQP);
   const int64_t TB = S * LQP;

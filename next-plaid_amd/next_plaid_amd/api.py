@@ -84,7 +84,8 @@ class np_stats(C.Structure):
                 ("ms_exact", C.c_float), ("ms_topk", C.c_float),
                 ("n_cells", C.c_int64), ("n_ivf_ids", C.c_int64), ("n_candidates", C.c_int64),
                 ("n_cand_tokens", C.c_int64), ("n_exact_docs", C.c_int64), ("n_exact_tokens", C.c_int64),
-                ("n_cand_codes", C.c_int64), ("n_queries", C.c_int32), ("reserved", C.c_int32)]
+                ("n_cand_codes", C.c_int64), ("n_queries", C.c_int32), ("n_rounds", C.c_int32),
+                ("n_survivors", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -107,7 +108,7 @@ class np_synth_spec(C.Structure):
 
 EXPORTS = [
     "np_hip_device_count", "np_hip_last_error", "np_hip_index_open", "np_hip_index_from_arrays",
-    "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_close",
+    "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_tune", "np_hip_index_close",
     "np_hip_index_info", "np_hip_index_probe_dir", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
     "np_hip_search_phase_b", "np_hip_search_end", "np_hip_n_sel", "np_hip_select_cut", "np_hip_merge_topk",
     "np_hip_decompress_documents", "np_hip_encode_tokens", "np_hip_rerank_maxsim", "np_hip_debug_trace",
@@ -161,6 +162,7 @@ def lib():
     L.np_hip_index_export.argtypes = [vp] * 6
     L.np_hip_index_ivf_size.argtypes = [vp]
     L.np_hip_index_ivf_size.restype = i64
+    L.np_hip_index_tune.argtypes = [vp, C.c_char_p, i32]
     L.np_hip_index_close.argtypes = [vp]
     L.np_hip_index_close.restype = None
     L.np_hip_index_info.argtypes = [vp, C.POINTER(np_info)]
@@ -237,14 +239,17 @@ def _ptr(a):
 
 @dataclass
 class SearchParameters:
-    """search.rs:26-69 (same field names and defaults) + `precision` (0 fp32 parity, 1 bf16 MaxSim)."""
+    """search.rs:26-69 (same field names and defaults) + `precision`, the arithmetic of the exact MaxSim stage
+    (S1-S5 are always exact f32): 2 (default) = QC-reuse form with split-bf16 MFMA on the residual term, f32-class
+    accuracy (max relative score error 5e-7 measured, the same as mode 0); 0 = exact-f32 MFMA on decompressed rows;
+    1 = QC-reuse with plain bf16 on the residual term (<= 1e-3 relative); 3 = bf16 MFMA on decompressed rows."""
     batch_size: int = 2000
     n_full_scores: int = 4096
     top_k: int = 10
     n_ivf_probe: int = 8
     centroid_batch_size: int = 100_000
     centroid_score_threshold: float | None = 0.4
-    precision: int = 0
+    precision: int = 2
 
     def _c(self) -> np_search_params:
         t = self.centroid_score_threshold
@@ -317,6 +322,10 @@ class MmapIndex:
         o = _opts(**opts)
         _check(lib().np_hip_index_synth(C.byref(s), C.byref(o), C.byref(h)))
         return cls(h, "<synth>")
+
+    def tune(self, name: str, value: int):
+        """Kernel-selection knob on a live handle (np_hip_index_tune): sweep tools / variant parity tests."""
+        _check(lib().np_hip_index_tune(self._h, name.encode(), int(value)))
 
     def close(self):
         h, self._h = self._h, None

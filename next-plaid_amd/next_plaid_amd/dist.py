@@ -143,12 +143,12 @@ class ShardedSearcher:
         dqs = [d_q] if single else list(d_q)
         dos = [d_qoff] if single else list(d_qoff)
         keys, states = [], []
-        for be, q, o in zip(self.backends, dqs, dos):
-            k, st = be.phase_a(q, o, h_qoff, params)
-            keys.append(k)
-            states.append(st)
         packed = []
         try:
+            for be, q, o in zip(self.backends, dqs, dos):   # inside the try: a failing shard must not strand the others' contexts
+                k, st = be.phase_a(q, o, h_qoff, params)
+                keys.append(k)
+                states.append(st)
             all_keys = self._all_gather(t.stack([k.to(keys[0].device) for k in keys], 0))
             for be, st in zip(self.backends, states):
                 cut = be.select_cut(all_keys.to(be.device))

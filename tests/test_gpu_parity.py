@@ -29,8 +29,24 @@ def P(**kw):
     return npa.SearchParameters(**kw)
 
 
-def check_trace(hx, ox, q, p, subset=None, what="", exact_rtol=RTOL_F32, bitexact_probe=True):
+# Every exact-MaxSim arithmetic the library ships is compared with the oracle in the edge-case tests below, not only
+# the strict f32 form: 2 is the default AND what bench.py times (exact_qct_kernel / exact_qc_kernel, split-bf16),
+# 0 the exact-f32 MFMA kernel, 1 and 3 the bf16 forms at north_star's 1e-3 bound.
+PRECISIONS = [2, 0, 1, 3]
+
+
+def rtol_of(prec):
+    return RTOL_F32 if prec in (0, 2) else RTOL_BF16
+
+
+@pytest.fixture(params=PRECISIONS, ids=[f"prec{p}" for p in PRECISIONS])
+def prec(request):
+    return request.param
+
+
+def check_trace(hx, ox, q, p, subset=None, what="", exact_rtol=None, bitexact_probe=True):
     """Stage-by-stage comparison for one query; returns the oracle result."""
+    exact_rtol = rtol_of(p.precision) if exact_rtol is None else exact_rtol
     tr = hx.debug_trace(q, p, subset)
     r = ox.search(q, to_oracle_params(p), subset, trace=True)
     t = r.trace
@@ -57,32 +73,46 @@ def test_device_present():
     assert npa.device_count() >= 1
 
 
-def test_stages_mid(mid):
+def test_default_precision_is_the_benched_one():
+    assert npa.SearchParameters().precision == 2
+
+
+def test_stages_mid(mid, prec):
     spec, a, ox, hx, qs, src = mid
     for thr in (0.4, None):
-        p = P(n_full_scores=512, top_k=10, n_ivf_probe=8, centroid_score_threshold=thr)
+        p = P(n_full_scores=512, top_k=10, n_ivf_probe=8, centroid_score_threshold=thr, precision=prec)
         for qi in range(4):
             check_trace(hx, ox, qs[qi], p, what=f"thr={thr} q{qi}")
 
 
+@pytest.fixture
+def tuned(mid):
+    """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
+    hx = mid[3]
+    yield hx
+    for k, v in (("s4_mode", 2), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0)):
+        hx.tune(k, v)
+
+
+@pytest.mark.parametrize("filt", [0, 1])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8])
-def test_s4_kernel_variants_bit_exact(mid, mode, monkeypatch):
-    """S4 has three kernels (all XCDs on one query / one XCD per query in 8,4,2,1 phases over the centroid range,
-    lockstep or streamed);
-    the library reads NP_S4_MODE / NP_S4_MINB on every call.  Every variant must reproduce the oracle's
-    approximate scores bit for bit -- also for one-query calls (MINB=1), ragged query lengths and the
-    bpermute code broadcast."""
+def test_s4_kernel_variants_bit_exact(mid, tuned, mode, filt):
+    """S4 has three exact kernels (all XCDs on one query / one XCD per query in 8,4,2,1 phases over the centroid range,
+    lockstep or streamed), with or without the u8 upper-bound filter in front; np_hip_index_tune selects them.
+    Every variant must reproduce the oracle's approximate scores bit for bit -- also for one-query calls (minb=1),
+    ragged query lengths and the bpermute code broadcast -- and the same selection through the batched entry."""
     spec, a, ox, hx, qs, src = mid
-    monkeypatch.setenv("NP_S4_MODE", str(mode))
-    monkeypatch.setenv("NP_S4_MINB", "1")
+    hx.tune("s4_mode", mode)
+    hx.tune("s4_minb", 1)
+    hx.tune("s4_filter", filt)
     p = P(n_full_scores=512, top_k=10, n_ivf_probe=8, centroid_score_threshold=0.4)
     for qi in (0, 5):
         check_trace(hx, ox, qs[qi], p, what=f"S4 mode {mode} q{qi}")
     check_trace(hx, ox, qs[7][:13], p, what=f"S4 mode {mode} short query")
-    monkeypatch.setenv("NP_S4_SWZ", "0")
+    hx.tune("s4_swz", 0)
     check_trace(hx, ox, qs[9], p, what=f"S4 mode {mode} bpermute")
     # whole batch through the batched entry point (B >= 8 takes the per-XCD kernel when mode > 0)
-    monkeypatch.delenv("NP_S4_MINB")
+    hx.tune("s4_minb", 8)
     res = hx.search_batch(qs[:16], p)
     ref = ox.search_batch(qs[:16], to_oracle_params(p))
     for i, (r, o) in enumerate(zip(res, ref)):
@@ -108,19 +138,20 @@ def test_batch_mid_all_precisions(mid):
 def test_search_equals_batch_of_one(mid):
     spec, a, ox, hx, qs, src = mid
     p = P(n_full_scores=256, top_k=7, n_ivf_probe=4)
+    assert p.precision == 2
     r1 = hx.search(qs[3], p)
     rb = hx.search_batch(qs[:8], p)[3]
     assert r1.query_id == 0 and np.array_equal(r1.passage_ids, rb.passage_ids) and np.array_equal(r1.scores, rb.scores)
 
 
 @pytest.mark.parametrize("case", [c[0] for c in MG.CASES])
-def test_golden_search(case):
+def test_golden_search(case, prec):
     spec = synth.SynthSpec(**MG.GOLDEN_SPEC)
     a = synth.generate_arrays(spec)
     hx = hip_index(a)
     gold = np.load(os.path.join(GOLDEN, "search_2000.npz"))
     name, kw, sub = next(c for c in MG.CASES if c[0] == case)
-    p = P(**kw)
+    p = P(**kw, precision=prec)
     subset = None if sub is None else np.arange(0, spec.num_docs, 2, dtype=np.int64)
     for qi, q in enumerate(gold["queries"]):
         tr = hx.debug_trace(q, p, subset)
@@ -128,29 +159,30 @@ def test_golden_search(case):
         assert np.array_equal(tr["cand"], gold[f"{name}_q{qi}_cand"]), f"{name} q{qi} cand"
         r = hx.search(q, p, subset)
         assert_ranking_close(r.passage_ids, r.scores, gold[f"{name}_q{qi}_ids"], gold[f"{name}_q{qi}_scores"],
-                             RTOL_F32, f"{name} q{qi}")
+                             rtol_of(prec), f"{name} q{qi}")
 
 
 @pytest.mark.parametrize("dim,nbits,K", [(64, 4, 100), (64, 2, 70), (96, 4, 257), (96, 2, 64), (32, 4, 33),
                                          (128, 2, 1000)])
-def test_shapes_ragged_edges(dim, nbits, K):
-    # ragged docs incl. EMPTY ones, K not a multiple of 32/64, short and long queries, top_k > candidates
+def test_shapes_ragged_edges(dim, nbits, K, prec):
+    # ragged docs incl. EMPTY ones, K not a multiple of 32/64, short and long queries (Lq 65/100/200 take the
+    # row-max exact_qc_kernel at precision 1/2), top_k > candidates
     spec, a = make_arrays(num_docs=700, num_centroids=K, dim=dim, nbits=nbits, doc_len_min=0, doc_len_max=70, seed=dim + nbits)
     assert (a["doc_lengths"] == 0).any()
     ox, hx = oracle_index(a), hip_index(a)
-    for ntok in (1, 5, 32, 48, 100):
+    for ntok in (1, 5, 32, 48, 65, 100, 200):
         qs, _ = synth.make_queries(spec, 3, n_tokens=ntok, cen=a["centroids"])
         for thr, nprobe, nfs, topk in ((None, 3, 64, 5), (0.35, 8, 256, 300), (None, 64, 40, 10)):
-            p = P(n_full_scores=nfs, top_k=topk, n_ivf_probe=nprobe, centroid_score_threshold=thr)
+            p = P(n_full_scores=nfs, top_k=topk, n_ivf_probe=nprobe, centroid_score_threshold=thr, precision=prec)
             for qi, q in enumerate(qs):
                 check_trace(hx, ox, q, p, what=f"d{dim} b{nbits} K{K} Lq{ntok} thr{thr} np{nprobe} q{qi}")
             res = hx.search_batch(qs, p)
             ref = ox.search_batch(qs, to_oracle_params(p))
             for r, o in zip(res, ref):
-                assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32)
+                assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, rtol_of(prec))
 
 
-def test_mixed_length_batch_and_slicing():
+def test_mixed_length_batch_and_slicing(prec):
     spec, a = make_arrays(num_docs=3000, num_centroids=512, dim=128, nbits=4, doc_len_min=10, doc_len_max=60, seed=8)
     ox = oracle_index(a)
     hx = hip_index(a, max_batch=5)          # forces 13 queries through 3 slices
@@ -159,14 +191,36 @@ def test_mixed_length_batch_and_slicing():
     for i in range(13):
         q, _ = synth.make_queries(spec, 1, n_tokens=int(g.integers(1, 70)), cen=a["centroids"], first_query=i)
         qs.append(q[0])
-    p = P(n_full_scores=128, top_k=6, n_ivf_probe=6)
+    p = P(n_full_scores=128, top_k=6, n_ivf_probe=6, precision=prec)
     res = hx.search_batch(qs, p)
     ref = ox.search_batch(qs, to_oracle_params(p))
     for i, (r, o) in enumerate(zip(res, ref)):
-        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32, f"q{i}")
+        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, rtol_of(prec), f"q{i}")
 
 
-def test_nan_inf_query_tokens():
+def test_candidate_pool_rounds(mid):
+    """The candidate arrays are one pool sized by workspace_bytes, not B x n_docs: a batch whose candidates do not
+    fit it together is processed in rounds (first-fit in query order).  A deliberately small budget with a wide probe
+    forces several rounds; results must equal the oracle's and the roomy handle's bit for bit."""
+    spec, a, ox, hx, qs, src = mid
+    small = hip_index(a, workspace_bytes=11 << 20, max_batch=16)
+    p = P(n_full_scores=512, top_k=10, n_ivf_probe=64, centroid_score_threshold=None)
+    res = small.search_batch(qs[:16], p)
+    assert small.last_stats["n_rounds"] >= 2, small.last_stats
+    ref = hx.search_batch(qs[:16], p)
+    assert hx.last_stats["n_rounds"] == 1
+    assert small.last_stats["n_candidates"] == hx.last_stats["n_candidates"]
+    orc = ox.search_batch(qs[:16], to_oracle_params(p))
+    for i, (r, f, o) in enumerate(zip(res, ref, orc)):
+        assert np.array_equal(r.passage_ids, f.passage_ids) and np.array_equal(r.scores, f.scores), f"q{i}"
+        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32, f"rounds q{i}")
+    for mode in (0, 2, 6):          # every S4 kernel family walks the rounds
+        small.tune("s4_mode", mode)
+        for r, f in zip(small.search_batch(qs[:16], p), ref):
+            assert np.array_equal(r.passage_ids, f.passage_ids) and np.array_equal(r.scores, f.scores), f"mode {mode}"
+
+
+def test_nan_inf_query_tokens(prec):
     spec, a = make_arrays(num_docs=1500, num_centroids=256, dim=128, nbits=4, doc_len_min=10, doc_len_max=40, seed=21)
     ox, hx = oracle_index(a), hip_index(a)
     qs, _ = synth.make_queries(spec, 2, n_tokens=8, cen=a["centroids"])
@@ -174,19 +228,20 @@ def test_nan_inf_query_tokens():
     q[2, :] = np.nan            # a NaN token: contributes 0, never selects cells ahead of finite scores
     q[5, 7] = np.inf
     for thr in (None, 0.4):
-        p = P(n_full_scores=128, top_k=5, n_ivf_probe=4, centroid_score_threshold=thr)
+        p = P(n_full_scores=128, top_k=5, n_ivf_probe=4, centroid_score_threshold=thr, precision=prec)
         r = hx.search(q, p)
         o = ox.search(q, to_oracle_params(p))
-        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32, f"nan thr={thr}")
+        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, rtol_of(prec), f"nan thr={thr}")
+        check_trace(hx, ox, q, p, what=f"nan thr={thr}")
         assert np.all(np.isfinite(r.scores))
 
 
-def test_subset_filter_and_empty_subset():
+def test_subset_filter_and_empty_subset(prec):
     # filtering_integration.rs:69-117, :320-349 through the HIP path
     spec, a = make_arrays(num_docs=2000, num_centroids=256, dim=128, nbits=4, doc_len_min=10, doc_len_max=40, seed=31)
     ox, hx = oracle_index(a), hip_index(a)
     qs, _ = synth.make_queries(spec, 4, n_tokens=16, cen=a["centroids"])
-    p = P(n_full_scores=256, top_k=5, n_ivf_probe=4, centroid_score_threshold=None)
+    p = P(n_full_scores=256, top_k=5, n_ivf_probe=4, centroid_score_threshold=None, precision=prec)
     for subset in (np.arange(0, 2000, 2), np.array([5, 17, 1999, 4000, -3]), np.arange(100)):
         subset = subset.astype(np.int64)
         for qi, q in enumerate(qs):
@@ -218,6 +273,22 @@ def test_on_disk_index_equals_arrays(tmp_path):
     for k in ("doc_lengths", "codes", "residuals", "ivf", "ivf_lengths"):
         assert np.array_equal(e1[k], e2[k]) and np.array_equal(e1[k], np.asarray(a[k])), k
     qs, _ = synth.make_queries(spec, 3, n_tokens=32, cen=a["centroids"])
+    p = P(n_full_scores=128, top_k=10, n_ivf_probe=8)
+    for r1, r2 in zip(hd.search_batch(qs, p), ha.search_batch(qs, p)):
+        assert np.array_equal(r1.passage_ids, r2.passage_ids) and np.array_equal(r1.scores, r2.scores)
+
+
+def test_float16_index_files(tmp_path):
+    """fast-plaid '<f2' centroids / bucket_weights (mmap.rs:1757-1778): same results as the widened '<f4' files."""
+    spec, a = make_arrays(num_docs=600, num_centroids=96, dim=64, nbits=2, doc_len_min=5, doc_len_max=40, seed=19)
+    a16 = dict(a)
+    a16["centroids"] = a["centroids"].astype(np.float16).astype(np.float32)
+    a16["bucket_weights"] = a["bucket_weights"].astype(np.float16).astype(np.float32)
+    synth.write_index(str(tmp_path), a16, chunk_docs=250)
+    np.save(os.path.join(str(tmp_path), "centroids.npy"), a["centroids"].astype("<f2"))
+    np.save(os.path.join(str(tmp_path), "bucket_weights.npy"), a["bucket_weights"].astype("<f2"))
+    hd, ha = npa.MmapIndex.load(str(tmp_path)), hip_index(a16)
+    qs, _ = synth.make_queries(spec, 3, n_tokens=20, cen=a16["centroids"])
     p = P(n_full_scores=128, top_k=10, n_ivf_probe=8)
     for r1, r2 in zip(hd.search_batch(qs, p), ha.search_batch(qs, p)):
         assert np.array_equal(r1.passage_ids, r2.passage_ids) and np.array_equal(r1.scores, r2.scores)

@@ -51,6 +51,16 @@ def test_fast_plaid_dtypes_and_v2_headers_are_accepted(index_dir):
     assert info.num_documents == 300 and info.num_partitions == 64
 
 
+def test_fast_plaid_float16_codec_files_are_accepted(index_dir):
+    """fast-plaid writes centroids / bucket_weights as '<f2'; MmapIndex::load converts them to '<f4' first
+    (mmap.rs:1757-1778).  The loader widens them in memory (values: test_gpu_parity.test_float16_index_files)."""
+    p, a = index_dir
+    np.save(os.path.join(p, "centroids.npy"), a["centroids"].astype("<f2"))
+    np.save(os.path.join(p, "bucket_weights.npy"), a["bucket_weights"].astype("<f2"))
+    info = npa.probe_index_dir(p)
+    assert info.num_documents == 300 and info.num_partitions == 64 and info.embedding_dim == 32
+
+
 def test_metadata_counts_are_inferred_when_zero(index_dir):
     p, a = index_dir
     m = json.load(open(os.path.join(p, "metadata.json")))
