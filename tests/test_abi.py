@@ -23,12 +23,27 @@ def test_header_symbols_are_exported():
     assert sorted(api.EXPORTS) == declared, "api.EXPORTS must list exactly the header's entry points"
 
 
-def test_struct_sizes_match_header():
-    # natural alignment, no packing surprises between ctypes and the C structs
-    assert C.sizeof(api.np_open_opts) == 32
-    assert C.sizeof(api.np_search_params) == 28
-    assert C.sizeof(api.np_stats) == 8 * 4 + 7 * 8 + 8
-    assert C.sizeof(api.np_info) == 3 * 8 + 2 * 4 + 8 + 3 * 8 + 8 + 2 * 4
+def test_struct_sizes_match_header(tmp_path):
+    # ctypes mirrors vs the C structs as gcc lays them out from include/nextplaid_hip.h (size AND field offsets)
+    import subprocess
+    names = ["np_open_opts", "np_search_params", "np_stats", "np_info", "np_index_arrays", "np_synth_spec"]
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "nextplaid_hip.h"', "int main(void) {"]
+    for n in names:
+        src.append(f'  printf("{n} %zu\\n", sizeof({n}));')
+        for f, _ in getattr(api, n)._fields_:
+            src.append(f'  printf("{n}.{f} %zu\\n", offsetof({n}, {f}));')
+    src += ["  return 0;", "}"]
+    c = tmp_path / "sz.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n in names:
+        st = getattr(api, n)
+        assert C.sizeof(st) == int(got[n]), n
+        for f, _ in st._fields_:
+            assert getattr(st, f).offset == int(got[f"{n}.{f}"]), f"{n}.{f}"
+    assert C.sizeof(api.np_search_params) == 28 and C.sizeof(api.np_open_opts) == 32
 
 
 def test_no_oracle_in_product_path():
