@@ -578,14 +578,17 @@ static int build_ivf_from_ucodes(DeviceIndex* ix) {
   std::vector<int64_t> upfx((size_t)N);
   if (N > 0) {
     NP_TRY(dev_alloc(&d_upfx, (size_t)N, nullptr));
-    ulen_to_i64_kernel<<<(unsigned)((N + 255) / 256), 256>>>(ix->d_ulen, N, d_upfx);
+    NP_TRY(dev_alloc(&d_start, (size_t)N, nullptr));   // scan input (freed below; d_start is re-allocated per code later)
+    ulen_to_i64_kernel<<<(unsigned)((N + 255) / 256), 256>>>(ix->d_ulen, N, d_start);
     size_t tb = 0;
-    NP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_upfx, d_upfx, (int)N));
+    NP_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_start, d_upfx, (int)N));
     NP_HIP(hipMalloc(&d_temp, std::max<size_t>(tb, 16)));
-    NP_HIP(hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_upfx, d_upfx, (int)N));
+    NP_HIP(hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_start, d_upfx, (int)N));
     NP_HIP(hipMemcpy(upfx.data(), d_upfx, (size_t)N * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_temp);
     d_temp = nullptr;
+    (void)hipFree(d_start);
+    d_start = nullptr;
   }
   const int64_t total = N > 0 ? upfx[(size_t)N - 1] : 0;
   // document ranges of at most NP_IVF_SEG pairs (a single document never exceeds 65535 distinct codes... any size fits)
