@@ -16,7 +16,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # Stated tolerances (north_star allows 1e-3 relative; the fp32 path is far inside it).
 RTOL_F32 = 2e-5   # fp32 MFMA path vs oracle: summation-order differences only
-RTOL_BF16 = 1e-3  # bf16 MaxSim (precision=1): north_star's bound
+RTOL_BF16 = 1e-3  # bf16 on the residual term only (precision=1): north_star's bound
+RTOL_BF16_PLAIN = 4e-3  # precision=3: BOTH operands of the whole dot product rounded to bf16 (2^-8 per product); the
+                        # config-5 comparison mode, measured 1.1e-3 on one-token queries -- outside north_star's bound,
+                        # which is why it is not a default
 
 
 def make_arrays(**kw):

@@ -8,6 +8,6 @@ tail -n 15 $O/test_gpu_all.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"
 timeout 600 python bench.py --docs 1000000 --steps 20 --warmup 3 --cpu-queries 16 > $O/bench_1m.json 2> $O/bench_1m.err; echo "bench_1m rc=$?"
 cut -c1-1800 $O/bench_1m.json
-/usr/bin/time -v timeout 900 python bench.py --steps 10 --warmup 2 > $O/bench_10m.json 2> $O/bench_10m.err; echo "bench_10m rc=$?"
+timeout 900 python bench.py --steps 10 --warmup 2 > $O/bench_10m.json 2> $O/bench_10m.err; echo "bench_10m rc=$?"
 cut -c1-2500 $O/bench_10m.json; tail -n 25 $O/bench_10m.err
 timeout 120 tools/probes/gather_probe2 > $O/gather_probe2.txt 2>&1; tail -n 50 $O/gather_probe2.txt
