@@ -9,6 +9,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -148,9 +149,43 @@ static int check_geometry(int64_t K, int dim, int nbits, int64_t n_total) {
   return NP_OK;
 }
 
+// largest squared row norm of the centroid table (bit pattern of a non-negative float orders like the float) and a
+// non-finite flag: |Q.c| <= ||q|| * cmax scales the u8 table of the S4 upper-bound filter (np_kernels.h)
+__global__ void __launch_bounds__(256) centroid_bound_kernel(const float* __restrict__ C, int64_t K, int dim,
+                                                             uint32_t* __restrict__ out /* [0] max bits, [1] non-finite */) {
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= K) return;
+  float ss = 0.f;
+  for (int j = lane; j < dim; j += 64) {
+    const float x = C[c * dim + j];
+    ss = fmaf(x, x, ss);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if (lane == 0) {
+    if ((__float_as_uint(ss) & 0x7F800000u) == 0x7F800000u) atomicOr(&out[1], 1u);
+    else atomicMax(&out[0], __float_as_uint(ss));
+  }
+}
+
 static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bucket_weights) {
   NP_TRY(dev_alloc(&ix->d_centroids, (size_t)ix->K * ix->dim, &ix->device_bytes));
   NP_HIP(hipMemcpy(ix->d_centroids, centroids, (size_t)ix->K * ix->dim * sizeof(float), hipMemcpyHostToDevice));
+  {
+    uint32_t* d_b = nullptr;
+    uint32_t h_b[2] = {0, 0};
+    NP_HIP(hipMalloc(&d_b, 8));
+    NP_HIP(hipMemset(d_b, 0, 8));
+    centroid_bound_kernel<<<(unsigned)((ix->K + 3) / 4), 256>>>(ix->d_centroids, ix->K, ix->dim, d_b);
+    hipError_t e = hipMemcpy(h_b, d_b, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_b);
+    NP_HIP(e);
+    float ss;
+    memcpy(&ss, &h_b[0], 4);
+    ix->cmax = sqrtf(ss) * 1.0001f;   // the f32 sum of squares is within ~dim * 2^-24 of the real one
+    ix->filter_ok = h_b[1] == 0;
+  }
   const int nb = 1 << ix->nbits;
   std::vector<float> wl(nb);
   for (int s = 0; s < nb; ++s) wl[s] = bucket_weights[bitrev((uint32_t)s, ix->nbits)];
@@ -284,7 +319,8 @@ __global__ void __launch_bounds__(256) useg_kernel(int64_t n_docs, const int64_t
 }
 
 static int build_unique_codes(DeviceIndex* ix) {
-  NP_TRY(dev_alloc(&ix->d_ucodes, (size_t)ix->T, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_ucodes, (size_t)ix->T + 4, &ix->device_bytes));   // +4: the S4 filter reads codes 4 at a time
+  NP_HIP(hipMemset(ix->d_ucodes + ix->T, 0, 16));
   NP_TRY(dev_alloc(&ix->d_ulen, (size_t)ix->n_docs, &ix->device_bytes));
   NP_TRY(dev_alloc(&ix->d_useg, (size_t)ix->n_docs, &ix->device_bytes));
   for (int64_t d0 = 0; d0 < ix->n_docs; d0 += (int64_t)1 << 30) {

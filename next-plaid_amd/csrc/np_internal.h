@@ -126,6 +126,8 @@ struct DeviceIndex {
   int32_t* d_ulen = nullptr;      // [n_docs] number of distinct codes per document (derived)
   uint4* d_useg = nullptr;        // [n_docs] 8 x u16: distinct codes below each eighth of the centroid range (derived)
   bool sliced_ok = false;         // every document's distinct-code list is sorted and < 65536 long
+  float cmax = 0.f;               // upper bound of the centroid row norms (derived; scales the S4 u8 score table)
+  bool filter_ok = false;         // every centroid value is finite: the S4 upper-bound filter may run
   float* d_inv_norm = nullptr;    // [T] 1 / max(||centroid[code] + residual||, 1e-12) per token (derived)
   uint8_t* d_residuals = nullptr;
   int64_t* d_doc_offsets = nullptr;

@@ -54,10 +54,15 @@ struct Counters {  // per-call work counters (np_stats)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restrict__ q, const int32_t* __restrict__ qoff,
                                                            int dim, int LQP, float* __restrict__ Qt,
-                                                           __bf16* __restrict__ Qb, __bf16* __restrict__ Qb_lo) {
+                                                           __bf16* __restrict__ Qb, __bf16* __restrict__ Qb_lo,
+                                                           float cmax, float* __restrict__ qinv,
+                                                           uint32_t* __restrict__ qflag) {
+  __shared__ float s_m[4];
+  __shared__ int s_bad;
   const int b = blockIdx.x;
   const int t0 = qoff[b], Lq = qoff[b + 1] - t0;
   const int n = dim * LQP;
+  if (threadIdx.x == 0) s_bad = 0;
   for (int i = threadIdx.x; i < n; i += 256) {
     {  // k-major write, coalesced over q
       int k = i / LQP, qq = i - k * LQP;
@@ -72,6 +77,39 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
       Qb_lo[(int64_t)b * n + i] = (__bf16)(v - (float)hi);   // q = hi + lo to ~2^-17 relative
     }
   }
+  // Scale of this query's u8 score table (S4 upper-bound filter): every finite Q.C^T value obeys
+  // |QC[q,c]| <= (1 + 128 * 2^-24) * ||q|| * ||c|| <= s = 1.001 * max_q ||q|| * cmax (Cauchy-Schwarz; the f32 norms and
+  // the k-ordered FMA chain are each within ~1e-5 relative).  qinv = 1 / s; a query with a non-finite value is flagged
+  // and keeps the unfiltered path.
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = 0.f;
+  int bad = 0;
+  for (int qq = wave; qq < Lq; qq += 4) {
+    float ss = 0.f;
+    for (int k = lane; k < dim; k += 64) {
+      const float v = q[(int64_t)(t0 + qq) * dim + k];
+      ss = fmaf(v, v, ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (!finitef(ss)) bad = 1;
+    else mx = fmaxf(mx, ss);
+  }
+  if (lane == 0) {
+    s_m[wave] = mx;
+    if (bad) atomicOr(&s_bad, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && qinv) {
+    const float m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    float sc = sqrtf(m) * cmax * 1.001f;
+    int isbad = s_bad;
+    if (!finitef(sc)) isbad = 1;
+    if (!(sc > 0.f)) sc = 1.0f;   // an all-zero query: every score is 0
+    qinv[b] = isbad ? 0.f : 1.0f / sc;
+    qflag[b] = isbad ? 1u : 0u;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -83,7 +121,9 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
 template <int DIM, int CPW>   // CPW = 32-centroid A fragments per wave
 __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
                                                       const float* __restrict__ Qt, int B, int LQP,
-                                                      float* __restrict__ QCT, uint32_t* __restrict__ gmax) {
+                                                      float* __restrict__ QCT, uint32_t* __restrict__ gmax,
+                                                      uint8_t* __restrict__ QCU, const float* __restrict__ qinv,
+                                                      const int32_t* __restrict__ qoff) {
   // The block's 4 waves walk the same sequence of 32-token query tiles ([DIM][32] f32, k-major).  Tile t+1 is
   // copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers) while tile t feeds
   // the MFMAs as conflict-free ds_read B operands; tile t-1's epilogue (QCT stores, group maxima) is issued
@@ -134,6 +174,20 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
       }
       k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
       if (kk == 0) gmax[((int64_t)b * G + ((c0 >> 5) + f)) * LQP + qt * 32 + li] = k0;
+      if (QCU) {
+        // u8 UPPER bound of every score for the S4 filter: u = floor((x / s + 1) * 127.5) + 1 in [1, 255] (never
+        // clipped: |x| <= s / 1.001), monotone in x, so max over a document's codes commutes with it; 0 marks the
+        // padding tokens q >= Lq.  One LQP-byte row per centroid.
+        const float inv = qinv[b];
+        const bool qv = qt * 32 + li < qoff[b + 1] - qoff[b];
+        uint8_t* o8 = QCU + ((int64_t)b * KP + c0 + 32 * f) * LQP + qt * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float h = fmaf(acc[f][r] * inv, 127.5f, 127.5f);
+          const uint32_t u = qv ? min((uint32_t)h + 1u, 255u) : 0u;
+          o8[(int64_t)mfma_row(r, kk) * LQP] = (uint8_t)u;
+        }
+      }
     }
   };
   if (ntiles > 0) dma_tile(0, 0);
@@ -1014,7 +1068,7 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
     }
   }
   flush(nbuf);
-  if (lane == 0 && toks) {
+  if (lane == 0 && toks && ctr) {
     atomicAdd(&ctr->n_cand_tokens, toks);
     atomicAdd(&ctr->n_cand_codes, ucodes);
   }
@@ -1196,7 +1250,7 @@ __global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict
     toks += __shfl_xor(toks, o);
     ucnt += __shfl_xor(ucnt, o);
   }
-  if (lane == 0 && toks) {
+  if (lane == 0 && toks && ctr) {
     atomicAdd(&ctr->n_cand_tokens, toks);
     atomicAdd(&ctr->n_cand_codes, ucnt);
   }
@@ -1405,10 +1459,207 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
     toks += __shfl_xor(toks, o);
     ucnt += __shfl_xor(ucnt, o);
   }
-  if (lane == 0 && toks) {
+  if (lane == 0 && toks && ctr) {
     atomicAdd(&ctr->n_cand_tokens, toks);
     atomicAdd(&ctr->n_cand_codes, ucnt);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S4, upper-bound filter (ahead of the exact kernels above; selection-preserving).
+// The exact approximate score needs one 128-B f32 table row per (document, distinct code) and one query's f32
+// table (8.4 MB) does not fit an XCD's 4 MB L2.  S1 also writes a u8 table (2 MB per query at Lq <= 32) whose
+// entry is a monotone UPPER bound of the score: u = floor((x / s + 1) * 127.5) + 1.  Monotone, so
+//     U(d) = sum_q max_{c in codes(d)} u[q, c]     (integers, exact)
+// brackets the f32 score:  U - Lq - z <= 127.5 * (approx(d) / s + Lq) <= U + z  with z < 1 covering the rounding
+// of u and of the reference's q-ordered f32 sum.  Hence approx(d1) >= approx(d2)  =>  U(d1) >= U(d2) - (Lq + 2),
+// and every document of the true top n_sel has U >= (n_sel-th largest U) - (Lq + 2): ub_cut_kernel keeps exactly
+// those ("survivors", typically n_sel plus a few hundred) and only they get the exact f32 score, from which S5
+// selects -- the same documents in the same order as without the filter.  Random row gathers run at ~260 G rows/s
+// out of L2 whatever the row size (tools/probes/gather_probe2.hip: the L2 serves one request per channel per
+// clock), vs ~57 G rows/s once they miss it, so the win is the table fitting L2, not the smaller rows.
+// One XCD owns a query (workgroup w -> XCD w % 8); a row is ROWB = LQP bytes = LPD lanes x 16 B, so a wave walks
+// 64 / LPD documents in lockstep, 8 gathers in flight per lane, codes fetched 4 at a time (positions past a
+// document's list repeat one of its own codes: no load is predicated).  Per-byte running maxima are SDWA
+// v_max_u32 on byte lanes.  Queries with a non-finite value (qflag) and queries with <= n_sel candidates skip
+// the filter: all their candidates survive.
+// ---------------------------------------------------------------------------------------------
+#define NP_UB_BINS 8192
+__device__ __forceinline__ uint4 load_codes4(const uint32_t* __restrict__ p) {   // 4-byte aligned 16-byte load
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
+template <int ROWB>
+__global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
+                                                        const uint4* __restrict__ cand_meta,
+                                                        const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
+                                                        int max_rounds, const uint32_t* __restrict__ codes,
+                                                        const uint32_t* __restrict__ qflag, int n_sel,
+                                                        uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift,
+                                                        Counters* ctr) {
+  constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
+  constexpr int DPW = 64 / LPD;    // documents per wave
+  static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128 || ROWB == 256, "row = LQP bytes");
+  __shared__ uint32_t s_hist[NP_UB_BINS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & (LPD - 1), grp = lane / LPD;
+  const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
+  const int64_t stride = (int64_t)NBX * 4 * DPW;
+  const int64_t first = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW + grp;
+  if (round >= rp.round_tab[2 * max_rounds]) return;
+  const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
+  unsigned long long toks = 0, ucnt = 0;
+  for (int b = rb + x; b < re; b += 8) {
+    const int64_t n = n_cand[b];
+    if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
+    const int64_t pbase = rp.cand_base[b];
+    const uint4* metab = cand_meta + pbase;
+    const char* Tb = reinterpret_cast<const char*>(QCU + (int64_t)b * KP * ROWB) + jl * 16;
+    __syncthreads();
+    for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for (int64_t i0 = first - grp; i0 < n; i0 += stride) {   // wave-uniform trip count
+      const int64_t i = i0 + grp;
+      const bool valid = i < n;
+      const uint4 m = metab[valid ? i : n - 1];
+      const int nd = valid ? (int)m.y : 0;
+      const uint32_t* cl = codes + ((int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32));
+      if (valid && jl == 0) {
+        toks += (unsigned long long)(m.w >> 8);
+        ucnt += (unsigned long long)nd;
+      }
+      int nmax = nd;
+#pragma unroll
+      for (int o = LPD; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+      nmax = __builtin_amdgcn_readfirstlane(nmax);
+      uint32_t st[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) st[k] = 0;
+      const int last = max(nd - 1, 0);
+      uint4 na = load_codes4(cl + min(0, last)), nb = load_codes4(cl + min(4, last));
+      for (int t = 0; t < nmax; t += 8) {
+        const uint4 ca = na, cb = nb;
+        if (t + 8 < nmax) {
+          na = load_codes4(cl + min(t + 8, last));
+          nb = load_codes4(cl + min(t + 12, last));
+        }
+        // codes past the end of this document's list fall back to the first code of the load (a valid code of
+        // the same document: min(t, last) <= last)
+        uint32_t c[8];
+        c[0] = ca.x;
+        c[1] = (t + 1 < nd) ? ca.y : ca.x;
+        c[2] = (t + 2 < nd) ? ca.z : ca.x;
+        c[3] = (t + 3 < nd) ? ca.w : ca.x;
+        c[4] = (t + 4 < nd) ? cb.x : ca.x;
+        c[5] = (t + 5 < nd) ? cb.y : ca.x;
+        c[6] = (t + 6 < nd) ? cb.z : ca.x;
+        c[7] = (t + 7 < nd) ? cb.w : ca.x;
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Tb + (size_t)c[k] * ROWB);
+        asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[4 * j + e] = max(st[4 * j + e], (w4[j] >> (8 * e)) & 0xFFu);
+        }
+      }
+      uint32_t sum = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += st[k];
+#pragma unroll
+      for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
+      if (valid && jl == 0) {
+        U[pbase + i] = (uint16_t)sum;
+        atomicAdd(&s_hist[min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+    for (int i = tid; i < NP_UB_BINS; i += 256) {
+      const uint32_t v = s_hist[i];
+      if (v) atomicAdd(&hb[i], v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    toks += __shfl_xor(toks, o);
+    ucnt += __shfl_xor(ucnt, o);
+  }
+  if (lane == 0 && toks && ctr) {
+    atomicAdd(&ctr->n_cand_tokens, toks);
+    atomicAdd(&ctr->n_cand_codes, ucnt);
+  }
+}
+
+// Survivors of the filter: documents whose U is within `slack` of the n_sel-th largest U of their query (see above).
+// grid (blocks per query, B).  Survivor records are appended in arbitrary order at the query's pool base (S5 orders
+// by (score, doc id) itself).
+__global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict__ U, const uint32_t* __restrict__ hist,
+                                                     int hshift, int slack, int n_sel,
+                                                     const uint4* __restrict__ cand_meta,
+                                                     const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
+                                                     const uint32_t* __restrict__ qflag, uint4* __restrict__ surv_meta,
+                                                     int32_t* __restrict__ n_surv, Counters* ctr) {
+  __shared__ uint32_t s_part[256];
+  __shared__ int s_thr;
+  __shared__ unsigned int s_kept;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  if (rp.round_of[b] != round) return;
+  const int64_t n = n_cand[b];
+  const int64_t pbase = rp.cand_base[b];
+  const bool all = qflag[b] != 0 || n <= (int64_t)n_sel;
+  if (tid == 0) {
+    s_thr = 0;
+    s_kept = 0;
+  }
+  if (!all) {
+    // bins from the top: thread t owns bins [(255 - t) * 32, +32); find the bin holding the n_sel-th largest U
+    const uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+    const int top = (255 - tid) * 32;
+    uint32_t mine = 0;
+    for (int k = 0; k < 32; ++k) mine += hb[top + k];
+    s_part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t cum = 0;
+      int t = 0;
+      for (; t < 255; ++t) {
+        if (cum + s_part[t] >= (uint32_t)n_sel) break;
+        cum += s_part[t];
+      }
+      int bin = (255 - t) * 32 + 31;
+      for (; bin > (255 - t) * 32; --bin) {
+        if (cum + hb[bin] >= (uint32_t)n_sel) break;
+        cum += hb[bin];
+      }
+      // bins are U >> hshift: the slack in bins is rounded up
+      s_thr = max(0, bin - ((slack + (1 << hshift) - 1) >> hshift));
+    }
+  }
+  __syncthreads();
+  const uint32_t thr = (uint32_t)s_thr;
+  unsigned int kept = 0;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i0 + tid;
+    const bool keep = i < n && (all || ((uint32_t)U[pbase + i] >> hshift) >= thr);
+    const unsigned long long bal = __ballot(keep);
+    if (bal) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&n_surv[b], (int)__popcll(bal));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (keep) surv_meta[pbase + base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = cand_meta[pbase + i];
+      if (lane == 0) kept += (unsigned int)__popcll(bal);
+    }
+  }
+  if (lane == 0 && kept) atomicAdd(&s_kept, kept);
+  __syncthreads();
+  if (tid == 0 && s_kept) atomicAdd(&ctr->n_survivors, (unsigned long long)s_kept);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1456,33 +1707,44 @@ struct SelectP {
 __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
   extern __shared__ uint64_t s_sel[];
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_rem, s_ngt, s_eqbase;
-  __shared__ uint32_t s_wtot[16];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ uint64_t s_prefix;
+  __shared__ uint32_t s_rem, s_ngt, s_done;
+  const int b = blockIdx.x, tid = threadIdx.x;
   if (p.rp.round_of[b] != p.round) return;
   const int n = p.n_cand[b];
   const float* ap = p.approx + p.rp.cand_base[b];
   const uint32_t* cd = p.cand + p.rp.cand_base[b] * p.cand_step;
   const int cstep = p.cand_step;
   const int nsel = min(p.n_sel, n);
+  // rank key of search.rs:460's stable sort over ascending doc ids: (approx desc [finite first], doc id asc);
+  // doc ids are unique, so the keys are too and the candidates may arrive in any order
+  auto comp_of = [&](int i) {
+    return ((uint64_t)okey(ap[i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + cd[(int64_t)i * cstep]));
+  };
   for (int i = tid; i < p.NSELP; i += 1024) s_sel[i] = 0;
-  if (tid == 0) { s_ngt = 0; s_eqbase = 0; }
+  if (tid == 0) s_ngt = 0;
   __syncthreads();
   if (nsel > 0) {
     if (n <= nsel) {
-      for (int i = tid; i < n; i += 1024)
-        s_sel[i] = ((uint64_t)okey(ap[i]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + cd[(int64_t)i * cstep]));
+      for (int i = tid; i < n; i += 1024) s_sel[i] = comp_of(i);
     } else {
-      if (tid == 0) { s_prefix = 0; s_rem = (uint32_t)nsel; }
+      // radix select of the nsel-th largest 64-bit key, 8 bits per pass from the top; the low word (doc id) is only
+      // walked when the score bits alone leave a tie at the cut
+      if (tid == 0) {
+        s_prefix = 0;
+        s_rem = (uint32_t)nsel;
+        s_done = 0;
+      }
       __syncthreads();
-      for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
+      for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        const uint32_t pre = s_prefix;
+        if (s_done) break;
+        const uint64_t pre = s_prefix;
         for (int i = tid; i < n; i += 1024) {
-          const uint32_t key = okey(ap[i]);
-          if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+          const uint64_t key = comp_of(i);
+          if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (tid == 0) {
@@ -1492,37 +1754,19 @@ __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
             if (cum + hist[bin] >= rem) break;
             cum += hist[bin];
           }
-          s_prefix = (pre << 8) | (uint32_t)bin;
+          s_prefix = (pre << 8) | (uint64_t)bin;
           s_rem = rem - cum;
+          // every key of the cut bin is taken: the remaining (lower) bits cannot matter
+          if (hist[bin] == rem - cum) s_done = (uint32_t)(pass + 1);
         }
         __syncthreads();
       }
-      const uint32_t tau = s_prefix, rem = s_rem;
-      const uint32_t ngt_total = (uint32_t)nsel - rem;
-      for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + tid;
-        const bool in = i < n;
-        const uint32_t key = in ? okey(ap[i]) : 0u;
-        const bool gt = in && key > tau, eq = in && key == tau;
-        // ordered rank among the ties (ascending candidate index == ascending doc id)
-        const unsigned long long bal = __ballot(eq);
-        const uint32_t wrank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wtot[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t before = s_eqbase;
-        for (int k = 0; k < wave; ++k) before += s_wtot[k];
-        const uint32_t rank = before + wrank;
-        const uint64_t comp =
-            ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(p.doc_begin + (in ? cd[(int64_t)i * cstep] : 0u)));
-        if (gt) s_sel[atomicAdd(&s_ngt, 1u)] = comp;
-        if (eq && rank < rem) s_sel[ngt_total + rank] = comp;
-        __syncthreads();
-        if (tid == 0) {
-          uint32_t t = 0;
-          for (int k = 0; k < 16; ++k) t += s_wtot[k];
-          s_eqbase += t;
-        }
-        __syncthreads();
+      const int npass = s_done ? (int)s_done : 8;
+      const uint64_t tau = s_prefix;                 // top 8 * npass bits of the cut
+      const int sh = 64 - 8 * npass;
+      for (int i = tid; i < n; i += 1024) {
+        const uint64_t key = comp_of(i);
+        if ((sh == 0 ? key : (key >> sh)) >= tau) s_sel[atomicAdd(&s_ngt, 1u)] = key;
       }
     }
   }

@@ -15,7 +15,7 @@ namespace np {
 
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
-      cand_base, round_of, round_tab, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
+      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
       subset_bits, elig, misc, cut;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
@@ -23,7 +23,7 @@ struct Workspace {
   bool done_valid = false;
   void release_all() {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &sel_keys, &sel_doc,
+                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &surv_meta, &n_surv, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
                      &cut};
     for (DevBuf* b : all) b->release();
@@ -169,10 +169,11 @@ static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_sear
 
 // ---- workspace plan: one expression set for slicing AND for the reserve() calls ---------------------------------
 // Per-query scratch that scales with the batch (score table, probe bitmaps, doc bitmap, selection) and the
-// candidate pool (NP_POOL_ENTRY bytes per entry: doc id + 16-B record + approximate score), which is sized by the
+// candidate pool (NP_POOL_ENTRY bytes per entry: doc id + 16-B record + approximate score + u16 upper bound + 16-B
+// survivor record), which is sized by the
 // budget, not by n_docs: B x n_docs entries only when that fits workspace_bytes, otherwise what is left of the
 // budget after the per-query scratch (never less than 2 x n_docs entries, one query's worst case twice).
-#define NP_POOL_ENTRY 24
+#define NP_POOL_ENTRY 42
 struct WsPlan {
   int S = 1;            // queries per slice
   int64_t pool = 1;     // candidate-pool entries
@@ -182,7 +183,8 @@ struct WsPlan {
 static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int top_k) {
   const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
   const int64_t nchunks = (NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS;
-  return KP * LQP * 4                      // QCT
+  return KP * LQP * 5                      // QCT (f32) + QCU (u8)
+         + NP_UB_BINS * 4
          + G * LQP * 4 + G * 4             // gmax, cellbits
          + KP * 8                          // cells_tmp, cells
          + (int64_t)LQP * 4                // tauq
@@ -213,15 +215,16 @@ static WsPlan plan_workspace(const DeviceIndex* ix, int B, int LQP, const np_sea
 
 template <int DIM>
 static void launch_gemm(hipStream_t st, const DeviceIndex* ix, const float* Qt, int B, int LQP, float* QCT,
-                        uint32_t* gmax) {
+                        uint32_t* gmax, uint8_t* QCU = nullptr, const float* qinv = nullptr,
+                        const int32_t* qoff = nullptr) {
   // one 32-centroid fragment per wave: 128 centroids per block, ~2 blocks per CU co-resident, so one wave's
   // epilogue (stores, key maxima) hides under another wave's MFMAs.  KP is a multiple of 64.
   if (ix->tune.gemm_cpw == 2) {
     const unsigned blocks = (unsigned)((ix->KP / 64 + 3) / 4);
-    qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax);
+    qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, qinv, qoff);
   } else {
     const unsigned blocks = (unsigned)((ix->KP / 32 + 3) / 4);
-    qc_gemm_kernel<DIM, 1><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax);
+    qc_gemm_kernel<DIM, 1><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, qinv, qoff);
   }
 }
 
@@ -273,7 +276,8 @@ static int launch_exact_nb(hipStream_t st, const DeviceIndex* ix, const ExactP& 
 
 // S4 for the queries of one round: exact f32 approximate scores of `n[b]` records at meta[cand_base[b]...]
 static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, const int32_t* d_qoff, int B, int LQP,
-                          const uint4* meta, const int32_t* n, const RoundPlan& rp, int round, int max_rounds) {
+                          const uint4* meta, const int32_t* n, const RoundPlan& rp, int round, int max_rounds,
+                          Counters* ctr) {
   const Tuning& t = ix->tune;
   const int64_t KP = ix->KP;
   // s4_mode: 0 = all XCDs walk one query (approx_kernel), 1..4 = one XCD per query in 8/4/2/1 phases,
@@ -287,7 +291,7 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
 #define NP_LAUNCH_APPROX_S(LPR)                                                                                       \
   approx_stream_kernel<LPR><<<8 * nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round,          \
                                                      max_rounds, ix->d_ucodes, ix->T, ix->d_useg, w.approx.as<float>(), \
-                                                     t.s4_mode - 5, slice_w, w.ctr.as<Counters>())
+                                                     t.s4_mode - 5, slice_w, ctr)
     if (LQP <= 32) NP_LAUNCH_APPROX_S(8);
     else if (LQP <= 64) NP_LAUNCH_APPROX_S(16);
     else if (LQP <= 128) NP_LAUNCH_APPROX_S(32);
@@ -297,7 +301,7 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
 #define NP_LAUNCH_APPROX_X(LPR, SWZ)                                                                                  \
   approx_xcd_kernel<LPR, SWZ><<<8 * nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round,        \
                                                        max_rounds, ix->d_ucodes, ix->T, ix->d_useg,                   \
-                                                       w.approx.as<float>(), s4_p - 1, w.ctr.as<Counters>())
+                                                       w.approx.as<float>(), s4_p - 1, ctr)
     if (LQP <= 32) {
       if (t.s4_swz) NP_LAUNCH_APPROX_X(8, true);
       else NP_LAUNCH_APPROX_X(8, false);
@@ -309,7 +313,7 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
     const unsigned grid = 768;
 #define NP_LAUNCH_APPROX(LPR)                                                                                          \
   approx_kernel<LPR><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round, max_rounds,         \
-                                           ix->d_ucodes, w.approx.as<float>(), w.ctr.as<Counters>())
+                                           ix->d_ucodes, w.approx.as<float>(), ctr)
     if (LQP <= 32) NP_LAUNCH_APPROX(8);
     else if (LQP <= 64) NP_LAUNCH_APPROX(16);
     else if (LQP <= 128) NP_LAUNCH_APPROX(32);
@@ -373,6 +377,18 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.cand_base.reserve((size_t)B * 8));
   NP_TRY(w.round_of.reserve((size_t)B * 4));
   NP_TRY(w.round_tab.reserve((size_t)(2 * max_rounds + 1) * 4));
+  // S4 upper-bound filter (np_kernels.h): off for debug traces (every candidate keeps its exact score) and for
+  // indices with a non-finite centroid value
+  const bool use_filter = ix->tune.s4_filter && ix->filter_ok && !cs->trace && cs->n_sel > 0 && ix->T > 0;
+  NP_TRY(w.qinv.reserve((size_t)B * 4));
+  NP_TRY(w.qflag.reserve((size_t)B * 4));
+  if (use_filter) {
+    NP_TRY(w.QCU.reserve((size_t)B * KP * LQP));
+    NP_TRY(w.ub.reserve((size_t)pool * 2));
+    NP_TRY(w.ub_hist.reserve((size_t)B * NP_UB_BINS * 4));
+    NP_TRY(w.surv_meta.reserve((size_t)pool * 16));
+    NP_TRY(w.n_surv.reserve((size_t)B * 4));
+  }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
   NP_TRY(w.nsel.reserve((size_t)B * 4));
@@ -393,16 +409,24 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_HIP(hipMemsetAsync(w.tauq.p, 0, (size_t)B * LQP * 4, st));
   if (NW > 0) NP_HIP(hipMemsetAsync(w.docbits.p, 0, (size_t)B * NW * 4, st));
   if (cs->n_sel > 0) NP_HIP(hipMemsetAsync(w.sel_keys.p, 0, (size_t)B * cs->n_sel * 8, st));
+  if (use_filter && B > 0) {
+    NP_HIP(hipMemsetAsync(w.ub_hist.p, 0, (size_t)B * NP_UB_BINS * 4, st));
+    NP_HIP(hipMemsetAsync(w.n_surv.p, 0, (size_t)B * 4, st));
+  }
   if (B == 0) return NP_OK;
 
   // ---- S1
   prep_queries_kernel<<<B, 256, 0, st>>>(d_q, d_qoff, ix->dim, LQP, w.Qt.as<float>(), w.Qb.as<__bf16>(),
-                                         w.Qbl.as<__bf16>());
-  switch (ix->dim) {
-    case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
-    case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
-    case 96: launch_gemm<96>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
-    default: launch_gemm<128>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
+                                         w.Qbl.as<__bf16>(), ix->cmax, w.qinv.as<float>(), w.qflag.as<uint32_t>());
+  {
+    uint8_t* qcu = use_filter ? w.QCU.as<uint8_t>() : nullptr;
+    const float* qinv = w.qinv.as<float>();
+    switch (ix->dim) {
+      case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
+      case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
+      case 96: launch_gemm<96>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
+      default: launch_gemm<128>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
+    }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[1], st));
 
@@ -494,8 +518,33 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
                                                      w.chunk_counts.as<int32_t>(), w.cand.as<uint32_t>(), rp, r,
                                                      ix->d_doc_offsets, ix->d_ulen, w.cand_meta.as<uint4>());
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
-    if (ix->T > 0)
-      launch_approx(st, ix, w, d_qoff, B, LQP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r, max_rounds);
+    if (use_filter) {
+      const int hshift = LQP <= 32 ? 0 : (LQP <= 64 ? 1 : (LQP <= 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
+      const unsigned nbx = (unsigned)ix->tune.s4_nbx;
+#define NP_LAUNCH_UB(ROWB)                                                                                            \
+  approx_ub_kernel<ROWB><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), \
+                                                  rp, r, max_rounds, ix->d_ucodes, w.qflag.as<uint32_t>(), cs->n_sel,  \
+                                                  w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift,              \
+                                                  w.ctr.as<Counters>())
+      if (LQP <= 32) NP_LAUNCH_UB(32);
+      else if (LQP <= 64) NP_LAUNCH_UB(64);
+      else if (LQP <= 128) NP_LAUNCH_UB(128);
+      else NP_LAUNCH_UB(256);
+#undef NP_LAUNCH_UB
+      const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
+      ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift, LQP + 2, cs->n_sel,
+                                                   w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r,
+                                                   w.qflag.as<uint32_t>(), w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(),
+                                                   w.ctr.as<Counters>());
+      // exact f32 approximate scores of the survivors only
+      launch_approx(st, ix, w, d_qoff, B, LQP, w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), rp, r, max_rounds, nullptr);
+      sp.cand = reinterpret_cast<const uint32_t*>(w.surv_meta.p);
+      sp.cand_step = 4;
+      sp.n_cand = w.n_surv.as<int32_t>();
+    } else if (ix->T > 0) {
+      launch_approx(st, ix, w, d_qoff, B, LQP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r, max_rounds,
+                    w.ctr.as<Counters>());
+    }
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
     if (cs->n_sel > 0) {
       sp.round = r;
@@ -1081,7 +1130,7 @@ int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_
     NP_HIP(hipMemcpyAsync(w.q.p, embeddings + t0 * dim, (size_t)nb * dim * 4, hipMemcpyHostToDevice, st));
     NP_HIP(hipMemcpyAsync(w.qoff.p, h_off.data(), (size_t)(Sb + 1) * 4, hipMemcpyHostToDevice, st));
     prep_queries_kernel<<<Sb, 256, 0, st>>>(w.q.as<float>(), w.qoff.as<int32_t>(), dim, LQP, w.Qt.as<float>(),
-                                            w.Qb.as<__bf16>(), w.Qbl.as<__bf16>());
+                                            w.Qb.as<__bf16>(), w.Qbl.as<__bf16>(), 0.f, nullptr, nullptr);
     switch (ix->dim) {
       case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), Sb, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
       case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), Sb, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;

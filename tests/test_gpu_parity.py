@@ -198,6 +198,36 @@ def test_mixed_length_batch_and_slicing(prec):
         assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, rtol_of(prec), f"q{i}")
 
 
+def test_s4_filter_preserves_selection(mid, tuned):
+    """The u8 upper-bound filter in front of S4 must not change WHICH documents are selected nor their order:
+    with top_k = n_sel the whole selected set is returned, so filtered and unfiltered runs must agree bit for bit
+    (ids and exact scores), for plain, ragged-length and non-finite queries; and it must actually prune."""
+    spec, a, ox, hx, qs, src = mid
+    batch = list(qs[:24]) + [qs[30][:7], qs[31][:1]]
+    bad = qs[32].copy()
+    bad[3, 5] = np.nan
+    batch.append(bad)
+    for nfs, nprobe, thr in ((512, 32, None), (2048, 16, 0.4), (64, 64, None)):
+        k = max(nfs // 4, 1)
+        p = P(n_full_scores=nfs, top_k=k, n_ivf_probe=nprobe, centroid_score_threshold=thr)
+        hx.tune("s4_filter", 0)
+        ref = hx.search_batch(batch, p)
+        st0 = dict(hx.last_stats)
+        hx.tune("s4_filter", 1)
+        got = hx.search_batch(batch, p)
+        st1 = dict(hx.last_stats)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert np.array_equal(g.passage_ids, r.passage_ids), f"nfs={nfs} q{i}: selected set / order changed"
+            assert np.array_equal(g.scores, r.scores), f"nfs={nfs} q{i}"
+        assert st1["n_candidates"] == st0["n_candidates"] and st1["n_cand_tokens"] == st0["n_cand_tokens"]
+        assert 0 < st1["n_survivors"] <= st1["n_candidates"]
+        if nfs == 512:
+            assert st1["n_survivors"] < st1["n_candidates"] // 2, st1
+    orc = ox.search_batch(batch[:8], to_oracle_params(p))
+    for g, o in zip(got[:8], orc):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
+
+
 def test_candidate_pool_rounds(mid):
     """The candidate arrays are one pool sized by workspace_bytes, not B x n_docs: a batch whose candidates do not
     fit it together is processed in rounds (first-fit in query order).  A deliberately small budget with a wide probe
