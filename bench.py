@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--query-batches", type=int, default=4)
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded RCCL protocol even with one rank (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--dist-impl", choices=["c", "torch"], default="c",
+                    help="sharded protocol through np_hip_search_batch_sharded (RCCL below the C ABI) or the torch.distributed harness")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin (each step = one full batch pass; the "
                          "small launch-bound kernels of one batch overlap the memory-bound ones of the next)")
@@ -142,9 +144,26 @@ def main():
     L = api.lib()
     cp = prm._c()
 
-    if use_dist:
-        # one searcher per stream, each with its own process group (= its own RCCL communicator), so the two
-        # small all-gathers of batch i overlap the kernels of batch i+1; every rank issues the same round-robin order
+    if use_dist and a.dist_impl == "c":
+        # the whole protocol below the C ABI (np_hip_search_batch_sharded, RCCL all-gathers issued by the library on
+        # the call's stream): one communicator per stream so the collectives of batch i overlap the kernels of batch
+        # i+1; rank 0's ncclUniqueId reaches the other ranks through a torch.distributed broadcast
+        from next_plaid_amd.dist import CShardedSearcher, ShardComm
+
+        def exchange(b):
+            obj = [b]
+            dist.broadcast_object_list(obj, src=0)
+            return obj[0]
+        comms = [ShardComm(ix, rank, world, exchange=exchange if world > 1 else None) for _ in range(nstr)]
+        sss = [CShardedSearcher(ix, comms[s], stream=streams[s]) for s in range(nstr)]
+        ss = sss[0]
+
+        def step(i):
+            s = i % nstr
+            return sss[s].search_batch_device(dq[i % a.query_batches], doff, off, prm, out=(o_ids[s], o_sc[s], o_cnt[s]))
+    elif use_dist:
+        # torch.distributed harness of the same protocol (dist.py): one searcher per stream, each with its own process
+        # group (= its own RCCL communicator); every rank issues the same round-robin order
         from next_plaid_amd.dist import HipShardBackend, ShardedSearcher
         groups = [dist.new_group(ranks=list(range(world))) for _ in range(nstr)]
         sss = [ShardedSearcher([HipShardBackend(ix, stream=streams[s])], use_dist=True, group=groups[s])
@@ -316,7 +335,8 @@ def main():
                                f"n_full_scores={a.n_full_scores}, t_cs={thr}, top_k={a.top_k}; one fixed corpus sharded "
                                f"{world} way(s): {docs_local} docs on rank 0's GPU",
                    "docs_total": a.docs, "docs_per_gpu": docs_local, "batch": a.batch,
-                   "parallelism": f"doc-shard x{world} + RCCL all-gather" if use_dist else "single GPU"},
+                   "parallelism": (f"doc-shard x{world} + RCCL all-gather ({'np_hip_search_batch_sharded' if a.dist_impl == 'c' else 'torch.distributed harness'})"
+                                   if use_dist else "single GPU")},
         "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
         "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stages.items()},
         "index_build_s": round(t_build, 2), "hbm_index_bytes": int(ix.info.device_bytes),

@@ -217,7 +217,17 @@ int np_hip_search_batch_device(const np_index* index, const float* d_queries,
 int np_hip_search_phase_a(const np_index* index, const float* d_queries, const int32_t* d_q_tok_offsets,
                           const int32_t* h_q_tok_offsets, int32_t B, int32_t dim,
                           const np_search_params* params, const int64_t* d_subset, int64_t subset_len,
-                          uint64_t* d_sel_keys, void* stream, void** call_state);
+                          const uint32_t* d_elig_global, uint64_t* d_sel_keys, void* stream, void** call_state);
+/* With a `subset` the dense path restricts the probe to the centroids that occur in the subset's documents and
+ * scales n_ivf_probe by their number (search.rs:350-382).  A document shard only sees its own documents, so for a
+ * result identical to the unsharded search the host ORs the shards' bitmaps: np_hip_subset_eligible writes this
+ * shard's bitmap (np_hip_elig_words() u32 words), the host all-gathers them, np_hip_or_bitmaps combines
+ * d_all[G][words] and the result goes into phase A as d_elig_global (NULL = use the local bitmap: unsharded). */
+int64_t np_hip_elig_words(const np_index* index);
+int np_hip_subset_eligible(const np_index* index, const int64_t* d_subset, int64_t subset_len, uint32_t* d_elig_bits,
+                           void* stream);
+int np_hip_or_bitmaps(const np_index* index, const uint32_t* d_all, int32_t G, int64_t words, uint32_t* d_out,
+                      void* stream);
 int np_hip_search_phase_b(const np_index* index, void* call_state, const uint64_t* d_cut,
                           int64_t* d_out_ids, float* d_out_scores, uint64_t* d_out_keys,
                           int32_t* d_out_counts, void* stream);
@@ -233,6 +243,32 @@ int np_hip_merge_topk(const np_index* index, const int64_t* d_ids, const float* 
                       const uint64_t* d_keys, const int32_t* d_counts, int32_t G, int32_t B,
                       int32_t top_k, int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts,
                       void* stream);
+
+/* The same merge over one packed record per rank: rank g's record starts at d_records + g * record_bytes and holds
+ * ids [B*top_k] i64 at 0, keys [B*top_k] u64 at off_keys, scores [B*top_k] f32 at off_scores, counts [B] i32 at
+ * off_counts (one all-gather instead of four). */
+int np_hip_merge_packed(const np_index* index, const void* d_records, int64_t record_bytes, int64_t off_keys,
+                        int64_t off_scores, int64_t off_counts, int32_t G, int32_t B, int32_t top_k,
+                        int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts, void* stream);
+
+/* ---- the whole sharded protocol in one call, RCCL below the ABI (np_dist.hip) -----------------------------------
+ * One process per GPU.  Every rank opens its document shard (np_open_opts.shard_rank / shard_count = rank / nranks),
+ * rank 0 draws a 128-byte id (np_hip_comm_unique_id = ncclGetUniqueId) and hands it to the others by whatever
+ * channel the host has (the crate: its own RPC / a file; bench.py: a torch.distributed broadcast), every rank calls
+ * np_hip_comm_create (= ncclCommInitRank; collective).  np_hip_search_batch_sharded then runs phase A ->
+ * ncclAllGather(keys) -> cut -> phase B -> ncclAllGather(packed top-k) -> merge on `stream` and leaves the GLOBAL
+ * top-k (identical to the unsharded search, subsets included) in the output buffers of EVERY rank.  All ranks must
+ * call it with the same queries / params / subset in the same order.  librccl is loaded at first use
+ * (dlopen "librccl.so.1"; NEXTPLAID_RCCL_LIB overrides); nranks == 1 with id128 == NULL needs no RCCL at all.
+ * A communicator serialises its calls; use one per concurrent stream. */
+typedef struct np_comm np_comm;
+int np_hip_comm_unique_id(void* id128);
+int np_hip_comm_create(const np_index* index, const void* id128, int32_t rank, int32_t nranks, np_comm** out);
+void np_hip_comm_destroy(np_comm* comm);
+int np_hip_search_batch_sharded(const np_index* index, np_comm* comm, const float* d_queries,
+                                const int32_t* d_q_tok_offsets, const int32_t* h_q_tok_offsets, int32_t B, int32_t dim,
+                                const np_search_params* params, const int64_t* d_subset, int64_t subset_len,
+                                int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts, void* stream);
 
 /* Host-only validation of an index directory: parses and checks every file exactly as np_hip_index_open
  * does (MmapIndex::load, index.rs:1026-1139; NPY headers mmap.rs:659-749; fast-plaid dtypes mmap.rs:1780-1808)

@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(256) subset_kernel(const int64_t* __restrict__
   if (i >= n) return;
   const int64_t d = subset[i] - doc_begin;
   if (d < 0 || d >= n_docs) return;
-  if (lane == 0) atomicOr(&docbits[d >> 5], 1u << (d & 31));
+  if (lane == 0 && docbits) atomicOr(&docbits[d >> 5], 1u << (d & 31));
   if (elig) {
     const int64_t s = doc_off[d], e = doc_off[d + 1];
     for (int64_t t = s + lane; t < e; t += 64) {
@@ -948,19 +948,27 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
   constexpr int RW = 4 * LPR + 1;          // LDS row stride in floats (+1: conflict-free column walks)
   constexpr int DPF = 256 / LPR;         // documents per flush (32 at Lq <= 32): ~17 KB of LDS per block
   __shared__ int64_t s_prefix[NP_S4_MAXB + 1];
+  __shared__ int64_t s_pbase[NP_S4_MAXB];
   __shared__ int s_lq[NP_S4_MAXB];
   __shared__ float s_rows[4][DPF * RW];    // per wave: combined per-token maxima of the last DPF documents
   __shared__ int64_t s_out[4][DPF];        // their output positions
   __shared__ int s_olq[4][DPF];            // and query lengths
-  // queries [rb, re) of this round; their pool positions are a running prefix (cand_base), so candidate w of the
-  // round IS pool entry w
+  // queries [rb, re) of this round: work item w = the (w - s_prefix[b])-th record of query b, stored at pool entry
+  // cand_base[b] + that (the records of a query are contiguous; survivor lists leave gaps between queries)
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], B = rp.round_tab[2 * round + 1] - rb;
   for (int k = threadIdx.x; k < B; k += 256) {
-    s_prefix[k] = rp.cand_base[rb + k];
+    s_pbase[k] = rp.cand_base[rb + k];
     s_lq[k] = qoff[rb + k + 1] - qoff[rb + k];
   }
-  if (threadIdx.x == 0) s_prefix[B] = B > 0 ? rp.cand_base[rb + B - 1] + n_cand[rb + B - 1] : 0;
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int k = 0; k < B; ++k) {
+      s_prefix[k] = run;
+      run += n_cand[rb + k];
+    }
+    s_prefix[B] = run;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jq = lane & (LPR - 1), grp = lane / LPR;   // this lane holds q = 4*jq .. 4*jq+3 of row `grp`
@@ -1003,22 +1011,23 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
   };
   if (w0 < total) {
     locate(w0, b1, i1);
-    m1 = cand_meta[w0];
+    m1 = cand_meta[s_pbase[b1] + i1];
   }
   if (w0 + nw < total) {
     locate(w0 + nw, b2, i2);
-    m2 = cand_meta[w0 + nw];
+    m2 = cand_meta[s_pbase[b2] + i2];
   }
   if (w0 < total) fetch_codes(m1);
   int nbuf = 0;
   for (int64_t w = w0; w < total; w += nw) {
     const uint4 m0 = m1;
     const int b0 = b1;
+    const int64_t i0 = i1;
     const uint32_t creg0 = c1, creg1 = c1b;
     m1 = m2; b1 = b2; i1 = i2;
     if (w + 2 * nw < total) {
       locate(w + 2 * nw, b2, i2);
-      m2 = cand_meta[w + 2 * nw];
+      m2 = cand_meta[s_pbase[b2] + i2];
     }
     if (w + nw < total) fetch_codes(m1);
     const int64_t off = (int64_t)m0.z | ((int64_t)(m0.w & 0xFF) << 32);
@@ -1059,7 +1068,7 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
       r[0] = mx; r[1] = my; r[2] = mz; r[3] = mw;
     }
     if (lane == 0) {
-      s_out[wave][nbuf] = w;
+      s_out[wave][nbuf] = s_pbase[b0] + i0;
       s_olq[wave][nbuf] = s_lq[b0];
     }
     if (++nbuf == DPF) {
@@ -1485,13 +1494,19 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 // the filter: all their candidates survive.
 // ---------------------------------------------------------------------------------------------
 #define NP_UB_BINS 8192
+template <bool NT>
 __device__ __forceinline__ uint4 load_codes4(const uint32_t* __restrict__ p) {   // 4-byte aligned 16-byte load
-  uint4 v;
-  __builtin_memcpy(&v, p, 16);
-  return v;
+  if constexpr (NT) {
+    return make_uint4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
+                      __builtin_nontemporal_load(p + 3));
+  } else {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+  }
 }
 
-template <int ROWB>
+template <int ROWB, bool NT>   // NT: candidate records and code lists are read once -> non-temporal loads
 __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
                                                         const uint4* __restrict__ cand_meta,
                                                         const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
@@ -1523,7 +1538,14 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     for (int64_t i0 = first - grp; i0 < n; i0 += stride) {   // wave-uniform trip count
       const int64_t i = i0 + grp;
       const bool valid = i < n;
-      const uint4 m = metab[valid ? i : n - 1];
+      uint4 m;
+      if constexpr (NT) {
+        const uint32_t* mp = reinterpret_cast<const uint32_t*>(metab + (valid ? i : n - 1));
+        m = make_uint4(__builtin_nontemporal_load(mp), __builtin_nontemporal_load(mp + 1), __builtin_nontemporal_load(mp + 2),
+                       __builtin_nontemporal_load(mp + 3));
+      } else {
+        m = metab[valid ? i : n - 1];
+      }
       const int nd = valid ? (int)m.y : 0;
       const uint32_t* cl = codes + ((int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32));
       if (valid && jl == 0) {
@@ -1538,12 +1560,12 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
 #pragma unroll
       for (int k = 0; k < 16; ++k) st[k] = 0;
       const int last = max(nd - 1, 0);
-      uint4 na = load_codes4(cl + min(0, last)), nb = load_codes4(cl + min(4, last));
+      uint4 na = load_codes4<NT>(cl + min(0, last)), nb = load_codes4<NT>(cl + min(4, last));
       for (int t = 0; t < nmax; t += 8) {
         const uint4 ca = na, cb = nb;
         if (t + 8 < nmax) {
-          na = load_codes4(cl + min(t + 8, last));
-          nb = load_codes4(cl + min(t + 12, last));
+          na = load_codes4<NT>(cl + min(t + 8, last));
+          nb = load_codes4<NT>(cl + min(t + 12, last));
         }
         // codes past the end of this document's list fall back to the first code of the load (a valid code of
         // the same document: min(t, last) <= last)
@@ -1597,54 +1619,64 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   }
 }
 
-// Survivors of the filter: documents whose U is within `slack` of the n_sel-th largest U of their query (see above).
-// grid (blocks per query, B).  Survivor records are appended in arbitrary order at the query's pool base (S5 orders
-// by (score, doc id) itself).
-__global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict__ U, const uint32_t* __restrict__ hist,
-                                                     int hshift, int slack, int n_sel,
-                                                     const uint4* __restrict__ cand_meta,
+// Per query: the histogram bin of the n_sel-th largest U minus the slack (see above) -> thr[b]; 0 keeps everyone
+// (flagged queries, queries with <= n_sel candidates).  One block per query.
+__global__ void __launch_bounds__(256) ub_thr_kernel(const uint32_t* __restrict__ hist, int hshift, int slack, int n_sel,
                                                      const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
-                                                     const uint32_t* __restrict__ qflag, uint4* __restrict__ surv_meta,
-                                                     int32_t* __restrict__ n_surv, Counters* ctr) {
+                                                     const uint32_t* __restrict__ qflag, uint32_t* __restrict__ thr) {
   __shared__ uint32_t s_part[256];
-  __shared__ int s_thr;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (rp.round_of[b] != round) return;
+  if (qflag[b] != 0 || n_cand[b] <= n_sel) {
+    if (tid == 0) thr[b] = 0;
+    return;
+  }
+  // bins from the top: thread t owns bins [(255 - t) * 32, +32)
+  const uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+  const int top = (255 - tid) * 32;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k4 = 0; k4 < 8; ++k4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(hb + top + 4 * k4);
+    mine += v.x + v.y + v.z + v.w;
+  }
+  s_part[tid] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t cum = 0;
+    int t = 0;
+    for (; t < 255; ++t) {
+      if (cum + s_part[t] >= (uint32_t)n_sel) break;
+      cum += s_part[t];
+    }
+    int bin = (255 - t) * 32 + 31;
+    for (; bin > (255 - t) * 32; --bin) {
+      if (cum + hb[bin] >= (uint32_t)n_sel) break;
+      cum += hb[bin];
+    }
+    // bins are U >> hshift: the slack in bins is rounded up
+    thr[b] = (uint32_t)max(0, bin - ((slack + (1 << hshift) - 1) >> hshift));
+  }
+}
+
+// Survivors of the filter: documents whose U bin is >= thr[b].  grid (blocks per query, B).  Survivor records are
+// appended in arbitrary order at the query's pool base (S5 orders by (score, doc id) itself).
+__global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict__ U, const uint32_t* __restrict__ thr_b,
+                                                     int hshift, const uint4* __restrict__ cand_meta,
+                                                     const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
+                                                     uint4* __restrict__ surv_meta, int32_t* __restrict__ n_surv,
+                                                     Counters* ctr) {
   __shared__ unsigned int s_kept;
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   if (rp.round_of[b] != round) return;
   const int64_t n = n_cand[b];
   const int64_t pbase = rp.cand_base[b];
-  const bool all = qflag[b] != 0 || n <= (int64_t)n_sel;
-  if (tid == 0) {
-    s_thr = 0;
-    s_kept = 0;
-  }
-  if (!all) {
-    // bins from the top: thread t owns bins [(255 - t) * 32, +32); find the bin holding the n_sel-th largest U
-    const uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
-    const int top = (255 - tid) * 32;
-    uint32_t mine = 0;
-    for (int k = 0; k < 32; ++k) mine += hb[top + k];
-    s_part[tid] = mine;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t cum = 0;
-      int t = 0;
-      for (; t < 255; ++t) {
-        if (cum + s_part[t] >= (uint32_t)n_sel) break;
-        cum += s_part[t];
-      }
-      int bin = (255 - t) * 32 + 31;
-      for (; bin > (255 - t) * 32; --bin) {
-        if (cum + hb[bin] >= (uint32_t)n_sel) break;
-        cum += hb[bin];
-      }
-      // bins are U >> hshift: the slack in bins is rounded up
-      s_thr = max(0, bin - ((slack + (1 << hshift) - 1) >> hshift));
-    }
-  }
+  const uint32_t thr = thr_b[b];
+  const bool all = thr == 0;
+  if (tid == 0) s_kept = 0;
   __syncthreads();
-  const uint32_t thr = (uint32_t)s_thr;
   unsigned int kept = 0;
+  unsigned long long toks = 0, ucnt = 0;   // work counters of the queries the filter kernel skipped
   for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
     const int64_t i = i0 + tid;
     const bool keep = i < n && (all || ((uint32_t)U[pbase + i] >> hshift) >= thr);
@@ -1653,11 +1685,29 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
       int base = 0;
       if (lane == 0) base = atomicAdd(&n_surv[b], (int)__popcll(bal));
       base = __builtin_amdgcn_readfirstlane(base);
-      if (keep) surv_meta[pbase + base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = cand_meta[pbase + i];
+      if (keep) {
+        const uint4 m = cand_meta[pbase + i];
+        surv_meta[pbase + base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = m;
+        if (all) {
+          toks += (unsigned long long)(m.w >> 8);
+          ucnt += (unsigned long long)m.y;
+        }
+      }
       if (lane == 0) kept += (unsigned int)__popcll(bal);
     }
   }
   if (lane == 0 && kept) atomicAdd(&s_kept, kept);
+  if (all) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      toks += __shfl_xor(toks, o);
+      ucnt += __shfl_xor(ucnt, o);
+    }
+    if (lane == 0 && toks) {
+      atomicAdd(&ctr->n_cand_tokens, toks);
+      atomicAdd(&ctr->n_cand_codes, ucnt);
+    }
+  }
   __syncthreads();
   if (tid == 0 && s_kept) atomicAdd(&ctr->n_survivors, (unsigned long long)s_kept);
 }
@@ -2558,34 +2608,45 @@ __global__ void __launch_bounds__(1024) select_cut_kernel(const uint64_t* __rest
   }
 }
 
-// merge G x top_k triples by (exact desc [finite first], approx key desc); rank by counting
+// out[w] = OR over the G gathered bitmaps (eligible centroids of a subset, search.rs:350-364, across document shards)
+__global__ void or_reduce_kernel(const uint32_t* __restrict__ all, int G, int64_t words, uint32_t* __restrict__ out) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= words) return;
+  uint32_t v = 0;
+  for (int g = 0; g < G; ++g) v |= all[(int64_t)g * words + w];
+  out[w] = v;
+}
+
+// merge G x top_k triples by (exact desc [finite first], approx key desc); rank by counting.  Rank g's arrays start
+// rs_* elements after rank g-1's (contiguous [G][B][top_k] arrays, or one packed record per rank).
 __global__ void __launch_bounds__(256) merge_topk_kernel(const int64_t* __restrict__ ids, const float* __restrict__ scores,
                                                          const uint64_t* __restrict__ keys,
-                                                         const int32_t* __restrict__ counts, int G, int B, int top_k,
-                                                         int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                         int32_t* __restrict__ out_counts) {
+                                                         const int32_t* __restrict__ counts, int64_t rs_ids,
+                                                         int64_t rs_scores, int64_t rs_keys, int64_t rs_counts, int G,
+                                                         int B, int top_k, int64_t* __restrict__ out_ids,
+                                                         float* __restrict__ out_scores, int32_t* __restrict__ out_counts) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = G * top_k;
   int total = 0;
-  for (int g = 0; g < G; ++g) total += counts[g * B + b];
+  for (int g = 0; g < G; ++g) total += counts[g * rs_counts + b];
   for (int i = tid; i < n; i += 256) {
     const int g = i / top_k, j = i - g * top_k;
-    if (j >= counts[g * B + b]) continue;
-    const int64_t e = ((int64_t)g * B + b) * top_k + j;
-    const uint32_t ks = okey(scores[e]);
-    const uint64_t ka = keys[e];
+    if (j >= counts[g * rs_counts + b]) continue;
+    const int64_t e = (int64_t)b * top_k + j;
+    const uint32_t ks = okey(scores[g * rs_scores + e]);
+    const uint64_t ka = keys[g * rs_keys + e];
     int rank = 0;
     for (int g2 = 0; g2 < G; ++g2) {
-      const int c2 = counts[g2 * B + b];
+      const int c2 = counts[g2 * rs_counts + b];
       for (int j2 = 0; j2 < c2; ++j2) {
-        const int64_t e2 = ((int64_t)g2 * B + b) * top_k + j2;
-        const uint32_t ks2 = okey(scores[e2]);
-        if (ks2 > ks || (ks2 == ks && keys[e2] > ka)) ++rank;
+        const int64_t e2 = (int64_t)b * top_k + j2;
+        const uint32_t ks2 = okey(scores[g2 * rs_scores + e2]);
+        if (ks2 > ks || (ks2 == ks && keys[g2 * rs_keys + e2] > ka)) ++rank;
       }
     }
     if (rank < top_k) {
-      out_ids[(int64_t)b * top_k + rank] = ids[e];
-      out_scores[(int64_t)b * top_k + rank] = scores[e];
+      out_ids[(int64_t)b * top_k + rank] = ids[g * rs_ids + e];
+      out_scores[(int64_t)b * top_k + rank] = scores[g * rs_scores + e];
     }
   }
   if (tid == 0) out_counts[b] = min(top_k, total);

@@ -15,7 +15,7 @@ namespace np {
 
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
-      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
+      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
       subset_bits, elig, misc, cut;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
@@ -23,7 +23,7 @@ struct Workspace {
   bool done_valid = false;
   void release_all() {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &surv_meta, &n_surv, &sel_keys, &sel_doc,
+                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &surv_meta, &n_surv, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
                      &cut};
     for (DevBuf* b : all) b->release();
@@ -115,6 +115,7 @@ struct CallState {
   bool empty_subset = false;
   bool timed = false;
   bool trace = false;   // debug_trace: every candidate keeps its exact approximate score
+  const uint32_t* elig_global = nullptr;   // sharded + subset: eligible-centroid bitmap OR-ed over all shards (search.rs:350-364)
 };
 
 static int next_pow2(int v) {
@@ -388,6 +389,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     NP_TRY(w.ub_hist.reserve((size_t)B * NP_UB_BINS * 4));
     NP_TRY(w.surv_meta.reserve((size_t)pool * 16));
     NP_TRY(w.n_surv.reserve((size_t)B * 4));
+    NP_TRY(w.ub_thr.reserve((size_t)B * 4));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -434,20 +436,25 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   const bool have_subset = subset_len > 0;
   const bool batched = prm.centroid_batch_size > 0 && ix->K > prm.centroid_batch_size;  // search.rs:337
   const bool use_elig = have_subset && !batched;
+  const uint32_t* elig_bits = nullptr;
   if (have_subset) {
     NP_TRY(w.subset_bits.reserve((size_t)std::max<int64_t>(NW, 1) * 4));
     NP_TRY(w.elig.reserve((size_t)G * 4));
     NP_HIP(hipMemsetAsync(w.subset_bits.p, 0, (size_t)std::max<int64_t>(NW, 1) * 4, st));
     NP_HIP(hipMemsetAsync(w.elig.p, 0, (size_t)G * 4, st));
+    // a document shard sees only its own documents' codes: the sharded host ORs the shards' bitmaps
+    // (np_hip_subset_eligible + one small all-gather) and hands the global one in
+    const bool local_elig = use_elig && !cs->elig_global;
     subset_kernel<<<(unsigned)((subset_len + 3) / 4), 256, 0, st>>>(
         d_subset, subset_len, ix->doc_begin, ix->n_docs, ix->d_doc_offsets, ix->d_codes, w.subset_bits.as<uint32_t>(),
-        use_elig ? w.elig.as<uint32_t>() : nullptr);
+        local_elig ? w.elig.as<uint32_t>() : nullptr);
     if (use_elig) {
-      subset_nprobe_kernel<<<1, 256, 0, st>>>(w.elig.as<uint32_t>(), G, prm.n_ivf_probe, ix->N_total, subset_len,
+      elig_bits = cs->elig_global ? cs->elig_global : w.elig.as<uint32_t>();
+      subset_nprobe_kernel<<<1, 256, 0, st>>>(elig_bits, G, prm.n_ivf_probe, ix->N_total, subset_len,
                                               w.misc.as<int32_t>(), w.misc.as<int32_t>() + 1);
       // the probe prunes by group maxima: restrict them to the eligible centroids
-      masked_gmax_kernel<<<dim3((unsigned)((G + 3) / 4), B), 256, 0, st>>>(w.QCT.as<float>(), KP, ix->K, LQP,
-                                                                           w.elig.as<uint32_t>(), w.gmax.as<uint32_t>());
+      masked_gmax_kernel<<<dim3((unsigned)((G + 3) / 4), B), 256, 0, st>>>(w.QCT.as<float>(), KP, ix->K, LQP, elig_bits,
+                                                                           w.gmax.as<uint32_t>());
     }
   }
 
@@ -462,7 +469,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     pp.LQP = LQP;
     pp.nprobe = prm.n_ivf_probe;
     pp.nprobe_dev = use_elig ? w.misc.as<int32_t>() + 1 : nullptr;
-    pp.elig = use_elig ? w.elig.as<uint32_t>() : nullptr;
+    pp.elig = use_elig ? elig_bits : nullptr;
     pp.n_elig = use_elig ? w.misc.as<int32_t>() : nullptr;
     pp.has_thr = prm.has_threshold;
     pp.thr = prm.centroid_score_threshold;
@@ -521,21 +528,29 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     if (use_filter) {
       const int hshift = LQP <= 32 ? 0 : (LQP <= 64 ? 1 : (LQP <= 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
       const unsigned nbx = (unsigned)ix->tune.s4_nbx;
-#define NP_LAUNCH_UB(ROWB)                                                                                            \
-  approx_ub_kernel<ROWB><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), \
-                                                  rp, r, max_rounds, ix->d_ucodes, w.qflag.as<uint32_t>(), cs->n_sel,  \
-                                                  w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift,              \
-                                                  w.ctr.as<Counters>())
-      if (LQP <= 32) NP_LAUNCH_UB(32);
-      else if (LQP <= 64) NP_LAUNCH_UB(64);
-      else if (LQP <= 128) NP_LAUNCH_UB(128);
-      else NP_LAUNCH_UB(256);
+#define NP_LAUNCH_UB(ROWB, NT)                                                                                        \
+  approx_ub_kernel<ROWB, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),                \
+                                                      w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,         \
+                                                      w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),           \
+                                                      w.ub_hist.as<uint32_t>(), hshift, w.ctr.as<Counters>())
+      if (ix->tune.ub_nt) {
+        if (LQP <= 32) NP_LAUNCH_UB(32, true);
+        else if (LQP <= 64) NP_LAUNCH_UB(64, true);
+        else if (LQP <= 128) NP_LAUNCH_UB(128, true);
+        else NP_LAUNCH_UB(256, true);
+      } else {
+        if (LQP <= 32) NP_LAUNCH_UB(32, false);
+        else if (LQP <= 64) NP_LAUNCH_UB(64, false);
+        else if (LQP <= 128) NP_LAUNCH_UB(128, false);
+        else NP_LAUNCH_UB(256, false);
+      }
 #undef NP_LAUNCH_UB
+      ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
+                                       w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
       const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
-      ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift, LQP + 2, cs->n_sel,
+      ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), w.ub_thr.as<uint32_t>(), hshift,
                                                    w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r,
-                                                   w.qflag.as<uint32_t>(), w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(),
-                                                   w.ctr.as<Counters>());
+                                                   w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), w.ctr.as<Counters>());
       // exact f32 approximate scores of the survivors only
       launch_approx(st, ix, w, d_qoff, B, LQP, w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), rp, r, max_rounds, nullptr);
       sp.cand = reinterpret_cast<const uint32_t*>(w.surv_meta.p);
@@ -826,8 +841,8 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
 // ---- document-sharded two-phase call -------------------------------------------------------------------
 int np_hip_search_phase_a(const np_index* ix, const float* d_queries, const int32_t* d_q_tok_offsets,
                           const int32_t* h_q_tok_offsets, int32_t B, int32_t dim, const np_search_params* params,
-                          const int64_t* d_subset, int64_t subset_len, uint64_t* d_sel_keys, void* stream,
-                          void** call_state) {
+                          const int64_t* d_subset, int64_t subset_len, const uint32_t* d_elig_global,
+                          uint64_t* d_sel_keys, void* stream, void** call_state) {
   clear_error();
   if (!call_state) {
     set_error("Search failed: call_state is NULL");
@@ -856,6 +871,7 @@ int np_hip_search_phase_a(const np_index* ix, const float* d_queries, const int3
   }
   cs->B = B;
   cs->prm = *params;
+  cs->elig_global = d_elig_global;
   rc = begin_use(cs, stream);
   if (rc == NP_OK) rc = phase_a(ix, cs, d_queries, d_q_tok_offsets, h_q_tok_offsets, d_subset, subset_len);
   if (rc == NP_OK && cs->n_sel > 0 && B > 0) {
@@ -914,6 +930,38 @@ void np_hip_search_end(const np_index* ix, void* call_state) {
   delete cs;
 }
 
+int64_t np_hip_elig_words(const np_index* ix) { return ix ? ix->KP / 32 : 0; }
+
+int np_hip_subset_eligible(const np_index* ix, const int64_t* d_subset, int64_t subset_len, uint32_t* d_elig_bits,
+                           void* stream) {
+  clear_error();
+  if (!ix || !d_elig_bits || (subset_len > 0 && !d_subset)) {
+    set_error("subset_eligible: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g(ix->device);
+  hipStream_t st = (hipStream_t)stream;
+  NP_HIP(hipMemsetAsync(d_elig_bits, 0, (size_t)(ix->KP / 32) * 4, st));
+  if (subset_len > 0)
+    subset_kernel<<<(unsigned)((subset_len + 3) / 4), 256, 0, st>>>(d_subset, subset_len, ix->doc_begin, ix->n_docs,
+                                                                     ix->d_doc_offsets, ix->d_codes, nullptr, d_elig_bits);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+int np_hip_or_bitmaps(const np_index* ix, const uint32_t* d_all, int32_t G, int64_t words, uint32_t* d_out, void* stream) {
+  clear_error();
+  if (!ix || !d_all || !d_out || G < 1 || words < 0) {
+    set_error("or_bitmaps: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (words == 0) return NP_OK;
+  DeviceGuard g(ix->device);
+  or_reduce_kernel<<<(unsigned)((words + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_all, G, words, d_out);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
 int np_hip_select_cut(const np_index* ix, const uint64_t* d_all_keys, int32_t G, int32_t B, int32_t n_sel,
                       uint64_t* d_cut, void* stream) {
   clear_error();
@@ -947,8 +995,32 @@ int np_hip_merge_topk(const np_index* ix, const int64_t* d_ids, const float* d_s
   }
   if (B == 0) return NP_OK;
   DeviceGuard g(ix->device);
-  merge_topk_kernel<<<B, 256, 0, (hipStream_t)stream>>>(d_ids, d_scores, d_keys, d_counts, G, B, top_k, d_out_ids,
-                                                        d_out_scores, d_out_counts);
+  const int64_t rs = (int64_t)B * top_k;
+  merge_topk_kernel<<<B, 256, 0, (hipStream_t)stream>>>(d_ids, d_scores, d_keys, d_counts, rs, rs, rs, B, G, B, top_k,
+                                                        d_out_ids, d_out_scores, d_out_counts);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+// Same merge over one PACKED record per rank (what np_hip_search_batch_sharded all-gathers): rank g's record starts at
+// d_records + g * record_bytes and holds ids at 0, keys at off_keys, scores at off_scores, counts at off_counts.
+int np_hip_merge_packed(const np_index* ix, const void* d_records, int64_t record_bytes, int64_t off_keys,
+                        int64_t off_scores, int64_t off_counts, int32_t G, int32_t B, int32_t top_k, int64_t* d_out_ids,
+                        float* d_out_scores, int32_t* d_out_counts, void* stream) {
+  clear_error();
+  if (!ix || !d_records || !d_out_counts || G < 1 || B < 0 || top_k < 0 || (record_bytes & 7) || (off_keys & 7) ||
+      (off_scores & 3) || (off_counts & 3)) {
+    set_error("merge_packed: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return NP_OK;
+  DeviceGuard g(ix->device);
+  const char* r = (const char*)d_records;
+  merge_topk_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const int64_t*)r, (const float*)(r + off_scores),
+                                                        (const uint64_t*)(r + off_keys), (const int32_t*)(r + off_counts),
+                                                        record_bytes / 8, record_bytes / 4, record_bytes / 8,
+                                                        record_bytes / 4, G, B, top_k, d_out_ids, d_out_scores,
+                                                        d_out_counts);
   NP_HIP(hipGetLastError());
   return NP_OK;
 }

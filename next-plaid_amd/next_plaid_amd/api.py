@@ -111,6 +111,8 @@ EXPORTS = [
     "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_tune", "np_hip_index_close",
     "np_hip_index_info", "np_hip_index_probe_dir", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
     "np_hip_search_phase_b", "np_hip_search_end", "np_hip_n_sel", "np_hip_select_cut", "np_hip_merge_topk",
+    "np_hip_merge_packed", "np_hip_elig_words", "np_hip_subset_eligible", "np_hip_or_bitmaps",
+    "np_hip_comm_unique_id", "np_hip_comm_create", "np_hip_comm_destroy", "np_hip_search_batch_sharded",
     "np_hip_decompress_documents", "np_hip_encode_tokens", "np_hip_rerank_maxsim", "np_hip_debug_trace",
 ]
 
@@ -171,8 +173,19 @@ def lib():
                                       C.POINTER(np_stats)]
     L.np_hip_search_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,
                                              vp, vp, vp, vp]
-    L.np_hip_search_phase_a.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64, vp, vp,
+    L.np_hip_search_phase_a.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64, vp, vp, vp,
                                         C.POINTER(vp)]
+    L.np_hip_elig_words.argtypes = [vp]
+    L.np_hip_elig_words.restype = i64
+    L.np_hip_subset_eligible.argtypes = [vp, vp, i64, vp, vp]
+    L.np_hip_or_bitmaps.argtypes = [vp, vp, i32, i64, vp, vp]
+    L.np_hip_merge_packed.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.np_hip_comm_unique_id.argtypes = [vp]
+    L.np_hip_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.np_hip_comm_destroy.argtypes = [vp]
+    L.np_hip_comm_destroy.restype = None
+    L.np_hip_search_batch_sharded.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,
+                                              vp, vp, vp, vp]
     L.np_hip_search_phase_b.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.np_hip_search_end.argtypes = [vp, vp]
     L.np_hip_search_end.restype = None

@@ -43,10 +43,22 @@ class HipShardBackend:
     def n_sel(self, params):
         return int(api.lib().np_hip_n_sel(C.byref(params._c())))
 
+    def num_partitions(self):
+        return self.index.num_partitions()
+
     def _stream(self):
         return C.c_void_p(self.stream.cuda_stream)
 
-    def phase_a(self, d_q, d_qoff, h_qoff, params):
+    def eligible(self, d_subset):
+        """This shard's eligible-centroid bitmap for a subset (search.rs:350-364), u32 words as an int32 tensor."""
+        t = self.torch
+        words = int(api.lib().np_hip_elig_words(self.index._h))
+        bits = t.zeros(max(words, 1), dtype=t.int32, device=self.device)
+        api._check(api.lib().np_hip_subset_eligible(self.index._h, C.c_void_p(d_subset.data_ptr()), d_subset.numel(),
+                                                    C.c_void_p(bits.data_ptr()), self._stream()))
+        return bits
+
+    def phase_a(self, d_q, d_qoff, h_qoff, params, d_subset=None, elig=None):
         t = self.torch
         B = len(h_qoff) - 1
         ns = max(self.n_sel(params), 1)
@@ -56,7 +68,9 @@ class HipShardBackend:
         hq = np.ascontiguousarray(h_qoff, np.int32)
         api._check(api.lib().np_hip_search_phase_a(
             self.index._h, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_qoff.data_ptr()), hq.ctypes.data_as(C.c_void_p),
-            B, self.index.embedding_dim(), C.byref(p), None, -1, C.c_void_p(keys.data_ptr()), self._stream(),
+            B, self.index.embedding_dim(), C.byref(p),
+            None if d_subset is None else C.c_void_p(d_subset.data_ptr()), -1 if d_subset is None else d_subset.numel(),
+            None if elig is None else C.c_void_p(elig.data_ptr()), C.c_void_p(keys.data_ptr()), self._stream(),
             C.byref(st)))
         return keys[:, : self.n_sel(params)], (st, B, params)
 
@@ -131,22 +145,43 @@ class ShardedSearcher:
         dist.all_gather(out, local.contiguous(), group=self.group)
         return self.torch.cat(out, 0)
 
-    def search_batch_device(self, d_q, d_qoff, h_qoff, params):
+    def search_batch_device(self, d_q, d_qoff, h_qoff, params, d_subset=None):
         """Queries already resident on every shard's device (the host broadcasts them).
-        d_q / d_qoff: one tensor per local backend (or a single tensor when there is one)."""
+        d_q / d_qoff (/ d_subset, global i64 doc ids): one tensor per local backend (or a single tensor when there is one)."""
         with self.backends[0].stream_ctx():
-            return self._search(d_q, d_qoff, h_qoff, params)
+            return self._search(d_q, d_qoff, h_qoff, params, d_subset)
 
-    def _search(self, d_q, d_qoff, h_qoff, params):
+    def _global_eligible(self, subs, params):
+        """OR of the shards' eligible-centroid bitmaps: one more small all-gather, only with a subset on the dense
+        path (the batched path just filters candidates, search.rs:542-545).  Identical on every shard."""
+        K = getattr(self.backends[0], "num_partitions", None)
+        cbs = params.centroid_batch_size
+        if subs is None or (K is not None and cbs > 0 and K() > cbs):
+            return None
+        if any(s.numel() == 0 for s in subs):
+            return None
+        t = self.torch
+        local = t.stack([be.eligible(s).to(self.backends[0].device) for be, s in zip(self.backends, subs)], 0)
+        allb = self._all_gather(local)
+        glob = allb[0].clone()
+        for g in range(1, allb.shape[0]):
+            glob |= allb[g]
+        return glob
+
+    def _search(self, d_q, d_qoff, h_qoff, params, d_subset=None):
         t = self.torch
         single = not isinstance(d_q, (list, tuple))
         dqs = [d_q] if single else list(d_q)
         dos = [d_qoff] if single else list(d_qoff)
+        subs = None if d_subset is None else ([d_subset] * len(self.backends) if not isinstance(d_subset, (list, tuple))
+                                              else list(d_subset))
+        glob = self._global_eligible(subs, params)
         keys, states = [], []
         packed = []
         try:
-            for be, q, o in zip(self.backends, dqs, dos):   # inside the try: a failing shard must not strand the others' contexts
-                k, st = be.phase_a(q, o, h_qoff, params)
+            for i, (be, q, o) in enumerate(zip(self.backends, dqs, dos)):   # inside the try: a failing shard must not strand the others' contexts
+                k, st = be.phase_a(q, o, h_qoff, params, None if subs is None else subs[i],
+                                   None if glob is None else glob.to(be.device))
                 keys.append(k)
                 states.append(st)
             all_keys = self._all_gather(t.stack([k.to(keys[0].device) for k in keys], 0))
@@ -159,7 +194,7 @@ class ShardedSearcher:
         all_packed = self._all_gather(t.stack([p.to(packed[0].device) for p in packed], 0))
         return self.backends[0].merge(all_packed.to(self.backends[0].device), params.top_k)
 
-    def search_batch(self, queries, params):
+    def search_batch(self, queries, params, subset=None):
         """Host-side convenience: numpy queries in, list of QueryResult out (rank-identical)."""
         t = self.torch
         qs = [np.ascontiguousarray(q, np.float32) for q in queries]
@@ -169,6 +204,80 @@ class ShardedSearcher:
         with self.backends[0].stream_ctx():
             dq = [t.from_numpy(flat).to(be.device) for be in self.backends]
             do = [t.from_numpy(off).to(be.device) for be in self.backends]
-            ids, sc, cnt = self._search(dq, do, off, params)
+            ds = None if subset is None else [t.from_numpy(np.ascontiguousarray(subset, np.int64)).to(be.device)
+                                              for be in self.backends]
+            ids, sc, cnt = self._search(dq, do, off, params, ds)
+            ids, sc, cnt = ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        return [api.QueryResult(i, ids[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(len(qs))]
+
+
+class ShardComm:
+    """np_comm: the RCCL communicator of the C-level sharded entry point (np_hip_comm_*, np_dist.hip).  The 128-byte
+    id is drawn on rank 0 and handed to the other ranks by `exchange` (a callable bytes -> bytes that broadcasts rank
+    0's value; bench.py uses a torch.distributed broadcast).  world 1 with rccl=False needs no RCCL at all."""
+
+    def __init__(self, index: "api.MmapIndex", rank: int = 0, world: int = 1, exchange=None, rccl: bool = True):
+        L = api.lib()
+        idbuf = None
+        if rccl:
+            idbuf = C.create_string_buffer(128)
+            if rank == 0:
+                api._check(L.np_hip_comm_unique_id(idbuf))
+            if exchange is not None:
+                idbuf = C.create_string_buffer(exchange(bytes(idbuf.raw)), 128)
+        self._h = C.c_void_p()
+        self.index = index
+        api._check(L.np_hip_comm_create(index._h, idbuf, rank, world, C.byref(self._h)))
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            api.lib().np_hip_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CShardedSearcher:
+    """The whole two-collective protocol through ONE C call per batch (np_hip_search_batch_sharded): what a compiled
+    host uses.  Outputs are torch tensors on the shard's device; every rank gets the global top-k."""
+
+    def __init__(self, index: "api.MmapIndex", comm: ShardComm, stream=None):
+        import torch
+        self.torch = torch
+        self.index, self.comm = index, comm
+        self.device = torch.device("cuda", index.info.device)
+        self.stream = torch.cuda.Stream(self.device) if stream is None else stream
+
+    def search_batch_device(self, d_q, d_qoff, h_qoff, params, d_subset=None, out=None):
+        t = self.torch
+        B, k = len(h_qoff) - 1, max(params.top_k, 1)
+        if out is None:
+            with t.cuda.stream(self.stream):
+                out = (t.zeros((B, k), dtype=t.int64, device=self.device), t.zeros((B, k), dtype=t.float32, device=self.device),
+                       t.zeros(B, dtype=t.int32, device=self.device))
+        p = params._c()
+        hq = np.ascontiguousarray(h_qoff, np.int32)
+        api._check(api.lib().np_hip_search_batch_sharded(
+            self.index._h, self.comm._h, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_qoff.data_ptr()),
+            hq.ctypes.data_as(C.c_void_p), B, self.index.embedding_dim(), C.byref(p),
+            None if d_subset is None else C.c_void_p(d_subset.data_ptr()), -1 if d_subset is None else d_subset.numel(),
+            C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()),
+            C.c_void_p(self.stream.cuda_stream)))
+        return out
+
+    def search_batch(self, queries, params, subset=None):
+        t = self.torch
+        qs = [np.ascontiguousarray(q, np.float32) for q in queries]
+        off = np.zeros(len(qs) + 1, np.int32)
+        off[1:] = np.cumsum([q.shape[0] for q in qs])
+        with t.cuda.stream(self.stream):
+            dq = t.from_numpy(np.concatenate(qs, 0)).to(self.device)
+            do = t.from_numpy(off).to(self.device)
+            ds = None if subset is None else t.from_numpy(np.ascontiguousarray(subset, np.int64)).to(self.device)
+            ids, sc, cnt = self.search_batch_device(dq, do, off, params, ds)
             ids, sc, cnt = ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
         return [api.QueryResult(i, ids[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(len(qs))]

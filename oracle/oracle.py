@@ -84,6 +84,10 @@ def lib():
         L.po_search_one.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_Params), C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Trace)]
         L.po_search_one.restype = C.c_int
+        L.po_search_one_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_Params), C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(_Trace)]
+        L.po_search_one_shard.restype = C.c_int
         L.po_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(_Params), C.c_int,
                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.po_search_many.restype = C.c_int
@@ -268,7 +272,9 @@ class OracleIndex:
         s, e = self.doc_offsets[doc_id], self.doc_offsets[doc_id + 1]
         return decompress(self.residuals[s:e], self.codes[s:e], self.centroids, self.bucket_weights, self.nbits)
 
-    def search(self, query, params: SearchParameters, subset=None, trace=False) -> QueryResult:
+    def search(self, query, params: SearchParameters, subset=None, trace=False, shard_view=None) -> QueryResult:
+        """shard_view = (eligible u8[K], n_total, subset_len_total): this index is ONE document shard and `subset`
+        holds its local ids (tests/shard_oracle_backend.py only)."""
         q = _f32(query)
         if q.ndim != 2 or q.shape[1] != self.d:
             raise ValueError(f"Shape error: query {q.shape} vs dim {self.d}")
@@ -287,9 +293,16 @@ class OracleIndex:
                         sel_exact=np.zeros(nfs, np.float32))
             tr = _Trace(0, _ptr(bufs["cells"]), 0, _ptr(bufs["cand"]), _ptr(bufs["approx"]), 0,
                         _ptr(bufs["sel"]), _ptr(bufs["sel_exact"]), 0, 0, 0, 0)
-        rc = lib().po_search_one(self._h, _ptr(q), q.shape[0], C.byref(p), _ptr(sub),
-                                 -1 if sub is None else sub.size, _ptr(ids), _ptr(sc), C.byref(cnt),
-                                 C.byref(tr) if tr is not None else None)
+        if shard_view is not None:
+            el = np.ascontiguousarray(shard_view[0], np.uint8)
+            rc = lib().po_search_one_shard(self._h, _ptr(q), q.shape[0], C.byref(p), _ptr(sub),
+                                           -1 if sub is None else sub.size, _ptr(el), int(shard_view[1]),
+                                           int(shard_view[2]), _ptr(ids), _ptr(sc), C.byref(cnt),
+                                           C.byref(tr) if tr is not None else None)
+        else:
+            rc = lib().po_search_one(self._h, _ptr(q), q.shape[0], C.byref(p), _ptr(sub),
+                                     -1 if sub is None else sub.size, _ptr(ids), _ptr(sc), C.byref(cnt),
+                                     C.byref(tr) if tr is not None else None)
         if rc:
             raise RuntimeError(f"Search failed: invalid parameters (rc={rc})")
         n = cnt.value

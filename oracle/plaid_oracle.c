@@ -591,9 +591,14 @@ static int po_rank_and_rescore(const po_index* ix, const float* Q, int64_t Lq, c
 /* ------------------------------------------------------------------------- */
 /* dense path: search.rs:327-516                                              */
 /* ------------------------------------------------------------------------- */
+/* Document-shard view (no reference counterpart; used only by tests/shard_oracle_backend.py to emulate ONE shard of
+ * the sharded protocol): the eligible-centroid set, N and |subset| of search.rs:350-382 are those of the WHOLE index,
+ * handed in, while `subset` holds the shard-local ids.  NULL = plain reference behaviour. */
+typedef struct { const uint8_t* eligible; int64_t n_total; int64_t subset_len; } po_shard_view;
+
 static int po_search_dense(const po_index* ix, const float* Q, int64_t Lq, const po_params* p,
                            const int64_t* subset, int64_t subset_len, int64_t* out_ids,
-                           float* out_scores, int32_t* out_count, po_trace* tr) {
+                           float* out_scores, int32_t* out_count, po_trace* tr, const po_shard_view* sv) {
   const int64_t K = ix->K, N = ix->N;
   *out_count = 0;
   float* qc = (float*)malloc(sizeof(float) * (size_t)(Lq * K > 0 ? Lq * K : 1));
@@ -604,6 +609,9 @@ static int po_search_dense(const po_index* ix, const float* Q, int64_t Lq, const
   int64_t n_eligible = 0;
   if (subset_len >= 0) {
     eligible = (uint8_t*)calloc((size_t)(K > 0 ? K : 1), 1);
+    if (sv && sv->eligible) {
+      for (int64_t c = 0; c < K; ++c) if (sv->eligible[c]) { eligible[c] = 1; ++n_eligible; }
+    } else
     for (int64_t i = 0; i < subset_len; ++i) {
       int64_t doc = subset[i];
       if (doc >= 0 && doc < N) { /* `doc_id as usize < len`; negative wraps to huge */
@@ -618,7 +626,8 @@ static int po_search_dense(const po_index* ix, const float* Q, int64_t Lq, const
   int64_t eff = p->n_ivf_probe;
   if (eligible && n_eligible > 0) {
     int64_t scaled = p->n_ivf_probe;
-    if (subset_len > 0) scaled = (int64_t)((uint64_t)p->n_ivf_probe * (uint64_t)N / (uint64_t)subset_len);
+    const int64_t n_all = sv ? sv->n_total : N, sl_all = sv ? sv->subset_len : subset_len;
+    if (sl_all > 0) scaled = (int64_t)((uint64_t)p->n_ivf_probe * (uint64_t)n_all / (uint64_t)sl_all);
     if (scaled < p->n_ivf_probe) scaled = p->n_ivf_probe;
     if (scaled > n_eligible) scaled = n_eligible;
     eff = scaled;
@@ -825,7 +834,22 @@ PO_API int po_search_one(const po_index* ix, const float* Q, int64_t Lq, const p
   int use_batched = p->centroid_batch_size > 0 && ix->K > p->centroid_batch_size; /* :337 */
   if (tr) tr->used_batched = use_batched;
   if (use_batched) return po_search_batched(ix, Q, Lq, p, subset, subset_len, out_ids, out_scores, out_count, tr);
-  return po_search_dense(ix, Q, Lq, p, subset, subset_len, out_ids, out_scores, out_count, tr);
+  return po_search_dense(ix, Q, Lq, p, subset, subset_len, out_ids, out_scores, out_count, tr, NULL);
+}
+
+/* One document shard's view of a subset search (see po_shard_view): eligible[K] / n_total / subset_len_total are
+ * the whole index's; `subset` holds this shard's local ids. */
+PO_API int po_search_one_shard(const po_index* ix, const float* Q, int64_t Lq, const po_params* p,
+                               const int64_t* subset, int64_t subset_len, const uint8_t* eligible, int64_t n_total,
+                               int64_t subset_len_total, int64_t* out_ids, float* out_scores, int32_t* out_count,
+                               po_trace* tr) {
+  *out_count = 0;
+  if (p->n_ivf_probe < 1 || p->top_k < 0 || p->n_full_scores < 0) return 2;
+  int use_batched = p->centroid_batch_size > 0 && ix->K > p->centroid_batch_size;
+  if (tr) tr->used_batched = use_batched;
+  if (use_batched) return po_search_batched(ix, Q, Lq, p, subset, subset_len, out_ids, out_scores, out_count, tr);
+  po_shard_view sv = { eligible, n_total, subset_len_total };
+  return po_search_dense(ix, Q, Lq, p, subset, subset_len, out_ids, out_scores, out_count, tr, &sv);
 }
 
 /* search.rs:643-675 search_many_mmap.  queries concatenated row-major, tok_off[B+1].

@@ -31,14 +31,39 @@ class OracleShardBackend:
         s = shard_arrays(a, b0, b1)
         self.ix = O.OracleIndex(s["centroids"], s["bucket_weights"], s["ivf"], s["ivf_lengths"], s["doc_lengths"],
                                 s["codes"], s["residuals"], s["nbits"])
-        self.b0 = b0
+        self.b0, self.b1 = b0, b1
+        self.n_total = int(a["doc_lengths"].size)
+        self.K = int(a["centroids"].shape[0])
+        self.codes, self.off = s["codes"], np.concatenate([[0], np.cumsum(s["doc_lengths"])])
         self.device = torch.device("cpu")
+
+    def num_partitions(self):
+        return self.K
+
+    def eligible(self, d_subset):
+        """np_hip_subset_eligible: bitmap (u32 words as int32) of the codes of this shard's subset documents."""
+        sub = d_subset.numpy()
+        loc = sub[(sub >= self.b0) & (sub < self.b1)] - self.b0
+        words = (self.K + 63) // 64 * 2
+        bits = np.zeros(words, np.uint32)
+        for d in loc:
+            c = self.codes[self.off[d]:self.off[d + 1]].astype(np.int64)
+            np.bitwise_or.at(bits, c >> 5, (np.uint32(1) << (c & 31).astype(np.uint32)))
+        return torch.from_numpy(bits.view(np.int32).copy())
 
     def stream_ctx(self):
         return contextlib.nullcontext()
 
-    def phase_a(self, d_q, d_qoff, h_qoff, params):
+    def phase_a(self, d_q, d_qoff, h_qoff, params, d_subset=None, elig=None):
         q = d_q.numpy()
+        sub = view = None
+        if d_subset is not None:
+            g = d_subset.numpy()
+            sub = (g[(g >= self.b0) & (g < self.b1)] - self.b0).astype(np.int64)
+            if elig is not None:
+                w = elig.numpy().view(np.uint32)
+                el = ((w[np.arange(self.K) >> 5] >> (np.arange(self.K) & 31).astype(np.uint32)) & 1).astype(np.uint8)
+                view = (el, self.n_total, int(g.size))
         B, ns = len(h_qoff) - 1, n_sel_of(params)
         keys = np.zeros((B, max(ns, 1)), np.uint64)
         per_q = []
@@ -48,7 +73,7 @@ class OracleShardBackend:
                                   centroid_score_threshold=params.centroid_score_threshold)
         for b in range(B):
             qb = q[h_qoff[b]:h_qoff[b + 1]]
-            t = self.ix.search(qb, wide, trace=True).trace
+            t = self.ix.search(qb, wide, sub, trace=True, shard_view=view).trace
             k = np.sort(rank_keys(t.approx, t.cand + self.b0))[::-1][:ns]
             keys[b, :k.size] = k
             per_q.append((qb, k))

