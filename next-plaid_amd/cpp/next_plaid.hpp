@@ -10,10 +10,24 @@
 //   index.search_batch(queries, params, parallel, subset)  index.rs:1279  -> query_id = batch position
 //   SearchParameters (defaults search.rs:58-69), QueryResult (search.rs:71-80), Error (error.rs:9-66)
 //
-// Header-only; link with -lnextplaid_hip.  No CPU fallback lives here: DeviceUnavailable is an Error.
+// Accelerator policy (the crate's precedent for its CUDA feature, lib.rs:71-84 and cuda.rs:52-182):
+//   NEXT_PLAID_FORCE_GPU=1|true   a device failure is an Error, never a fallback            (is_force_gpu)
+//   NEXT_PLAID_FORCE_CPU=1|true   the HIP library is not touched at all (unless FORCE_GPU)  (is_force_cpu)
+//   is_hip_broken / mark_hip_broken / clear_hip_broken: once DeviceUnavailable / OutOfMemory is seen the flag makes
+//   every later call skip the device until it is cleared (CUDA_BROKEN, get_global_context's fast path).
+// The CPU implementation itself is the crate's existing Rust path; here it is a hook (set_cpu_fallback) that the
+// DeviceUnavailable hand-off calls -- this header ships NO CPU search of its own, and with no hook installed a
+// device failure stays an Error (nothing is papered over).
+//
+// Header-only; link with -lnextplaid_hip.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -33,6 +47,28 @@ struct Error : std::runtime_error {  // error.rs:9-66
 inline void check(int rc) {
   if (rc != NP_OK) throw Error(rc, np_hip_last_error());
 }
+
+// ---- accelerator policy: lib.rs:71-84 -----------------------------------------------------------------------
+inline bool env_flag(const char* name) {
+  const char* v = std::getenv(name);
+  if (!v) return false;
+  if (std::strcmp(v, "1") == 0) return true;
+  std::string s(v);
+  std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+  return s == "true";
+}
+inline bool is_force_gpu() { return env_flag("NEXT_PLAID_FORCE_GPU"); }
+inline bool is_force_cpu() { return !is_force_gpu() && env_flag("NEXT_PLAID_FORCE_CPU"); }
+
+// ---- broken flag: cuda.rs:52-182 ----------------------------------------------------------------------------------
+inline std::atomic<bool>& hip_broken_flag() {
+  static std::atomic<bool> f{false};
+  return f;
+}
+inline bool is_hip_broken() { return hip_broken_flag().load(std::memory_order_relaxed); }
+inline void mark_hip_broken() { hip_broken_flag().store(true, std::memory_order_relaxed); }
+inline void clear_hip_broken() { hip_broken_flag().store(false, std::memory_order_relaxed); }
+inline bool is_device_failure(int rc) { return rc == NP_ERR_DEVICE_UNAVAILABLE || rc == NP_ERR_OUT_OF_MEMORY; }
 
 struct SearchParameters {  // search.rs:26-69
   size_t batch_size = 2000;
@@ -68,14 +104,37 @@ struct Query {
   size_t n_tokens;
 };
 
+// The CPU path a device failure hands off to (in the crate: search::search_many_mmap on the mmap'ed index).
+using CpuSearchFn = std::function<std::vector<QueryResult>(const std::string& index_path, const Query* queries, size_t n,
+                                                           size_t dim, const SearchParameters& params, bool parallel,
+                                                           const std::vector<int64_t>* subset)>;
+inline CpuSearchFn& cpu_fallback() {
+  static CpuSearchFn f;
+  return f;
+}
+inline void set_cpu_fallback(CpuSearchFn f) { cpu_fallback() = std::move(f); }
+
 class MmapIndex {
  public:
   // MmapIndex::load (index.rs:1026).  `opts` selects the device / document shard.
+  // Policy: FORCE_CPU or a raised broken flag never touch the device (the handle stays empty and searches go to the
+  // CPU hook); a device failure raises the flag and falls back unless FORCE_GPU; every other error is the caller's.
   static MmapIndex load(const std::string& index_path, const np_open_opts* opts = nullptr) {
+    if ((is_force_cpu() || (is_hip_broken() && !is_force_gpu())) && cpu_fallback()) return MmapIndex(nullptr, index_path);
     np_index* h = nullptr;
-    check(np_hip_index_open(index_path.c_str(), opts, &h));
+    const int rc = np_hip_index_open(index_path.c_str(), opts, &h);
+    if (is_device_failure(rc)) {
+      mark_hip_broken();
+      if (!is_force_gpu() && cpu_fallback()) {
+        std::fprintf(stderr, "[next-plaid] HIP device unavailable: %s. Falling back to CPU. Set NEXT_PLAID_FORCE_CPU=1 to "
+                             "skip the GPU and silence this warning.\n", np_hip_last_error());
+        return MmapIndex(nullptr, index_path);
+      }
+    }
+    check(rc);
     return MmapIndex(h, index_path);
   }
+  bool on_device() const { return h_ != nullptr; }
   MmapIndex(MmapIndex&& o) noexcept : path(std::move(o.path)), h_(o.h_), info_(o.info_) { o.h_ = nullptr; }
   MmapIndex& operator=(MmapIndex&& o) noexcept {
     if (this != &o) {
@@ -104,6 +163,7 @@ class MmapIndex {
   // parallel = true a failing search yields empty results instead of an error (search.rs:656-660).
   std::vector<QueryResult> search_batch(const Query* queries, size_t n, const SearchParameters& params, bool parallel,
                                         const std::vector<int64_t>* subset = nullptr) const {
+    if (!h_) return cpu_search(queries, n, params, parallel, subset);
     const size_t dim = embedding_dim();
     std::vector<int32_t> off(n + 1, 0);
     for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int32_t)queries[i].n_tokens;
@@ -121,6 +181,10 @@ class MmapIndex {
     std::vector<QueryResult> out(n);
     for (size_t i = 0; i < n; ++i) out[i].query_id = i;
     if (rc != NP_OK) {
+      if (is_device_failure(rc)) {   // mid-flight device loss: flag it, hand this call to the CPU unless FORCE_GPU
+        mark_hip_broken();
+        if (!is_force_gpu() && cpu_fallback()) return cpu_search(queries, n, params, parallel, subset);
+      }
       if (parallel && rc == NP_ERR_SEARCH) return out;
       check(rc);
     }
@@ -169,9 +233,17 @@ class MmapIndex {
 
   std::string path;
   mutable np_stats last_stats{};
+  size_t cpu_dim = 0;   // embedding dim for the CPU hand-off when no device handle exists (set by the caller)
 
  private:
-  MmapIndex(np_index* h, std::string p) : path(std::move(p)), h_(h) { check(np_hip_index_info(h_, &info_)); }
+  MmapIndex(np_index* h, std::string p) : path(std::move(p)), h_(h) {
+    if (h_) check(np_hip_index_info(h_, &info_));
+  }
+  std::vector<QueryResult> cpu_search(const Query* queries, size_t n, const SearchParameters& params, bool parallel,
+                                      const std::vector<int64_t>* subset) const {
+    if (!cpu_fallback()) throw Error(NP_ERR_DEVICE_UNAVAILABLE, "HIP device unavailable and no CPU fallback installed");
+    return cpu_fallback()(path, queries, n, h_ ? embedding_dim() : cpu_dim, params, parallel, subset);
+  }
   void close() {
     if (h_) np_hip_index_close(h_);
     h_ = nullptr;

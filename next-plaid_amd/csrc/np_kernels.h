@@ -122,8 +122,8 @@ template <int DIM, int CPW>   // CPW = 32-centroid A fragments per wave
 __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
                                                       const float* __restrict__ Qt, int B, int LQP,
                                                       float* __restrict__ QCT, uint32_t* __restrict__ gmax,
-                                                      uint8_t* __restrict__ QCU, const float* __restrict__ qinv,
-                                                      const int32_t* __restrict__ qoff) {
+                                                      uint8_t* __restrict__ QCU, int RB /* u8 row bytes: power of two >= LQP */,
+                                                      const float* __restrict__ qinv, const int32_t* __restrict__ qoff) {
   // The block's 4 waves walk the same sequence of 32-token query tiles ([DIM][32] f32, k-major).  Tile t+1 is
   // copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers) while tile t feeds
   // the MFMAs as conflict-free ds_read B operands; tile t-1's epilogue (QCT stores, group maxima) is issued
@@ -177,15 +177,15 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
       if (QCU) {
         // u8 UPPER bound of every score for the S4 filter: u = floor((x / s + 1) * 127.5) + 1 in [1, 255] (never
         // clipped: |x| <= s / 1.001), monotone in x, so max over a document's codes commutes with it; 0 marks the
-        // padding tokens q >= Lq.  One LQP-byte row per centroid.
+        // padding tokens q >= Lq.  One RB-byte row per centroid (bytes LQP .. RB-1 are zeroed by the host).
         const float inv = qinv[b];
         const bool qv = qt * 32 + li < qoff[b + 1] - qoff[b];
-        uint8_t* o8 = QCU + ((int64_t)b * KP + c0 + 32 * f) * LQP + qt * 32 + li;
+        uint8_t* o8 = QCU + ((int64_t)b * KP + c0 + 32 * f) * RB + qt * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float h = fmaf(acc[f][r] * inv, 127.5f, 127.5f);
           const uint32_t u = qv ? min((uint32_t)h + 1u, 255u) : 0u;
-          o8[(int64_t)mfma_row(r, kk) * LQP] = (uint8_t)u;
+          o8[(int64_t)mfma_row(r, kk) * RB] = (uint8_t)u;
         }
       }
     }
@@ -1494,19 +1494,10 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 // the filter: all their candidates survive.
 // ---------------------------------------------------------------------------------------------
 #define NP_UB_BINS 8192
-template <bool NT>
-__device__ __forceinline__ uint4 load_codes4(const uint32_t* __restrict__ p) {   // 4-byte aligned 16-byte load
-  if constexpr (NT) {
-    return make_uint4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
-                      __builtin_nontemporal_load(p + 3));
-  } else {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-  }
-}
+#define NP_UB_NBX 96       // workgroups per XCD: 3 per CU (48 KB of LDS each)
 
-template <int ROWB, bool NT>   // NT: candidate records and code lists are read once -> non-temporal loads
+// CT = uint16_t when every code fits 16 bits (K <= 65536), else uint32_t.
+template <int ROWB, typename CT>
 __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
                                                         const uint4* __restrict__ cand_meta,
                                                         const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
@@ -1516,41 +1507,51 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         Counters* ctr) {
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
-  static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128 || ROWB == 256, "row = LQP bytes");
-  __shared__ uint32_t s_hist[NP_UB_BINS];
+  constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // distinct codes of one document staged per pass (32 KB of LDS per
+                                                    // workgroup either way; longer lists take further passes)
+  constexpr int CPS = CAP / 32;                     // codes a staging lane loads (half a wave per document)
+  static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128 || ROWB == 256, "row = power-of-two bytes >= LQP");
+  // A document's distinct-code list is read from memory ONCE, coalesced, into LDS (half a wave per document, 16 B
+  // per lane), and the gathers take their codes from there.  (Reading it 16 B at a time per lane as the walk
+  // proceeds keeps ~3 lines per document live for the whole walk -- 6 MB per XCD next to the 2 MB table: measured
+  // 30 M L2 misses and 8x over-fetch per launch.)
+  __shared__ uint32_t s_hist[NP_UB_BINS / 2];          // two u16 counters per word (a block sees < 65536 docs per query)
+  __shared__ CT s_codes[4][DPW][CAP];
+  __shared__ int64_t s_cl[4][DPW];
+  __shared__ int s_nd[4][DPW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
   const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
   const int64_t stride = (int64_t)NBX * 4 * DPW;
-  const int64_t first = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW + grp;
+  const int64_t first = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW;
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
   unsigned long long toks = 0, ucnt = 0;
+  const int half = lane >> 5, hl = lane & 31;   // staging: half-wave `half` loads 4 codes per lane of one document
   for (int b = rb + x; b < re; b += 8) {
     const int64_t n = n_cand[b];
     if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
     const int64_t pbase = rp.cand_base[b];
     const uint4* metab = cand_meta + pbase;
     const char* Tb = reinterpret_cast<const char*>(QCU + (int64_t)b * KP * ROWB) + jl * 16;
+    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+    const bool big = n / NBX >= 60000;   // a block could see >= 2^16 documents of one bin: count in memory instead
     __syncthreads();
-    for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
+    for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
     __syncthreads();
-    for (int64_t i0 = first - grp; i0 < n; i0 += stride) {   // wave-uniform trip count
+    for (int64_t i0 = first; i0 < n; i0 += stride) {   // wave-uniform trip count
       const int64_t i = i0 + grp;
       const bool valid = i < n;
-      uint4 m;
-      if constexpr (NT) {
-        const uint32_t* mp = reinterpret_cast<const uint32_t*>(metab + (valid ? i : n - 1));
-        m = make_uint4(__builtin_nontemporal_load(mp), __builtin_nontemporal_load(mp + 1), __builtin_nontemporal_load(mp + 2),
-                       __builtin_nontemporal_load(mp + 3));
-      } else {
-        m = metab[valid ? i : n - 1];
-      }
+      const uint4 m = metab[valid ? i : n - 1];
       const int nd = valid ? (int)m.y : 0;
-      const uint32_t* cl = codes + ((int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32));
-      if (valid && jl == 0) {
-        toks += (unsigned long long)(m.w >> 8);
-        ucnt += (unsigned long long)nd;
+      const int64_t cl = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
+      if (jl == 0) {
+        s_cl[wave][grp] = cl;
+        s_nd[wave][grp] = nd;
+        if (valid) {
+          toks += (unsigned long long)(m.w >> 8);
+          ucnt += (unsigned long long)nd;
+        }
       }
       int nmax = nd;
 #pragma unroll
@@ -1559,36 +1560,61 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
       uint32_t st[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) st[k] = 0;
-      const int last = max(nd - 1, 0);
-      uint4 na = load_codes4<NT>(cl + min(0, last)), nb = load_codes4<NT>(cl + min(4, last));
-      for (int t = 0; t < nmax; t += 8) {
-        const uint4 ca = na, cb = nb;
-        if (t + 8 < nmax) {
-          na = load_codes4<NT>(cl + min(t + 8, last));
-          nb = load_codes4<NT>(cl + min(t + 12, last));
+      for (int p0 = 0; p0 < nmax; p0 += CAP) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();     // s_cl / s_nd written, the previous pass's codes consumed
+        // ---- stage codes [p0, p0 + CAP) of every document of the wave; positions past a list hold the list's
+        // first code (a duplicate cannot change a max), so the walk below is unpredicated
+#pragma unroll 4
+        for (int s0 = 0; s0 < DPW; s0 += 2) {
+          const int sl = s0 + half;
+          const int nds = s_nd[wave][sl];
+          const uint32_t* cp = codes + s_cl[wave][sl];
+          const int pos = p0 + CPS * hl;
+          uint32_t cv[4] = {0, 0, 0, 0};
+          uint32_t c0 = 0;
+          if (nds > 0) {
+            c0 = cp[0];
+            if (pos < nds) __builtin_memcpy(cv, cp + pos, 4 * CPS);   // 4-byte aligned load; the array is padded by 4 entries
+          }
+#pragma unroll
+          for (int k = 0; k < CPS; ++k)
+            if (pos + k >= nds) cv[k] = c0;
+          CT* dst = &s_codes[wave][sl][CPS * hl];
+          if constexpr (sizeof(CT) == 2) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(cv[0] | (cv[1] << 16), cv[2] | (cv[3] << 16));
+          } else {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(cv[0], cv[1]);
+          }
         }
-        // codes past the end of this document's list fall back to the first code of the load (a valid code of
-        // the same document: min(t, last) <= last)
-        uint32_t c[8];
-        c[0] = ca.x;
-        c[1] = (t + 1 < nd) ? ca.y : ca.x;
-        c[2] = (t + 2 < nd) ? ca.z : ca.x;
-        c[3] = (t + 3 < nd) ? ca.w : ca.x;
-        c[4] = (t + 4 < nd) ? cb.x : ca.x;
-        c[5] = (t + 5 < nd) ? cb.y : ca.x;
-        c[6] = (t + 6 < nd) ? cb.z : ca.x;
-        c[7] = (t + 7 < nd) ? cb.w : ca.x;
-        uint4 v[8];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- walk: 8 gathers in flight per lane
+        const int np = min(CAP, nmax - p0);
+        const CT* mine = &s_codes[wave][grp][0];
+        for (int t = 0; t < np; t += 8) {
+          uint32_t c[8];
+          if constexpr (sizeof(CT) == 2) {
+            const uint4 cw = *reinterpret_cast<const uint4*>(mine + t);
+            c[0] = cw.x & 0xFFFFu; c[1] = cw.x >> 16; c[2] = cw.y & 0xFFFFu; c[3] = cw.y >> 16;
+            c[4] = cw.z & 0xFFFFu; c[5] = cw.z >> 16; c[6] = cw.w & 0xFFFFu; c[7] = cw.w >> 16;
+          } else {
+            const uint4 ca = *reinterpret_cast<const uint4*>(mine + t), cb = *reinterpret_cast<const uint4*>(mine + t + 4);
+            c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w;
+            c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
+          }
+          uint4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Tb + (size_t)c[k] * ROWB);
-        asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
+          for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Tb + (size_t)c[k] * ROWB);
+          asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[4 * j + e] = max(st[4 * j + e], (w4[j] >> (8 * e)) & 0xFFu);
+              for (int e = 0; e < 4; ++e) st[4 * j + e] = max(st[4 * j + e], (w4[j] >> (8 * e)) & 0xFFu);
+          }
         }
       }
       uint32_t sum = 0;
@@ -1598,14 +1624,17 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
       for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
       if (valid && jl == 0) {
         U[pbase + i] = (uint16_t)sum;
-        atomicAdd(&s_hist[min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
+        const uint32_t bin = min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1));
+        if (big) atomicAdd(&hb[bin], 1u);
+        else atomicAdd(&s_hist[bin >> 1], 1u << (16 * (bin & 1)));
       }
+      __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next one
     }
     __syncthreads();
-    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
-    for (int i = tid; i < NP_UB_BINS; i += 256) {
+    for (int i = tid; i < NP_UB_BINS / 2; i += 256) {
       const uint32_t v = s_hist[i];
-      if (v) atomicAdd(&hb[i], v);
+      if (v & 0xFFFFu) atomicAdd(&hb[2 * i], v & 0xFFFFu);
+      if (v >> 16) atomicAdd(&hb[2 * i + 1], v >> 16);
     }
   }
 #pragma unroll
@@ -1613,7 +1642,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     toks += __shfl_xor(toks, o);
     ucnt += __shfl_xor(ucnt, o);
   }
-  if (lane == 0 && toks && ctr) {
+  if (lane == 0 && toks) {
     atomicAdd(&ctr->n_cand_tokens, toks);
     atomicAdd(&ctr->n_cand_codes, ucnt);
   }

@@ -184,7 +184,7 @@ struct WsPlan {
 static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int top_k) {
   const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
   const int64_t nchunks = (NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS;
-  return KP * LQP * 5                      // QCT (f32) + QCU (u8)
+  return KP * LQP * 6                      // QCT (f32) + QCU (u8, rows padded to a power of two)
          + NP_UB_BINS * 4
          + G * LQP * 4 + G * 4             // gmax, cellbits
          + KP * 8                          // cells_tmp, cells
@@ -216,16 +216,16 @@ static WsPlan plan_workspace(const DeviceIndex* ix, int B, int LQP, const np_sea
 
 template <int DIM>
 static void launch_gemm(hipStream_t st, const DeviceIndex* ix, const float* Qt, int B, int LQP, float* QCT,
-                        uint32_t* gmax, uint8_t* QCU = nullptr, const float* qinv = nullptr,
+                        uint32_t* gmax, uint8_t* QCU = nullptr, int RB = 0, const float* qinv = nullptr,
                         const int32_t* qoff = nullptr) {
   // one 32-centroid fragment per wave: 128 centroids per block, ~2 blocks per CU co-resident, so one wave's
   // epilogue (stores, key maxima) hides under another wave's MFMAs.  KP is a multiple of 64.
   if (ix->tune.gemm_cpw == 2) {
     const unsigned blocks = (unsigned)((ix->KP / 64 + 3) / 4);
-    qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, qinv, qoff);
+    qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, RB, qinv, qoff);
   } else {
     const unsigned blocks = (unsigned)((ix->KP / 32 + 3) / 4);
-    qc_gemm_kernel<DIM, 1><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, qinv, qoff);
+    qc_gemm_kernel<DIM, 1><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, RB, qinv, qoff);
   }
 }
 
@@ -381,10 +381,11 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   // S4 upper-bound filter (np_kernels.h): off for debug traces (every candidate keeps its exact score) and for
   // indices with a non-finite centroid value
   const bool use_filter = ix->tune.s4_filter && ix->filter_ok && !cs->trace && cs->n_sel > 0 && ix->T > 0;
+  const int RB = LQP <= 32 ? 32 : (LQP <= 64 ? 64 : (LQP <= 128 ? 128 : 256));   // u8 table row bytes
   NP_TRY(w.qinv.reserve((size_t)B * 4));
   NP_TRY(w.qflag.reserve((size_t)B * 4));
   if (use_filter) {
-    NP_TRY(w.QCU.reserve((size_t)B * KP * LQP));
+    NP_TRY(w.QCU.reserve((size_t)B * KP * RB));
     NP_TRY(w.ub.reserve((size_t)pool * 2));
     NP_TRY(w.ub_hist.reserve((size_t)B * NP_UB_BINS * 4));
     NP_TRY(w.surv_meta.reserve((size_t)pool * 16));
@@ -414,6 +415,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   if (use_filter && B > 0) {
     NP_HIP(hipMemsetAsync(w.ub_hist.p, 0, (size_t)B * NP_UB_BINS * 4, st));
     NP_HIP(hipMemsetAsync(w.n_surv.p, 0, (size_t)B * 4, st));
+    if (RB != LQP) NP_HIP(hipMemsetAsync(w.QCU.p, 0, (size_t)B * KP * RB, st));   // row bytes LQP .. RB-1 stay 0
   }
   if (B == 0) return NP_OK;
 
@@ -424,10 +426,10 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     uint8_t* qcu = use_filter ? w.QCU.as<uint8_t>() : nullptr;
     const float* qinv = w.qinv.as<float>();
     switch (ix->dim) {
-      case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
-      case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
-      case 96: launch_gemm<96>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
-      default: launch_gemm<128>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, qinv, d_qoff); break;
+      case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, RB, qinv, d_qoff); break;
+      case 64: launch_gemm<64>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, RB, qinv, d_qoff); break;
+      case 96: launch_gemm<96>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, RB, qinv, d_qoff); break;
+      default: launch_gemm<128>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, RB, qinv, d_qoff); break;
     }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[1], st));
@@ -526,23 +528,23 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
                                                      ix->d_doc_offsets, ix->d_ulen, w.cand_meta.as<uint4>());
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
     if (use_filter) {
-      const int hshift = LQP <= 32 ? 0 : (LQP <= 64 ? 1 : (LQP <= 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
-      const unsigned nbx = (unsigned)ix->tune.s4_nbx;
-#define NP_LAUNCH_UB(ROWB, NT)                                                                                        \
-  approx_ub_kernel<ROWB, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),                \
+      const int hshift = RB == 32 ? 0 : (RB == 64 ? 1 : (RB == 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
+      const unsigned nbx = NP_UB_NBX;
+#define NP_LAUNCH_UB(ROWB, CT)                                                                                        \
+  approx_ub_kernel<ROWB, CT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),                \
                                                       w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,         \
                                                       w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),           \
                                                       w.ub_hist.as<uint32_t>(), hshift, w.ctr.as<Counters>())
-      if (ix->tune.ub_nt) {
-        if (LQP <= 32) NP_LAUNCH_UB(32, true);
-        else if (LQP <= 64) NP_LAUNCH_UB(64, true);
-        else if (LQP <= 128) NP_LAUNCH_UB(128, true);
-        else NP_LAUNCH_UB(256, true);
+      if (ix->K <= 65536) {
+        if (RB == 32) NP_LAUNCH_UB(32, uint16_t);
+        else if (RB == 64) NP_LAUNCH_UB(64, uint16_t);
+        else if (RB == 128) NP_LAUNCH_UB(128, uint16_t);
+        else NP_LAUNCH_UB(256, uint16_t);
       } else {
-        if (LQP <= 32) NP_LAUNCH_UB(32, false);
-        else if (LQP <= 64) NP_LAUNCH_UB(64, false);
-        else if (LQP <= 128) NP_LAUNCH_UB(128, false);
-        else NP_LAUNCH_UB(256, false);
+        if (RB == 32) NP_LAUNCH_UB(32, uint32_t);
+        else if (RB == 64) NP_LAUNCH_UB(64, uint32_t);
+        else if (RB == 128) NP_LAUNCH_UB(128, uint32_t);
+        else NP_LAUNCH_UB(256, uint32_t);
       }
 #undef NP_LAUNCH_UB
       ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
