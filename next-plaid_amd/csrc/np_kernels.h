@@ -514,9 +514,10 @@ __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
   }
 }
 
+#define NP_PROBE_NF 8   // probe_finish workgroups per query (each owns 1/NF of the marked-cell bitmap)
 __global__ void __launch_bounds__(256) probe_finish_kernel(ProbeP p) {
-  __shared__ uint32_t s_ntmp, s_nfinal;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ uint32_t s_ntmp, s_nfinal, s_obase;
+  const int b = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int Lq = p.qoff[b + 1] - p.qoff[b];
   const int64_t G = p.KP >> 5;
@@ -529,9 +530,11 @@ __global__ void __launch_bounds__(256) probe_finish_kernel(ProbeP p) {
   const uint32_t n_probe = (uint32_t)min(eff, pool);
   if (tid == 0) { s_ntmp = 0; s_nfinal = 0; }
   __syncthreads();
-  // ---- compact the marked cells
-  uint32_t* tmp = p.cells_tmp + (int64_t)b * p.KP;
-  for (int64_t w = tid; w < G; w += 256) {
+  // ---- compact the marked cells of this workgroup's slice of the bitmap (words [w_lo, w_hi))
+  const int64_t wper = (G + NP_PROBE_NF - 1) / NP_PROBE_NF;
+  const int64_t w_lo = (int64_t)f * wper, w_hi = min(G, w_lo + wper);
+  uint32_t* tmp = p.cells_tmp + (int64_t)b * p.KP + w_lo * 32;   // at most 32 cells per word: the slice cannot overflow
+  for (int64_t w = w_lo + tid; w < w_hi; w += 256) {
     uint32_t m = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (m) {
       const int bit = __ffs(m) - 1;
@@ -542,36 +545,51 @@ __global__ void __launch_bounds__(256) probe_finish_kernel(ProbeP p) {
   __syncthreads();
   // ---- threshold.
   // dense path (search.rs:417-425): keep c iff finite-first max_q QC[q,c] >= t_cs; max_by keeps the
-  //   LAST of equal maxima, so an all-non-finite column yields QC[Lq-1, c].
+  //   LAST of equal maxima, so an all-non-finite column yields QC[Lq-1, c].  One LANE per cell.
   // batched path (search.rs:184-196,243-251): the max runs only over (q,c) pairs that were ever
   //   pushed into token q's slab-local heap: pushed <=> fewer than n_probe earlier centroids of the
   //   same slab score >= QC[q,c].  Pairs inside token q's global top-n_probe are always pushed, so
-  //   the slab prefix is only counted for a token with QC[q,c] >= t_cs outside its top-n_probe.
+  //   the slab prefix is only counted for a token with QC[q,c] >= t_cs outside its top-n_probe.  One WAVE per cell.
   const uint32_t ntmp = s_ntmp;
-  uint32_t* outc = p.cells + (int64_t)b * p.KP;
-  for (uint32_t i = wave; i < ntmp; i += 4) {
-    const uint32_t c = tmp[i];
-    bool pass = true;
-    if (p.has_thr) {
-      const float* row = QCT + (int64_t)c * LQP;
-      if (p.slab <= 0) {
+  uint32_t* lst = tmp;   // survivors are compacted in place (reads of entry i happen before any write to slot <= i)
+  if (!p.has_thr) {
+    if (tid == 0) s_nfinal = ntmp;
+  } else if (p.slab <= 0) {
+    for (uint32_t i0 = 0; i0 < ntmp; i0 += 256) {
+      const uint32_t i = i0 + tid;
+      uint32_t c = 0;
+      bool pass = false;
+      if (i < ntmp) {
+        c = tmp[i];
+        const float4* row4 = reinterpret_cast<const float4*>(QCT + (int64_t)c * LQP);
         uint32_t km = 0;
-        for (int q0 = 0; q0 < Lq; q0 += 64) {
-          const int qx = q0 + lane;
-          const uint32_t k = (qx < Lq) ? okey(row[qx]) : 0u;
-          km = max(km, k);
+        for (int q4 = 0; 4 * q4 < Lq; ++q4) {
+          const float4 v = row4[q4];
+          km = max(km, okey(v.x));
+          if (4 * q4 + 1 < Lq) km = max(km, okey(v.y));
+          if (4 * q4 + 2 < Lq) km = max(km, okey(v.z));
+          if (4 * q4 + 3 < Lq) km = max(km, okey(v.w));
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, o));
         float mx;
         if (km != 0) mx = unkey(km);
-        else mx = (Lq > 0) ? row[Lq - 1] : NP_NEG_INF;
+        else mx = (Lq > 0) ? QCT[(int64_t)c * LQP + Lq - 1] : NP_NEG_INF;
         pass = mx >= p.thr;
-      } else {
+      }
+      __syncthreads();   // every read of this step's entries is done
+      if (pass) lst[atomicAdd(&s_nfinal, 1u)] = c;
+      __syncthreads();
+    }
+  } else {
+    for (uint32_t i0 = 0; i0 < ntmp; i0 += 4) {
+      const uint32_t i = i0 + wave;
+      bool pass = false;
+      uint32_t c = 0;
+      if (i < ntmp) {
+        c = tmp[i];
+        const float* row = QCT + (int64_t)c * LQP;
         const int64_t slab0 = ((int64_t)c / p.slab) * p.slab;
         uint32_t km = 0;       // best finite score among the always-pushed pairs
         int first_sel = 0x7FFFFFFF;
-        pass = false;
         for (int q0 = 0; q0 < Lq && !pass; q0 += 64) {
           const int qx = q0 + lane;
           const bool qv = qx < Lq;
@@ -606,14 +624,21 @@ __global__ void __launch_bounds__(256) probe_finish_kernel(ProbeP p) {
           pass = row[first_sel] >= p.thr;
         }
       }
+      __syncthreads();
+      if (pass && lane == 0) lst[atomicAdd(&s_nfinal, 1u)] = c;
+      __syncthreads();
     }
-    if (pass && lane == 0) outc[atomicAdd(&s_nfinal, 1u)] = c;
   }
   __syncthreads();
+  // ---- append this slice's cells to the query's list
+  const uint32_t nfin = s_nfinal;
   if (tid == 0) {
-    p.n_cells[b] = (int32_t)s_nfinal;
-    atomicAdd(&p.ctr->n_cells, (unsigned long long)s_nfinal);
+    s_obase = nfin ? (uint32_t)atomicAdd(&p.n_cells[b], (int32_t)nfin) : 0u;
+    if (nfin) atomicAdd(&p.ctr->n_cells, (unsigned long long)nfin);
   }
+  __syncthreads();
+  uint32_t* outc = p.cells + (int64_t)b * p.KP + s_obase;
+  for (uint32_t i = tid; i < nfin; i += 256) outc[i] = lst[i];
 }
 
 // Group maxima restricted to eligible centroids (subset path): gmax[b][g][q] = max over eligible
@@ -1589,17 +1614,23 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- walk: 8 gathers in flight per lane
-        const int np = min(CAP, nmax - p0);
+        // ---- walk: 8 gathers in flight per lane.  The lists are sorted, so documents walked in lockstep from
+        // position 0 would all be in the same narrow band of the table at the same time (a few L2 channels);
+        // every document group starts its (cyclic) walk at a different position instead.
+        const int np = (min(CAP, nmax - p0) + 7) & ~7;
         const CT* mine = &s_codes[wave][grp][0];
+        int tt = (int)(((unsigned)(grp * 5 + wave * 3) * 8u) % (unsigned)np);
         for (int t = 0; t < np; t += 8) {
           uint32_t c[8];
+          const int tcur = tt;
+          tt += 8;
+          if (tt >= np) tt = 0;
           if constexpr (sizeof(CT) == 2) {
-            const uint4 cw = *reinterpret_cast<const uint4*>(mine + t);
+            const uint4 cw = *reinterpret_cast<const uint4*>(mine + tcur);
             c[0] = cw.x & 0xFFFFu; c[1] = cw.x >> 16; c[2] = cw.y & 0xFFFFu; c[3] = cw.y >> 16;
             c[4] = cw.z & 0xFFFFu; c[5] = cw.z >> 16; c[6] = cw.w & 0xFFFFu; c[7] = cw.w >> 16;
           } else {
-            const uint4 ca = *reinterpret_cast<const uint4*>(mine + t), cb = *reinterpret_cast<const uint4*>(mine + t + 4);
+            const uint4 ca = *reinterpret_cast<const uint4*>(mine + tcur), cb = *reinterpret_cast<const uint4*>(mine + tcur + 4);
             c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w;
             c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
           }
@@ -1642,9 +1673,19 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     toks += __shfl_xor(toks, o);
     ucnt += __shfl_xor(ucnt, o);
   }
+  // one pair of (same-address) memory atomics per workgroup, not per wave
+  __shared__ unsigned long long s_cnt[2];
+  __syncthreads();
+  if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
+  __syncthreads();
   if (lane == 0 && toks) {
-    atomicAdd(&ctr->n_cand_tokens, toks);
-    atomicAdd(&ctr->n_cand_codes, ucnt);
+    atomicAdd(&s_cnt[0], toks);
+    atomicAdd(&s_cnt[1], ucnt);
+  }
+  __syncthreads();
+  if (tid == 0 && s_cnt[0]) {
+    atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
+    atomicAdd(&ctr->n_cand_codes, s_cnt[1]);
   }
 }
 
@@ -1695,37 +1736,39 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
                                                      const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
                                                      uint4* __restrict__ surv_meta, int32_t* __restrict__ n_surv,
                                                      Counters* ctr) {
-  __shared__ unsigned int s_kept;
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  __shared__ int s_wcnt[4], s_base;
+  __shared__ unsigned long long s_cnt[2];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (rp.round_of[b] != round) return;
   const int64_t n = n_cand[b];
   const int64_t pbase = rp.cand_base[b];
   const uint32_t thr = thr_b[b];
   const bool all = thr == 0;
-  if (tid == 0) s_kept = 0;
-  __syncthreads();
-  unsigned int kept = 0;
+  if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
   unsigned long long toks = 0, ucnt = 0;   // work counters of the queries the filter kernel skipped
-  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {   // block-uniform trip count
     const int64_t i = i0 + tid;
     const bool keep = i < n && (all || ((uint32_t)U[pbase + i] >> hshift) >= thr);
     const unsigned long long bal = __ballot(keep);
-    if (bal) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&n_surv[b], (int)__popcll(bal));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (keep) {
-        const uint4 m = cand_meta[pbase + i];
-        surv_meta[pbase + base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = m;
-        if (all) {
-          toks += (unsigned long long)(m.w >> 8);
-          ucnt += (unsigned long long)m.y;
-        }
-      }
-      if (lane == 0) kept += (unsigned int)__popcll(bal);
+    if (lane == 0) s_wcnt[wave] = (int)__popcll(bal);
+    __syncthreads();
+    if (tid == 0) {   // one append per workgroup and step
+      const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      s_base = tot ? atomicAdd(&n_surv[b], tot) : 0;
     }
+    __syncthreads();
+    if (keep) {
+      int pos = s_base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+      for (int k = 0; k < wave; ++k) pos += s_wcnt[k];
+      const uint4 m = cand_meta[pbase + i];
+      surv_meta[pbase + pos] = m;
+      if (all) {
+        toks += (unsigned long long)(m.w >> 8);
+        ucnt += (unsigned long long)m.y;
+      }
+    }
+    __syncthreads();
   }
-  if (lane == 0 && kept) atomicAdd(&s_kept, kept);
   if (all) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1733,12 +1776,15 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
       ucnt += __shfl_xor(ucnt, o);
     }
     if (lane == 0 && toks) {
-      atomicAdd(&ctr->n_cand_tokens, toks);
-      atomicAdd(&ctr->n_cand_codes, ucnt);
+      atomicAdd(&s_cnt[0], toks);
+      atomicAdd(&s_cnt[1], ucnt);
+    }
+    __syncthreads();
+    if (tid == 0 && s_cnt[0]) {
+      atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
+      atomicAdd(&ctr->n_cand_codes, s_cnt[1]);
     }
   }
-  __syncthreads();
-  if (tid == 0 && s_kept) atomicAdd(&ctr->n_survivors, (unsigned long long)s_kept);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1781,6 +1827,7 @@ struct SelectP {
   uint64_t* sel_keys;   // [B][n_sel]
   uint32_t* sel_doc;    // [B][n_sel] shard-local doc
   int32_t* nsel_out;    // [B]
+  Counters* ctr;        // n_survivors += n when non-NULL (the filter's survivor lists)
 };
 
 __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
@@ -1856,7 +1903,10 @@ __global__ void __launch_bounds__(1024) select_kernel(SelectP p) {
     p.sel_doc[(int64_t)b * p.n_sel + j] =
         (j < nsel) ? (uint32_t)((int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull)) - p.doc_begin) : 0u;
   }
-  if (tid == 0) p.nsel_out[b] = nsel;
+  if (tid == 0) {
+    p.nsel_out[b] = nsel;
+    if (p.ctr) atomicAdd(&p.ctr->n_survivors, (unsigned long long)n);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2005,10 +2055,8 @@ __global__ void __launch_bounds__(256) exact_f32_kernel(ExactP p) {
     }
     if (lane == 0) p.exact[oj] = total;
   }
-  if (lane == 0 && ndocs) {
-    atomicAdd(&p.ctr->n_exact_docs, ndocs);
-    atomicAdd(&p.ctr->n_exact_tokens, toks);
-  }
+  (void)toks;
+  (void)ndocs;
 }
 
 // bf16 MFMA variant (precision = 1): A fragment s of lane (tok, kk) = dims [16s + 8kk, +8).
@@ -2121,10 +2169,8 @@ __global__ void __launch_bounds__(256) exact_bf16_kernel(ExactP p) {
     }
     if (lane == 0) p.exact[oj] = total;
   }
-  if (lane == 0 && ndocs) {
-    atomicAdd(&p.ctr->n_exact_docs, ndocs);
-    atomicAdd(&p.ctr->n_exact_tokens, toks);
-  }
+  (void)toks;
+  (void)ndocs;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2332,10 +2378,8 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
     }
     if (lane == 0) p.exact[oj] = total;
   }
-  if (lane == 0 && ndocs) {
-    atomicAdd(&p.ctr->n_exact_docs, ndocs);
-    atomicAdd(&p.ctr->n_exact_tokens, toks);
-  }
+  (void)toks;
+  (void)ndocs;
 }
 
 template <int DIM, int NBITS, int NQT, int SPLIT>
@@ -2560,10 +2604,8 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
     }
     if (lane == 0) p.exact[oj] = total;
   }
-  if (lane == 0 && ndocs) {
-    atomicAdd(&p.ctr->n_exact_docs, ndocs);
-    atomicAdd(&p.ctr->n_exact_tokens, toks);
-  }
+  (void)toks;
+  (void)ndocs;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2577,6 +2619,8 @@ struct TopkP {
   const uint64_t* cut;
   int n_sel, NSELP, top_k;
   int64_t doc_begin;
+  const int64_t* doc_off;   // document token offsets (work counters)
+  Counters* ctr;
   int64_t* out_ids;     // [B][top_k]
   float* out_scores;
   uint64_t* out_keys;   // may be NULL
@@ -2586,21 +2630,33 @@ struct TopkP {
 __global__ void __launch_bounds__(1024) topk_kernel(TopkP p) {
   extern __shared__ uint64_t s_sel[];
   __shared__ int s_valid;
+  __shared__ unsigned long long s_ntok;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int nsel = p.nsel[b];
   const uint64_t cut = p.cut ? p.cut[b] : 0ull;
-  if (tid == 0) s_valid = 0;
+  if (tid == 0) {
+    s_valid = 0;
+    s_ntok = 0;
+  }
   __syncthreads();
   int nv = 0;
+  unsigned long long ntok = 0;
   for (int j = tid; j < p.NSELP; j += 1024) {
     uint64_t c = 0;
     if (j < nsel && p.sel_keys[(int64_t)b * p.n_sel + j] >= cut) {
       c = ((uint64_t)okey(p.exact[(int64_t)b * p.n_sel + j]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)j);
       ++nv;
+      const uint32_t d = p.sel_doc[(int64_t)b * p.n_sel + j];
+      ntok += (unsigned long long)(p.doc_off[d + 1] - p.doc_off[d]);
     }
     s_sel[j] = c;
   }
   if (nv) atomicAdd(&s_valid, nv);
+  if (p.ctr) {   // the exact-scored work of this query (S6 itself carries no counters)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ntok += __shfl_xor(ntok, o);
+    if ((tid & 63) == 0 && ntok) atomicAdd(&s_ntok, ntok);
+  }
   bitonic_sort_desc(s_sel, p.NSELP, tid, 1024);
   const int cnt = min(p.top_k, s_valid);
   for (int i = tid; i < cnt; i += 1024) {
@@ -2610,7 +2666,13 @@ __global__ void __launch_bounds__(1024) topk_kernel(TopkP p) {
     p.out_scores[(int64_t)b * p.top_k + i] = p.exact[oj];
     if (p.out_keys) p.out_keys[(int64_t)b * p.top_k + i] = p.sel_keys[oj];
   }
-  if (tid == 0) p.out_counts[b] = cnt;
+  if (tid == 0) {
+    p.out_counts[b] = cnt;
+    if (p.ctr && s_valid) {
+      atomicAdd(&p.ctr->n_exact_docs, (unsigned long long)s_valid);
+      atomicAdd(&p.ctr->n_exact_tokens, s_ntok);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

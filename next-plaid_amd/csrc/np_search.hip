@@ -483,7 +483,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     pp.n_cells = w.n_cells.as<int32_t>();
     pp.ctr = w.ctr.as<Counters>();
     probe_mark_kernel<<<dim3((unsigned)(LQP / NP_PROBE_QW), B), 256, 0, st>>>(pp);
-    probe_finish_kernel<<<B, 256, 0, st>>>(pp);
+    probe_finish_kernel<<<dim3(NP_PROBE_NF, B), 256, 0, st>>>(pp);
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));
 
@@ -516,6 +516,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   sp.sel_keys = w.sel_keys.as<uint64_t>();
   sp.sel_doc = w.sel_doc.as<uint32_t>();
   sp.nsel_out = w.nsel.as<int32_t>();
+  sp.ctr = nullptr;
   const size_t sel_lds = (size_t)cs->NSELP * 8;
   if (cs->n_sel > 0 && sel_lds > 48 * 1024)
     NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel),
@@ -558,6 +559,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       sp.cand = reinterpret_cast<const uint32_t*>(w.surv_meta.p);
       sp.cand_step = 4;
       sp.n_cand = w.n_surv.as<int32_t>();
+      sp.ctr = w.ctr.as<Counters>();
     } else if (ix->T > 0) {
       launch_approx(st, ix, w, d_qoff, B, LQP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r, max_rounds,
                     w.ctr.as<Counters>());
@@ -627,6 +629,8 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     tp.NSELP = cs->NSELP;
     tp.top_k = cs->prm.top_k;
     tp.doc_begin = ix->doc_begin;
+    tp.doc_off = ix->d_doc_offsets;
+    tp.ctr = w.ctr.as<Counters>();
     tp.out_ids = d_out_ids;
     tp.out_scores = d_out_scores;
     tp.out_keys = d_out_keys;
