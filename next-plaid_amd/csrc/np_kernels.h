@@ -1590,53 +1590,60 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         __builtin_amdgcn_wave_barrier();     // s_cl / s_nd written, the previous pass's codes consumed
         // ---- stage codes [p0, p0 + CAP) of every document of the wave; positions past a list hold the list's
         // first code (a duplicate cannot change a max), so the walk below is unpredicated
-#pragma unroll 4
-        for (int s0 = 0; s0 < DPW; s0 += 2) {
-          const int sl = s0 + half;
-          const int nds = s_nd[wave][sl];
-          const uint32_t* cp = codes + s_cl[wave][sl];
-          const int pos = p0 + CPS * hl;
-          uint32_t cv[4] = {0, 0, 0, 0};
-          uint32_t c0 = 0;
-          if (nds > 0) {
-            c0 = cp[0];
-            if (pos < nds) __builtin_memcpy(cv, cp + pos, 4 * CPS);   // 4-byte aligned load; the array is padded by 4 entries
+        // (all loads of a batch of documents are issued before the first LDS write: one memory round trip per batch,
+        // not one per document)
+        constexpr int SB = DPW / 2 < 8 ? DPW / 2 : 8;   // staging steps per batch (two documents per step)
+#pragma unroll 1
+        for (int sb = 0; sb < DPW / 2; sb += SB) {
+          uint32_t cv[SB][4], c0[SB];
+          int nds[SB];
+#pragma unroll
+          for (int j = 0; j < SB; ++j) {
+            const int sl = 2 * (sb + j) + half;
+            nds[j] = s_nd[wave][sl];
+            const uint32_t* cp = codes + s_cl[wave][sl];
+            const int pos = min(p0 + CPS * hl, max(nds[j] - 1, 0));   // clamped: always inside (or 3 past) the list
+            c0[j] = cp[0];
+            __builtin_memcpy(cv[j], cp + pos, 4 * CPS);   // 4-byte aligned load; the array is padded by 4 entries
           }
 #pragma unroll
-          for (int k = 0; k < CPS; ++k)
-            if (pos + k >= nds) cv[k] = c0;
-          CT* dst = &s_codes[wave][sl][CPS * hl];
-          if constexpr (sizeof(CT) == 2) {
-            *reinterpret_cast<uint2*>(dst) = make_uint2(cv[0] | (cv[1] << 16), cv[2] | (cv[3] << 16));
-          } else {
-            *reinterpret_cast<uint2*>(dst) = make_uint2(cv[0], cv[1]);
+          for (int j = 0; j < SB; ++j) {
+            const int sl = 2 * (sb + j) + half;
+            const int pos = p0 + CPS * hl;
+#pragma unroll
+            for (int k = 0; k < CPS; ++k)
+              if (pos + k >= nds[j]) cv[j][k] = c0[j];
+            CT* dst = &s_codes[wave][sl][CPS * hl];
+            if constexpr (sizeof(CT) == 2) {
+              *reinterpret_cast<uint2*>(dst) = make_uint2(cv[j][0] | (cv[j][1] << 16), cv[j][2] | (cv[j][3] << 16));
+            } else {
+              *reinterpret_cast<uint2*>(dst) = make_uint2(cv[j][0], cv[j][1]);
+            }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- walk: 8 gathers in flight per lane.  The lists are sorted, so documents walked in lockstep from
-        // position 0 would all be in the same narrow band of the table at the same time (a few L2 channels);
-        // every document group starts its (cyclic) walk at a different position instead.
+        // ---- walk: two batches of 8 gathers in flight per lane: the per-byte maxima of batch A are folded while
+        // batch B's rows are on their way (a wave alone waits ~3 us for a batch at this occupancy).  Documents are
+        // walked in lockstep from position 0 of their SORTED lists, so the rows a wave wants at the same time sit
+        // in a narrow band of the table (measured: starting every document at a different position costs 5 %).
         const int np = (min(CAP, nmax - p0) + 7) & ~7;
         const CT* mine = &s_codes[wave][grp][0];
-        int tt = (int)(((unsigned)(grp * 5 + wave * 3) * 8u) % (unsigned)np);
-        for (int t = 0; t < np; t += 8) {
+        auto issue = [&](int t, uint4 (&v)[8]) {
           uint32_t c[8];
-          const int tcur = tt;
-          tt += 8;
-          if (tt >= np) tt = 0;
           if constexpr (sizeof(CT) == 2) {
-            const uint4 cw = *reinterpret_cast<const uint4*>(mine + tcur);
+            const uint4 cw = *reinterpret_cast<const uint4*>(mine + t);
             c[0] = cw.x & 0xFFFFu; c[1] = cw.x >> 16; c[2] = cw.y & 0xFFFFu; c[3] = cw.y >> 16;
             c[4] = cw.z & 0xFFFFu; c[5] = cw.z >> 16; c[6] = cw.w & 0xFFFFu; c[7] = cw.w >> 16;
           } else {
-            const uint4 ca = *reinterpret_cast<const uint4*>(mine + tcur), cb = *reinterpret_cast<const uint4*>(mine + tcur + 4);
+            const uint4 ca = *reinterpret_cast<const uint4*>(mine + t), cb = *reinterpret_cast<const uint4*>(mine + t + 4);
             c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w;
             c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
           }
-          uint4 v[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Tb + (size_t)c[k] * ROWB);
+        };
+        auto fold = [&](uint4 (&v)[8]) {
           asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -1646,6 +1653,22 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
 #pragma unroll
               for (int e = 0; e < 4; ++e) st[4 * j + e] = max(st[4 * j + e], (w4[j] >> (8 * e)) & 0xFFu);
           }
+        };
+        uint4 va[8], vb[8];
+        issue(0, va);
+        int t = 0;
+        for (; t + 16 < np; t += 16) {   // steady state, no branch between an issue and the fold before it
+          issue(t + 8, vb);
+          fold(va);
+          issue(t + 16, va);
+          fold(vb);
+        }
+        if (t + 8 < np) {                // va holds batch t; one more batch
+          issue(t + 8, vb);
+          fold(va);
+          fold(vb);
+        } else {
+          fold(va);
         }
       }
       uint32_t sum = 0;
