@@ -1529,6 +1529,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         int max_rounds, const uint32_t* __restrict__ codes,
                                                         const uint32_t* __restrict__ qflag, int n_sel,
                                                         uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift,
+                                                        uint32_t* __restrict__ cursor /* [B] zeroed: next unclaimed candidate */,
                                                         Counters* ctr) {
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
@@ -1547,12 +1548,13 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
   const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
-  const int64_t stride = (int64_t)NBX * 4 * DPW;
-  const int64_t first = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW;
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
   unsigned long long toks = 0, ucnt = 0;
   const int half = lane >> 5, hl = lane & 31;   // staging: half-wave `half` loads 4 codes per lane of one document
+  // The waves of an XCD claim the query's documents DPW at a time from a per-query cursor, so every workgroup of
+  // the XCD finishes a query within one claim of the others and moves on together: with a fixed share per
+  // workgroup the fast ones run ahead, two queries' tables (2 x 2 MB) are live in the 4 MB L2 and the gathers miss.
   for (int b = rb + x; b < re; b += 8) {
     const int64_t n = n_cand[b];
     if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
@@ -1564,7 +1566,12 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     __syncthreads();
     for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
     __syncthreads();
-    for (int64_t i0 = first; i0 < n; i0 += stride) {   // wave-uniform trip count
+    uint32_t inext = 0;
+    if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
+    for (;;) {
+      const int64_t i0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
+      if (i0 >= n) break;
+      if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);   // the next claim travels while this one is processed
       const int64_t i = i0 + grp;
       const bool valid = i < n;
       const uint4 m = metab[valid ? i : n - 1];

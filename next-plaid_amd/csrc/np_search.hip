@@ -15,7 +15,7 @@ namespace np {
 
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
-      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
+      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
       subset_bits, elig, misc, cut;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
@@ -23,7 +23,7 @@ struct Workspace {
   bool done_valid = false;
   void release_all() {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &surv_meta, &n_surv, &sel_keys, &sel_doc,
+                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &surv_meta, &n_surv, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
                      &cut};
     for (DevBuf* b : all) b->release();
@@ -391,6 +391,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     NP_TRY(w.surv_meta.reserve((size_t)pool * 16));
     NP_TRY(w.n_surv.reserve((size_t)B * 4));
     NP_TRY(w.ub_thr.reserve((size_t)B * 4));
+    NP_TRY(w.ub_cursor.reserve((size_t)B * 4));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -415,6 +416,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   if (use_filter && B > 0) {
     NP_HIP(hipMemsetAsync(w.ub_hist.p, 0, (size_t)B * NP_UB_BINS * 4, st));
     NP_HIP(hipMemsetAsync(w.n_surv.p, 0, (size_t)B * 4, st));
+    NP_HIP(hipMemsetAsync(w.ub_cursor.p, 0, (size_t)B * 4, st));
     if (RB != LQP) NP_HIP(hipMemsetAsync(w.QCU.p, 0, (size_t)B * KP * RB, st));   // row bytes LQP .. RB-1 stay 0
   }
   if (B == 0) return NP_OK;
@@ -535,7 +537,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   approx_ub_kernel<ROWB, CT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),                \
                                                       w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,         \
                                                       w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),           \
-                                                      w.ub_hist.as<uint32_t>(), hshift, w.ctr.as<Counters>())
+                                                      w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(),    \
+                                                      w.ctr.as<Counters>())
       if (ix->K <= 65536) {
         if (RB == 32) NP_LAUNCH_UB(32, uint16_t);
         else if (RB == 64) NP_LAUNCH_UB(64, uint16_t);
