@@ -105,6 +105,7 @@ struct Tuning {
   int s4_nbx = 128;      // workgroups per XCD
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
+  int ub_nt = 0;         // non-temporal loads for the filter's candidate records / code lists
   int s6_xcd = 1;        // one XCD per query in S6
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel

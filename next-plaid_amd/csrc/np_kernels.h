@@ -1522,7 +1522,7 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 #define NP_UB_NBX 96       // workgroups per XCD: 3 per CU (48 KB of LDS each)
 
 // CT = uint16_t when every code fits 16 bits (K <= 65536), else uint32_t.
-template <int ROWB, typename CT>
+template <int ROWB, typename CT, bool NT>   // NT: records / code lists are read once -> non-temporal loads
 __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
                                                         const uint4* __restrict__ cand_meta,
                                                         const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
@@ -1574,7 +1574,14 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
       if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);   // the next claim travels while this one is processed
       const int64_t i = i0 + grp;
       const bool valid = i < n;
-      const uint4 m = metab[valid ? i : n - 1];
+      uint4 m;
+      if constexpr (NT) {
+        const uint32_t* mp = reinterpret_cast<const uint32_t*>(metab + (valid ? i : n - 1));
+        m = make_uint4(__builtin_nontemporal_load(mp), __builtin_nontemporal_load(mp + 1), __builtin_nontemporal_load(mp + 2),
+                       __builtin_nontemporal_load(mp + 3));
+      } else {
+        m = metab[valid ? i : n - 1];
+      }
       const int nd = valid ? (int)m.y : 0;
       const int64_t cl = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
       if (jl == 0) {
@@ -1610,8 +1617,14 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
             nds[j] = s_nd[wave][sl];
             const uint32_t* cp = codes + s_cl[wave][sl];
             const int pos = min(p0 + CPS * hl, max(nds[j] - 1, 0));   // clamped: always inside (or 3 past) the list
-            c0[j] = cp[0];
-            __builtin_memcpy(cv[j], cp + pos, 4 * CPS);   // 4-byte aligned load; the array is padded by 4 entries
+            if constexpr (NT) {
+              c0[j] = __builtin_nontemporal_load(cp);
+#pragma unroll
+              for (int k = 0; k < CPS; ++k) cv[j][k] = __builtin_nontemporal_load(cp + pos + k);
+            } else {
+              c0[j] = cp[0];
+              __builtin_memcpy(cv[j], cp + pos, 4 * CPS);   // 4-byte aligned load; the array is padded by 4 entries
+            }
           }
 #pragma unroll
           for (int j = 0; j < SB; ++j) {

@@ -533,23 +533,27 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     if (use_filter) {
       const int hshift = RB == 32 ? 0 : (RB == 64 ? 1 : (RB == 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
       const unsigned nbx = NP_UB_NBX;
-#define NP_LAUNCH_UB(ROWB, CT)                                                                                        \
-  approx_ub_kernel<ROWB, CT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),                \
-                                                      w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,         \
-                                                      w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),           \
-                                                      w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(),    \
-                                                      w.ctr.as<Counters>())
+#define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                    \
+  approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),            \
+                                                          w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,     \
+                                                          w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),       \
+                                                          w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(), \
+                                                          w.ctr.as<Counters>())
+#define NP_LAUNCH_UB_RB(CT, NT)                 \
+  do {                                          \
+    if (RB == 32) NP_LAUNCH_UB(32, CT, NT);     \
+    else if (RB == 64) NP_LAUNCH_UB(64, CT, NT);   \
+    else if (RB == 128) NP_LAUNCH_UB(128, CT, NT); \
+    else NP_LAUNCH_UB(256, CT, NT);             \
+  } while (0)
       if (ix->K <= 65536) {
-        if (RB == 32) NP_LAUNCH_UB(32, uint16_t);
-        else if (RB == 64) NP_LAUNCH_UB(64, uint16_t);
-        else if (RB == 128) NP_LAUNCH_UB(128, uint16_t);
-        else NP_LAUNCH_UB(256, uint16_t);
+        if (ix->tune.ub_nt) NP_LAUNCH_UB_RB(uint16_t, true);
+        else NP_LAUNCH_UB_RB(uint16_t, false);
       } else {
-        if (RB == 32) NP_LAUNCH_UB(32, uint32_t);
-        else if (RB == 64) NP_LAUNCH_UB(64, uint32_t);
-        else if (RB == 128) NP_LAUNCH_UB(128, uint32_t);
-        else NP_LAUNCH_UB(256, uint32_t);
+        if (ix->tune.ub_nt) NP_LAUNCH_UB_RB(uint32_t, true);
+        else NP_LAUNCH_UB_RB(uint32_t, false);
       }
+#undef NP_LAUNCH_UB_RB
 #undef NP_LAUNCH_UB
       ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
                                        w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
