@@ -773,6 +773,7 @@ struct RoundPlan {
   int64_t* cand_base;   // [B] first pool entry of query b (inside its round)
   int32_t* round_of;    // [B]
   int32_t* round_tab;   // [2 * max_rounds]: first query, one-past-last query of each round; [2*max_rounds] = n_rounds
+  int32_t* order;       // [B] the queries of every round, heaviest (most candidates) first, at the round's query range
 };
 
 __global__ void __launch_bounds__(256) plan_rounds_kernel(const int32_t* __restrict__ chunk_counts, int nchunks, int B,
@@ -812,6 +813,40 @@ __global__ void __launch_bounds__(256) plan_rounds_kernel(const int32_t* __restr
     atomicAdd(&ctr->n_candidates, total);
     atomicMax(&ctr->n_rounds, (unsigned long long)(r + 1));
   }
+  __syncthreads();
+  // heaviest-first order inside each round (rank by counting; rounds are contiguous query ranges): the per-XCD
+  // kernels hand queries to XCDs in this order, first come first served, so no XCD is left with the long tail
+  for (int b = tid; b < B; b += 256) {
+    const int r = rp.round_of[b], rb = rp.round_tab[2 * r], re = rp.round_tab[2 * r + 1];
+    const int n = rp.n_cand[b];
+    int rank = 0;
+    for (int j = rb; j < re; ++j) {
+      const int nj = rp.n_cand[j];
+      rank += (nj > n || (nj == n && j < b)) ? 1 : 0;
+    }
+    rp.order[rb + rank] = b;
+  }
+}
+
+// One query per XCD at a time, handed out dynamically.  Workgroup w runs on XCD w % 8 (tools/probes/xcc_probe.hip);
+// at step j every workgroup of XCD x works on the query in slot[x][j], which the first of them to arrive fills with
+// the next entry of the heaviest-first order (global ticket).  -1 = empty, -2 = being filled, -3 = no query left.
+// The workgroup that fills a slot is running, so nobody waits on a workgroup that is not resident.
+__device__ __forceinline__ int xcd_next_query(int32_t* slots, int32_t* ticket, int x, int step, int B,
+                                              const int32_t* order, int rb, int re) {
+  int32_t* slot = slots + (int64_t)x * (B + 1) + step;
+  int v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v == -1 && atomicCAS(slot, -1, -2) == -1) {
+    const int t = atomicAdd(ticket, 1);
+    v = (t < re - rb) ? order[rb + t] : -3;
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  }
+  while (v == -1 || v == -2) {
+    __builtin_amdgcn_s_sleep(4);
+    v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
 }
 
 // writes ascending doc ids; thread t owns words [4t, 4t+4) of the chunk so the order is preserved
@@ -1530,6 +1565,8 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         const uint32_t* __restrict__ qflag, int n_sel,
                                                         uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift,
                                                         uint32_t* __restrict__ cursor /* [B] zeroed: next unclaimed candidate */,
+                                                        int32_t* __restrict__ slots /* [8][B+1] = -1 */,
+                                                        int32_t* __restrict__ ticket /* [1] = 0 */, int B,
                                                         Counters* ctr) {
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
@@ -1555,7 +1592,13 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   // The waves of an XCD claim the query's documents DPW at a time from a per-query cursor, so every workgroup of
   // the XCD finishes a query within one claim of the others and moves on together: with a fixed share per
   // workgroup the fast ones run ahead, two queries' tables (2 x 2 MB) are live in the 4 MB L2 and the gathers miss.
-  for (int b = rb + x; b < re; b += 8) {
+  __shared__ int s_q;
+  for (int step = 0;; ++step) {
+    __syncthreads();
+    if (tid == 0) s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re);
+    __syncthreads();
+    const int b = s_q;
+    if (b < 0) break;
     const int64_t n = n_cand[b];
     if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
     const int64_t pbase = rp.cand_base[b];

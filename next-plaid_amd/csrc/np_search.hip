@@ -15,7 +15,7 @@ namespace np {
 
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
-      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
+      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
       subset_bits, elig, misc, cut;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
@@ -23,7 +23,7 @@ struct Workspace {
   bool done_valid = false;
   void release_all() {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &surv_meta, &n_surv, &sel_keys, &sel_doc,
+                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
                      &cut};
     for (DevBuf* b : all) b->release();
@@ -378,6 +378,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.cand_base.reserve((size_t)B * 8));
   NP_TRY(w.round_of.reserve((size_t)B * 4));
   NP_TRY(w.round_tab.reserve((size_t)(2 * max_rounds + 1) * 4));
+  NP_TRY(w.q_order.reserve((size_t)B * 4));
+  NP_TRY(w.xcd_slots.reserve((size_t)(8 * (B + 1) + 1) * 4));
   // S4 upper-bound filter (np_kernels.h): off for debug traces (every candidate keeps its exact score) and for
   // indices with a non-finite centroid value
   const bool use_filter = ix->tune.s4_filter && ix->filter_ok && !cs->trace && cs->n_sel > 0 && ix->T > 0;
@@ -495,6 +497,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   rp.cand_base = w.cand_base.as<int64_t>();
   rp.round_of = w.round_of.as<int32_t>();
   rp.round_tab = w.round_tab.as<int32_t>();
+  rp.order = w.q_order.as<int32_t>();
   const bool have_cands = !cs->empty_subset && ix->n_docs > 0;
   if (have_cands) {
     mark_candidates_kernel<<<dim3(128, B), 256, 0, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
@@ -533,12 +536,17 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     if (use_filter) {
       const int hshift = RB == 32 ? 0 : (RB == 64 ? 1 : (RB == 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
       const unsigned nbx = NP_UB_NBX;
+      // query hand-out state of this launch: slots = -1 (empty), ticket = 0
+      int32_t* xslots = w.xcd_slots.as<int32_t>();
+      int32_t* xticket = xslots + 8 * (B + 1);
+      NP_HIP(hipMemsetAsync(xslots, 0xFF, (size_t)8 * (B + 1) * 4, st));
+      NP_HIP(hipMemsetAsync(xticket, 0, 4, st));
 #define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                    \
   approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),            \
                                                           w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,     \
                                                           w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),       \
                                                           w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(), \
-                                                          w.ctr.as<Counters>())
+                                                          xslots, xticket, B, w.ctr.as<Counters>())
 #define NP_LAUNCH_UB_RB(CT, NT)                 \
   do {                                          \
     if (RB == 32) NP_LAUNCH_UB(32, CT, NT);     \
