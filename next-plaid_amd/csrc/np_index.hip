@@ -118,6 +118,7 @@ void destroy_device_index(DeviceIndex* ix) {
   (void)hipFree(ix->d_ulen);
   (void)hipFree(ix->d_useg);
   (void)hipFree(ix->d_inv_norm);
+  (void)hipFree(ix->d_tok_pos);
   (void)hipFree(ix->d_residuals);
   (void)hipFree(ix->d_doc_offsets);
   (void)hipFree(ix->d_ivf);
@@ -245,6 +246,93 @@ __global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __rest
   if (tid == 0) ulen[d] = base;
 }
 
+
+// ---- derived layout: every document's tokens ordered by centroid code ------------------------------------------------
+// S6 gathers one 128-B row of the query's score table per token (the MFMA C-in).  MaxSim is a max over the document's
+// tokens, so their order is free: with the tokens of a document stored in code order, the 32 tokens of a tile name
+// only a few distinct rows (the texture unit merges equal addresses of one instruction) and the gather traffic drops
+// from one row per TOKEN to about one per DISTINCT code of the document.  codes / residuals are permuted in place at
+// open (one workgroup per document, rows staged in LDS); tok_pos keeps the original position so that
+// decompress_documents and np_hip_index_export return the on-disk order.  Documents longer than NP_SORT_MAX tokens
+// stay as they are.  direction 1 = sort, 0 = restore the original order (export).
+#define NP_SORT_MAX 512
+__global__ void __launch_bounds__(256) sort_doc_tokens_kernel(const int64_t* __restrict__ doc_off, uint32_t* __restrict__ codes,
+                                                              uint8_t* __restrict__ residuals, uint16_t* __restrict__ tok_pos,
+                                                              int pd, int to_sorted) {
+  extern __shared__ uint64_t s_keys[];                        // [NP_SORT_MAX] (code << 32 | position)
+  uint32_t* s_rows = reinterpret_cast<uint32_t*>(s_keys + NP_SORT_MAX);   // [len][pd / 4]
+  const int tid = threadIdx.x;
+  const int64_t off = doc_off[blockIdx.x];
+  const int len = (int)(doc_off[blockIdx.x + 1] - off);
+  if (len > NP_SORT_MAX) {
+    if (to_sorted)
+      for (int i = tid; i < len; i += 256) tok_pos[off + i] = (uint16_t)min(i, 65535);
+    return;
+  }
+  if (len == 0) return;
+  const int pw = pd / 4;                                       // dwords per residual row (pd is a multiple of 4 here)
+  uint32_t* rows_g = reinterpret_cast<uint32_t*>(residuals + off * pd);
+  for (int w = tid; w < len * pw; w += 256) s_rows[w] = rows_g[w];
+  if (to_sorted) {
+    int n = 1;
+    while (n < len) n <<= 1;
+    for (int i = tid; i < n; i += 256) s_keys[i] = (i < len) ? (((uint64_t)codes[off + i] << 32) | (uint64_t)i) : ~0ull;
+    for (int k = 2; k <= n; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const uint64_t a = s_keys[i], c = s_keys[ixj];
+            const bool asc = (i & k) == 0;
+            if (asc ? (a > c) : (a < c)) { s_keys[i] = c; s_keys[ixj] = a; }
+          }
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < len; i += 256) {
+      codes[off + i] = (uint32_t)(s_keys[i] >> 32);
+      tok_pos[off + i] = (uint16_t)(s_keys[i] & 0xFFFFu);
+    }
+    for (int w = tid; w < len * pw; w += 256) {
+      const int i = w / pw, c = w - i * pw;
+      rows_g[w] = s_rows[(int)(s_keys[i] & 0xFFFFFFFFull) * pw + c];
+    }
+  } else {
+    for (int i = tid; i < len; i += 256) s_keys[i] = ((uint64_t)codes[off + i] << 32) | (uint64_t)tok_pos[off + i];
+    __syncthreads();
+    for (int i = tid; i < len; i += 256) codes[off + (int)(s_keys[i] & 0xFFFFull)] = (uint32_t)(s_keys[i] >> 32);
+    for (int w = tid; w < len * pw; w += 256) {
+      const int i = w / pw, c = w - i * pw;
+      rows_g[(int)(s_keys[i] & 0xFFFFull) * pw + c] = s_rows[w];
+    }
+  }
+}
+
+static int permute_tokens(const DeviceIndex* ix, int to_sorted) {
+  if (ix->n_docs == 0 || ix->T == 0 || (ix->pd & 3)) return NP_OK;
+  const size_t lds = (size_t)NP_SORT_MAX * 8 + (size_t)NP_SORT_MAX * ix->pd;
+  if (lds > 48 * 1024)
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_doc_tokens_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int64_t d0 = 0; d0 < ix->n_docs; d0 += (int64_t)1 << 30) {
+    const int64_t n = std::min<int64_t>((int64_t)1 << 30, ix->n_docs - d0);
+    sort_doc_tokens_kernel<<<(unsigned)n, 256, lds>>>(ix->d_doc_offsets + d0, ix->d_codes, ix->d_residuals, ix->d_tok_pos,
+                                                      ix->pd, to_sorted);
+  }
+  NP_HIP(hipGetLastError());
+  NP_HIP(hipDeviceSynchronize());
+  return NP_OK;
+}
+
+static int sort_tokens(DeviceIndex* ix) {
+  const char* e = getenv("NP_TOK_SORT");
+  if ((e && *e && atoi(e) == 0) || (ix->pd & 3)) return NP_OK;   // off: the on-disk order (A/B measurements)
+  NP_TRY(dev_alloc(&ix->d_tok_pos, (size_t)ix->T, &ix->device_bytes));
+  NP_TRY(permute_tokens(ix, 1));
+  ix->tok_sorted = true;
+  return NP_OK;
+}
 
 // ---- derived: 1 / ||centroid[code] + residual|| per token (codec.rs:443-467's normaliser) ------------------
 // one wave per 64 consecutive tokens; lanes sweep the dims of one token at a time (coalesced rows)
@@ -483,6 +571,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
     NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
   }
+  NP_TRY(sort_tokens(ix));
   NP_TRY(build_unique_codes(ix));
   NP_TRY(build_inv_norm(ix));
   cleanup.p = nullptr;
@@ -785,8 +874,8 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     NP_TRY(dev_alloc(&d_lens, (size_t)ix->n_docs, nullptr));
     synth_lens_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(p, d_lens);
     size_t tb = 0;
-    hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_lens, ix->d_doc_offsets + 1, (int)ix->n_docs);
-    hipError_t e = hipMalloc(&d_temp, std::max<size_t>(tb, 16));
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_lens, ix->d_doc_offsets + 1, (int)ix->n_docs);
+    if (e == hipSuccess) e = hipMalloc(&d_temp, std::max<size_t>(tb, 16));
     if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_lens, ix->d_doc_offsets + 1, (int)ix->n_docs);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_lens);
@@ -816,6 +905,7 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
   else
     ix->n_emb_total = ix->n_docs > 0 ? (int64_t)((double)ix->T / (double)ix->n_docs * (double)s->num_docs) : 0;
   ix->avg_doclen = s->num_docs > 0 ? (double)ix->n_emb_total / (double)s->num_docs : 0.0;
+  NP_TRY(sort_tokens(ix));
   NP_TRY(build_unique_codes(ix));
   NP_TRY(build_ivf_from_ucodes(ix));   // index.rs:479-499
   NP_TRY(build_inv_norm(ix));
@@ -959,6 +1049,19 @@ int np_hip_index_export(const np_index* ix, int64_t* doc_lengths, int64_t* codes
     std::vector<int64_t> off((size_t)ix->n_docs + 1);
     NP_HIP(hipMemcpy(off.data(), ix->d_doc_offsets, off.size() * 8, hipMemcpyDeviceToHost));
     for (int64_t d = 0; d < ix->n_docs; ++d) doc_lengths[d] = off[d + 1] - off[d];
+  }
+  // codes / residuals are kept in per-document code order (np_internal.h): put the on-disk order back for the copy
+  // (not concurrent with searches on this handle: export is a test / bench utility)
+  struct Resort {
+    const np_index* ix;
+    bool active;
+    ~Resort() {
+      if (active) (void)permute_tokens(ix, 1);
+    }
+  } resort{ix, false};
+  if ((codes || residuals) && ix->tok_sorted && ix->T > 0) {
+    NP_TRY(permute_tokens(ix, 0));
+    resort.active = true;
   }
   if (codes && ix->T > 0) {
     const int64_t PIECE = (int64_t)8 << 20;

@@ -8,6 +8,9 @@
 //   residuals   u8  [T][pd]             packed buckets, unchanged   (N.residuals.npy)
 //   ucodes/ulen u32 [T] / i32 [n_docs]  derived at open: each document's DISTINCT codes (S4 gathers these)
 //   inv_norm    f32 [T]                 derived at open: 1/||centroid + residual|| per token (S6 QC-reuse form)
+//   tok_pos     u16 [T]                 derived at open: codes / residuals / inv_norm keep each document's tokens ORDERED BY
+//                                       CODE (MaxSim is a max over tokens: order-free), tok_pos = the original position
+//                                       (decompress_documents / export restore the on-disk order)
 //   doc_offsets i64 [n_docs+1]          prefix sum of doclens       (index.rs:1106-1110)
 //   ivf         u32 [ivf_size]          shard-local doc ids         (ivf.npy re-based)
 //   ivf_offsets i64 [K+1]                                           (index.rs:1089-1094)
@@ -131,6 +134,8 @@ struct DeviceIndex {
   float cmax = 0.f;               // upper bound of the centroid row norms (derived; scales the S4 u8 score table)
   bool filter_ok = false;         // every centroid value is finite: the S4 upper-bound filter may run
   float* d_inv_norm = nullptr;    // [T] 1 / max(||centroid[code] + residual||, 1e-12) per token (derived)
+  uint16_t* d_tok_pos = nullptr;  // [T] original position (inside its document) of the token stored here (derived; see below)
+  bool tok_sorted = false;        // codes / residuals / inv_norm hold every document's tokens ORDERED BY CODE
   uint8_t* d_residuals = nullptr;
   int64_t* d_doc_offsets = nullptr;
   uint32_t* d_ivf = nullptr;

@@ -1062,7 +1062,7 @@ int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int6
   DeviceGuard g(ix->device);
   std::vector<int64_t> off((size_t)ix->n_docs + 1);
   NP_HIP(hipMemcpy(off.data(), ix->d_doc_offsets, off.size() * 8, hipMemcpyDeviceToHost));
-  std::vector<int64_t> toks;
+  std::vector<int64_t> toks, bases;
   for (int64_t i = 0; i < n_docs; ++i) {
     const int64_t d = doc_ids[i] - ix->doc_begin;
     if (d < 0 || d >= ix->n_docs) {  // index.rs:1202-1204: out-of-range ids contribute length 0
@@ -1070,8 +1070,13 @@ int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int6
       continue;
     }
     out_lengths[i] = off[d + 1] - off[d];
-    if (out_embeddings)
-      for (int64_t t = off[d]; t < off[d + 1]; ++t) toks.push_back(t);
+    if (out_embeddings) {
+      const int64_t base = (int64_t)toks.size();
+      for (int64_t t = off[d]; t < off[d + 1]; ++t) {
+        toks.push_back(t);
+        bases.push_back(base);
+      }
+    }
   }
   if (!out_embeddings || toks.empty()) return NP_OK;
   if ((int64_t)toks.size() > out_capacity_rows) {
@@ -1080,7 +1085,7 @@ int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int6
   }
   int64_t* d_tok = nullptr;
   float* d_out = nullptr;
-  NP_HIP(hipMalloc(&d_tok, toks.size() * 8));
+  NP_HIP(hipMalloc(&d_tok, toks.size() * 16));
   hipError_t e = hipMalloc(&d_out, toks.size() * (size_t)ix->dim * 4);
   if (e != hipSuccess) {
     (void)hipFree(d_tok);
@@ -1088,10 +1093,13 @@ int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int6
     return NP_ERR_OUT_OF_MEMORY;
   }
   e = hipMemcpy(d_tok, toks.data(), toks.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_tok + toks.size(), bases.data(), toks.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    decompress_kernel<<<(unsigned)((toks.size() + 3) / 4), 256>>>(d_tok, (int64_t)toks.size(), ix->dim, ix->nbits,
-                                                                  ix->pd, ix->d_centroids, ix->d_wlut, ix->d_codes,
-                                                                  ix->d_residuals, d_out);
+    decompress_kernel<<<(unsigned)((toks.size() + 3) / 4), 256>>>(d_tok, d_tok + toks.size(),
+                                                                  ix->tok_sorted ? ix->d_tok_pos : nullptr,
+                                                                  (int64_t)toks.size(), ix->dim, ix->nbits, ix->pd,
+                                                                  ix->d_centroids, ix->d_wlut, ix->d_codes, ix->d_residuals,
+                                                                  d_out);
     e = hipMemcpy(out_embeddings, d_out, toks.size() * (size_t)ix->dim * 4, hipMemcpyDeviceToHost);
   }
   (void)hipFree(d_tok);
