@@ -75,6 +75,7 @@ void read_tuning_env(Tuning* t) {
   t->ub_nt = env("NP_UB_NT", t->ub_nt) != 0;
   t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
   t->s6_pipe = env("NP_S6_PIPE", t->s6_pipe) != 0;
+  t->s6_waves = env("NP_S6_WAVES", t->s6_waves) >= 3 ? 3 : 2;
   t->gemm_cpw = env("NP_GEMM_CPW", t->gemm_cpw) == 2 ? 2 : 1;
   t->exact_rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
 }
@@ -117,6 +118,7 @@ void destroy_device_index(DeviceIndex* ix) {
   (void)hipFree(ix->d_ucodes);
   (void)hipFree(ix->d_ulen);
   (void)hipFree(ix->d_useg);
+  (void)hipFree(ix->d_doc_meta);
   (void)hipFree(ix->d_inv_norm);
   (void)hipFree(ix->d_tok_pos);
   (void)hipFree(ix->d_residuals);
@@ -408,15 +410,27 @@ __global__ void __launch_bounds__(256) useg_kernel(int64_t n_docs, const int64_t
   useg[d] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
 }
 
+__global__ void doc_meta_kernel(int64_t n_docs, const int64_t* __restrict__ doc_off, const int32_t* __restrict__ ulen,
+                                uint4* __restrict__ meta) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n_docs) return;
+  const int64_t o = doc_off[d];
+  const uint32_t dl = (uint32_t)(doc_off[d + 1] - o);   // w = offset bits 32..39 | doc length << 8
+  meta[d] = make_uint4((uint32_t)d, (uint32_t)ulen[d], (uint32_t)(o & 0xFFFFFFFFll), (uint32_t)((o >> 32) & 0xFF) | (dl << 8));
+}
+
 static int build_unique_codes(DeviceIndex* ix) {
   NP_TRY(dev_alloc(&ix->d_ucodes, (size_t)ix->T + 4, &ix->device_bytes));   // +4: the S4 filter reads codes 4 at a time
   NP_HIP(hipMemset(ix->d_ucodes + ix->T, 0, 16));
   NP_TRY(dev_alloc(&ix->d_ulen, (size_t)ix->n_docs, &ix->device_bytes));
   NP_TRY(dev_alloc(&ix->d_useg, (size_t)ix->n_docs, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_doc_meta, (size_t)ix->n_docs, &ix->device_bytes));
   for (int64_t d0 = 0; d0 < ix->n_docs; d0 += (int64_t)1 << 30) {
     const int64_t n = std::min<int64_t>((int64_t)1 << 30, ix->n_docs - d0);
     unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->d_codes, ix->d_ucodes, ix->d_ulen + d0);
   }
+  if (ix->n_docs > 0)
+    doc_meta_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(ix->n_docs, ix->d_doc_offsets, ix->d_ulen, ix->d_doc_meta);
   NP_HIP(hipGetLastError());
   ix->sliced_ok = false;
   if (ix->n_docs > 0) {
@@ -1028,6 +1042,7 @@ int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
   else if (n == "ub_nt") t.ub_nt = value != 0;
   else if (n == "s6_xcd") t.s6_xcd = value != 0;
   else if (n == "s6_pipe") t.s6_pipe = value != 0;
+  else if (n == "s6_waves") t.s6_waves = value >= 3 ? 3 : 2;
   else if (n == "gemm_cpw") t.gemm_cpw = value == 2 ? 2 : 1;
   else if (n == "exact_rowmax") t.exact_rowmax = value != 0;
   else {

@@ -111,6 +111,7 @@ struct Tuning {
   int ub_nt = 0;         // non-temporal loads for the filter's candidate records / code lists
   int s6_xcd = 1;        // one XCD per query in S6
   int s6_pipe = 1;       // software-pipelined QC-reuse S6 kernel (exact_qcp_kernel) instead of exact_qct_kernel
+  int s6_waves = 2;      // register budget of exact_qcp_kernel: 3 waves per SIMD (168 registers) or 2 (256)
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };
@@ -130,6 +131,8 @@ struct DeviceIndex {
   uint32_t* d_ucodes = nullptr;   // [T] per-document sorted distinct codes at the document's offset (derived)
   int32_t* d_ulen = nullptr;      // [n_docs] number of distinct codes per document (derived)
   uint4* d_useg = nullptr;        // [n_docs] 8 x u16: distinct codes below each eighth of the centroid range (derived)
+  uint4* d_doc_meta = nullptr;    // [n_docs] the 16-B candidate record of every document {doc, n distinct codes, token offset lo,
+                                  // offset bits 32..39 | doc length << 8} (derived): S3 copies it instead of three gathers
   bool sliced_ok = false;         // every document's distinct-code list is sorted and < 65536 long
   float cmax = 0.f;               // upper bound of the centroid row norms (derived; scales the S4 u8 score table)
   bool filter_ok = false;         // every centroid value is finite: the S4 upper-bound filter may run

@@ -853,8 +853,7 @@ __device__ __forceinline__ int xcd_next_query(int32_t* slots, int32_t* ticket, i
 __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict__ docbits, int64_t NW, int nchunks,
                                                       const int32_t* __restrict__ chunk_counts,
                                                       uint32_t* __restrict__ cand, RoundPlan rp, int round,
-                                                      const int64_t* __restrict__ doc_off,
-                                                      const int32_t* __restrict__ ulen, uint4* __restrict__ cand_meta) {
+                                                      const uint4* __restrict__ doc_meta, uint4* __restrict__ cand_meta) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -903,10 +902,8 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
       const int bit = __ffs(m) - 1;
       m &= m - 1;
       const uint32_t d = (uint32_t)((w0 + k) * 32 + bit);
-      const int64_t o = doc_off[d];
-      const uint32_t dl = (uint32_t)(doc_off[d + 1] - o);   // w = offset bits 32..39 | doc length << 8
       if (pos < limit) {
-        outm[pos] = make_uint4(d, (uint32_t)ulen[d], (uint32_t)(o & 0xFFFFFFFFll), (uint32_t)((o >> 32) & 0xFF) | (dl << 8));
+        outm[pos] = doc_meta[d];   // {doc, distinct codes, token offset lo, offset hi | doc length << 8}: one 16-B gather
         out[pos] = d;
       }
       ++pos;
@@ -2732,8 +2729,8 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
 //   * the low halves of the split query (32 VGPRs in exact_qct_kernel) live in LDS, which pays for the extra
 //     pipeline registers at the same 3 waves per SIMD.
 // ---------------------------------------------------------------------------------------------
-template <int DIM, int NBITS, int NQT, int SPLIT>
-__global__ void __launch_bounds__(256) exact_qcp_kernel(ExactP p) {
+template <int DIM, int NBITS, int NQT, int SPLIT, int MINW>   // MINW: waves per SIMD the register allocation must allow
+__global__ void __launch_bounds__(256, MINW) exact_qcp_kernel(ExactP p) {
   constexpr int NS = DIM / 16;            // MFMA k-steps
   constexpr int PD = DIM * NBITS / 8;     // bytes per token
   constexpr int PH = PD / 2;              // bytes per lane: lane (tok, kk) owns dims [kk*DIM/2, +DIM/2)
@@ -2889,10 +2886,9 @@ __global__ void __launch_bounds__(256) exact_qcp_kernel(ExactP p) {
   while (d0 < DPW) {
     stream(d2, t2, sb);        // S(t+2)
     cin(sa.code, acc_n);       // C(t+1)
-    // ---- tile t: residual bytes -> bf16 A fragments (8 dims = 8*NBITS/8 bytes per k-step)
-    bf16x8 ah[NS], al[SPLIT == 3 ? NS : 1];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    // ---- tile t: residual bytes -> bf16 A fragments (8 dims = 8*NBITS/8 bytes per k-step), built k-step by k-step
+    // right before the MFMAs that consume them (all 16 fragments at once would cost 64 VGPRs and a wave per SIMD)
+    auto frag = [&](int s, bf16x8& fh, bf16x8& fl) {
       uint32_t wh[4], wl[4];
       if constexpr (NBITS == 4) {
         const uint32_t word = sc.rw[s];
@@ -2914,12 +2910,10 @@ __global__ void __launch_bounds__(256) exact_qcp_kernel(ExactP p) {
       }
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       u32x4 vh = {wh[0], wh[1], wh[2], wh[3]};
-      ah[s] = __builtin_bit_cast(bf16x8, vh);
-      if constexpr (SPLIT == 3) {
-        u32x4 vl = {wl[0], wl[1], wl[2], wl[3]};
-        al[s] = __builtin_bit_cast(bf16x8, vl);
-      }
-    }
+      fh = __builtin_bit_cast(bf16x8, vh);
+      u32x4 vl = {wl[0], wl[1], wl[2], wl[3]};
+      fl = __builtin_bit_cast(bf16x8, vl);
+    };
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
       if (qt < nqt) {
@@ -2933,6 +2927,9 @@ __global__ void __launch_bounds__(256) exact_qcp_kernel(ExactP p) {
             acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
           }
         }
+        // three independent accumulation chains (hi.hi on top of the C-in, lo.hi, hi.lo): a 32x32x16 MFMA that
+        // accumulates into the previous one's result issues every 64 cycles, independent ones every 32
+        f32x16 accl, acch;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           bf16x8 bh, bl;
@@ -2943,15 +2940,25 @@ __global__ void __launch_bounds__(256) exact_qcp_kernel(ExactP p) {
             bh = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)(qt * 32 + li) * DIM + 8 * s);
             if constexpr (SPLIT == 3) bl = *reinterpret_cast<const bf16x8*>(Ql + (int64_t)(qt * 32 + li) * DIM + 8 * s);
           }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[s], acc, 0, 0, 0);   // rows = q, cols = tokens
+          bf16x8 fh, fl;
+          frag(s, fh, fl);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fh, acc, 0, 0, 0);   // rows = q, cols = tokens
           if constexpr (SPLIT == 3) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[s], acc, 0, 0, 0);
+            if (s == 0) {
+              const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fl, z, 0, 0, 0);
+              acch = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, fh, z, 0, 0, 0);
+            } else {
+              accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fl, accl, 0, 0, 0);
+              acch = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, fh, acch, 0, 0, 0);
+            }
           }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float x = acc[r] * sc.rn;
+          float v = acc[r];
+          if constexpr (SPLIT == 3) v += accl[r] + acch[r];
+          const float x = v * sc.rn;
           // maxsim.rs:284-291 ignores non-finite entries: x + (x - x) is x when finite and NaN for
           // +-inf / NaN (rn is NaN for tokens past the end), and fmaxf never returns a NaN operand
           m[qt][r] = fmaxf(m[qt][r], x + (x - x));

@@ -251,8 +251,10 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
         grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
       }
       if (ix->tune.s6_pipe) {   // software-pipelined form (same arithmetic)
-        if (precision == 1) exact_qcp_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<grid, 256, 0, st>>>(px);
-        else exact_qcp_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<grid, 256, 0, st>>>(px);
+        constexpr int NQ = NQT <= 2 ? NQT : 1;
+        if (precision == 1) exact_qcp_kernel<DIM, NBITS, NQ, 1, (NQ == 1 ? 3 : 2)><<<grid, 256, 0, st>>>(px);
+        else if (NQ == 1 && ix->tune.s6_waves >= 3) exact_qcp_kernel<DIM, NBITS, NQ, 3, (NQ == 1 ? 3 : 2)><<<grid, 256, 0, st>>>(px);
+        else exact_qcp_kernel<DIM, NBITS, NQ, 3, 2><<<grid, 256, 0, st>>>(px);
       } else {
         if (precision == 1) exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<grid, 256, 0, st>>>(px);
         else exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<grid, 256, 0, st>>>(px);
@@ -536,7 +538,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   for (int r = 0; r < (have_cands ? max_rounds : 0); ++r) {
     compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
                                                      w.chunk_counts.as<int32_t>(), w.cand.as<uint32_t>(), rp, r,
-                                                     ix->d_doc_offsets, ix->d_ulen, w.cand_meta.as<uint4>());
+                                                     ix->d_doc_meta, w.cand_meta.as<uint4>());
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
     if (use_filter) {
       const int hshift = RB == 32 ? 0 : (RB == 64 ? 1 : (RB == 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
