@@ -74,8 +74,6 @@ void read_tuning_env(Tuning* t) {
   t->s4_filter = env("NP_S4_FILTER", t->s4_filter) != 0;
   t->ub_nt = env("NP_UB_NT", t->ub_nt) != 0;
   t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
-  t->s6_pipe = env("NP_S6_PIPE", t->s6_pipe) != 0;
-  t->s6_waves = env("NP_S6_WAVES", t->s6_waves) >= 3 ? 3 : 2;
   t->gemm_cpw = env("NP_GEMM_CPW", t->gemm_cpw) == 2 ? 2 : 1;
   t->exact_rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
 }
@@ -1041,8 +1039,6 @@ int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
   else if (n == "s4_filter") t.s4_filter = value != 0;
   else if (n == "ub_nt") t.ub_nt = value != 0;
   else if (n == "s6_xcd") t.s6_xcd = value != 0;
-  else if (n == "s6_pipe") t.s6_pipe = value != 0;
-  else if (n == "s6_waves") t.s6_waves = value >= 3 ? 3 : 2;
   else if (n == "gemm_cpw") t.gemm_cpw = value == 2 ? 2 : 1;
   else if (n == "exact_rowmax") t.exact_rowmax = value != 0;
   else {

@@ -100,7 +100,7 @@ struct Context {
 };
 
 // Kernel-selection knobs.  Read from the environment ONCE, at index open (NP_S4_MODE, NP_S4_MINB, NP_S4_NBX,
-// NP_S4_SWZ, NP_S4_FILTER, NP_S6_XCD, NP_S6_PIPE, NP_GEMM_CPW, NP_EXACT_ROWMAX); np_hip_index_tune() changes them on a live handle
+// NP_S4_SWZ, NP_S4_FILTER, NP_S6_XCD, NP_GEMM_CPW, NP_EXACT_ROWMAX); np_hip_index_tune() changes them on a live handle
 // for sweep tools and the kernel-variant parity tests.  Every setting produces identical results.
 struct Tuning {
   int s4_mode = 2;       // 0 approx_kernel; 1..4 approx_xcd_kernel with 8/4/2/1 phases; 5..8 approx_stream_kernel
@@ -110,8 +110,6 @@ struct Tuning {
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
   int ub_nt = 0;         // non-temporal loads for the filter's candidate records / code lists
   int s6_xcd = 1;        // one XCD per query in S6
-  int s6_pipe = 1;       // software-pipelined QC-reuse S6 kernel (exact_qcp_kernel) instead of exact_qct_kernel
-  int s6_waves = 2;      // register budget of exact_qcp_kernel: 3 waves per SIMD (168 registers) or 2 (256)
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };

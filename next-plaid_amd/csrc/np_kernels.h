@@ -1579,9 +1579,6 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   __shared__ CT s_codes[4][DPW][CAP];
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
-  constexpr int NG = 128 / DPW < 4 ? 128 / DPW : 4;   // groups per claim
-  constexpr int CLAIM = NG * DPW;                     // <= 128 documents: two per lane
-  __shared__ uint8_t s_ord[4][CLAIM];                 // claim-local document index by ascending list length
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
   const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
@@ -1610,34 +1607,13 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
     __syncthreads();
     uint32_t inext = 0;
-    if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)CLAIM);
+    if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
     for (;;) {
-      const int64_t c0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
-      if (c0 >= n) break;
-      if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)CLAIM);   // the next claim travels while this one is processed
-      // A claim is CLAIM = NG x DPW documents.  The wave orders them by list length (rank by counting, two per lane)
-      // and walks them in NG groups of similar length: a group runs as long as its LONGEST list, and with lengths
-      // as they come ~40 % of the gathers were padding.
-      {
-        uint32_t k0 = 0xFFFFFF00u | (uint32_t)lane, k1 = 0xFFFFFF00u | (uint32_t)(lane + 64);
-        if (lane < CLAIM && c0 + lane < n) k0 = (min(metab[c0 + lane].y, 0xFFFFFFu) << 8) | (uint32_t)lane;
-        if (lane + 64 < CLAIM && c0 + lane + 64 < n) k1 = (min(metab[c0 + lane + 64].y, 0xFFFFFFu) << 8) | (uint32_t)(lane + 64);
-        int r0 = 0, r1 = 0;
-        for (int sl = 0; sl < 64; ++sl) {
-          const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)k0, sl), c = (uint32_t)__builtin_amdgcn_readlane((int)k1, sl);
-          r0 += (int)(a < k0) + (int)(c < k0);
-          r1 += (int)(a < k1) + (int)(c < k1);
-        }
-        __builtin_amdgcn_wave_barrier();       // the previous claim's order is consumed
-        if (r0 < CLAIM) s_ord[wave][r0] = (uint8_t)lane;
-        if (r1 < CLAIM) s_ord[wave][r1] = (uint8_t)(lane + 64);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-     for (int g = 0; g < NG; ++g) {
-      const int64_t i = c0 + (int64_t)s_ord[wave][g * DPW + grp];
+      const int64_t i0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
+      if (i0 >= n) break;
+      if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);   // the next claim travels while this one is processed
+      const int64_t i = i0 + grp;
       const bool valid = i < n;
-      if (g * DPW >= n - c0) break;            // wave-uniform: the claim's tail
       uint4 m;
       if constexpr (NT) {
         const uint32_t* mp = reinterpret_cast<const uint32_t*>(metab + (valid ? i : n - 1));
@@ -1767,7 +1743,6 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         else atomicAdd(&s_hist[bin >> 1], 1u << (16 * (bin & 1)));
       }
       __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next one
-     }
     }
     __syncthreads();
     for (int i = tid; i < NP_UB_BINS / 2; i += 256) {
@@ -2714,298 +2689,6 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
   }
   (void)toks;
   (void)ndocs;
-}
-
-// ---------------------------------------------------------------------------------------------
-// S6, QC-reuse form, software-pipelined (the default for Lq <= 64; same arithmetic as exact_qct_kernel, bit for bit).
-// exact_qct_kernel issues a tile's C-in gather (one 128-B score-table row per token, an L2 miss more often than
-// not) and needs it at once: measured, a wave spends ~2 us per 32-token tile waiting for it and ~0.7 us computing,
-// and every document start adds a chain of dependent loads (selection record -> offsets -> codes -> rows).  Here
-//   * the wave's NP_EXACT_DPW documents are looked up once, up front, and walked as ONE stream of 32-token tiles;
-//   * S(t) = {code, 1/n, residual words} of tile t is issued two tiles ahead, C(t) = the C-in rows of tile t one
-//     tile ahead (it needs S(t).code), so tile t computes while C(t+1) and S(t+2) are in flight -- across
-//     document boundaries too; every load is unconditional (tiles past the end re-read a valid token), so no
-//     branch sits between an issue and the compute that overlaps it;
-//   * the low halves of the split query (32 VGPRs in exact_qct_kernel) live in LDS, which pays for the extra
-//     pipeline registers at the same 3 waves per SIMD.
-// ---------------------------------------------------------------------------------------------
-template <int DIM, int NBITS, int NQT, int SPLIT, int MINW>   // MINW: waves per SIMD the register allocation must allow
-__global__ void __launch_bounds__(256, MINW) exact_qcp_kernel(ExactP p) {
-  constexpr int NS = DIM / 16;            // MFMA k-steps
-  constexpr int PD = DIM * NBITS / 8;     // bytes per token
-  constexpr int PH = PD / 2;              // bytes per lane: lane (tok, kk) owns dims [kk*DIM/2, +DIM/2)
-  constexpr int NW = PH / 4;              // residual dwords per lane
-  constexpr int WPB = (NBITS == 4) ? 1 : 2;  // u32 words of packed bf16 per residual byte (2 or 4 values)
-  constexpr int QLS = DIM + 8;            // LDS row stride of the Q-lo tile (bf16 elements): 16 B of padding -> conflict-free b128 reads
-  constexpr int DPW = NP_EXACT_DPW;
-  static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0 && DPW == 4, "unsupported DIM/NBITS");
-  __shared__ uint32_t lut[256 * WPB * 2];
-  __shared__ __bf16 sQl[SPLIT == 3 ? 32 * QLS : 8];
-  int b = blockIdx.y, bx = blockIdx.x;
-  if (p.xcd_B > 0) {
-    const int slot = blockIdx.x >> 3;
-    b = (slot / p.gx) * 8 + (blockIdx.x & 7);
-    bx = slot % p.gx;
-    if (b >= p.xcd_B) return;
-  }
-  const int tid = threadIdx.x;
-  const int LQP = p.LQP;
-  {
-    constexpr int PER = 8 / NBITS;
-    constexpr uint32_t MASK = (1u << NBITS) - 1u;
-    uint16_t hh[4] = {0, 0, 0, 0}, ll[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {   // first dim of the byte = highest segment -> low half-word
-      const float w = p.wlut[((uint32_t)tid >> (8 - NBITS * (e + 1))) & MASK];
-      const __bf16 h = (__bf16)w;
-      const __bf16 l = (__bf16)(w - (float)h);
-      hh[e] = __builtin_bit_cast(uint16_t, h);
-      ll[e] = __builtin_bit_cast(uint16_t, l);
-    }
-#pragma unroll
-    for (int w2 = 0; w2 < WPB; ++w2) {
-      lut[(tid * WPB + w2) * 2 + 0] = (uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16);
-      lut[(tid * WPB + w2) * 2 + 1] = (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16);
-    }
-    if constexpr (SPLIT == 3) {
-      const __bf16* src = p.Qb_lo + (int64_t)b * LQP * DIM;
-      for (int i = tid; i < 32 * (DIM / 8); i += 256) {
-        const int row = i / (DIM / 8), c8 = i - row * (DIM / 8);
-        *reinterpret_cast<bf16x8*>(&sQl[row * QLS + 8 * c8]) = *reinterpret_cast<const bf16x8*>(src + (int64_t)row * DIM + 8 * c8);
-      }
-    }
-  }
-  __syncthreads();
-  const uint2* lut2 = reinterpret_cast<const uint2*>(lut);
-  const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
-  const int Lq = p.qoff[b + 1] - p.qoff[b];
-  const int nqt = (Lq + 31) >> 5;
-  const int nsel = p.nsel[b];
-  const uint64_t cut = p.cut ? p.cut[b] : 0ull;
-  // slot (s, kk, e) of the MFMA k dimension <-> dim kk*DIM/2 + 8s + e, for A (tokens) and B (query) alike
-  const __bf16* Qb = p.Qb + (int64_t)b * LQP * DIM + kk * (DIM / 2);
-  const __bf16* Ql = p.Qb_lo + (int64_t)b * LQP * DIM + kk * (DIM / 2);
-  const __bf16* sQlk = sQl + li * QLS + kk * (DIM / 2);
-  const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP);   // row base; columns added per load
-  const uint32_t row_bytes = (uint32_t)LQP * 4u;
-  bf16x8 bh0[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) bh0[s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)li * DIM + 8 * s);
-
-  // ---- the wave's documents (wave-uniform scalars)
-  const int j0 = (bx * 4 + wave) * DPW;
-  int dl[DPW];
-  int64_t dof[DPW];
-#pragma unroll
-  for (int dd = 0; dd < DPW; ++dd) {
-    dl[dd] = 0;
-    dof[dd] = 0;
-    const int j = j0 + dd;
-    if (j < nsel) {
-      const int64_t oj = (int64_t)b * p.n_sel + j;
-      int len = 0;
-      if (p.sel_keys[oj] >= cut) {
-        const uint32_t doc = p.sel_doc[oj];
-        dof[dd] = p.doc_off[doc];
-        len = (int)(p.doc_off[doc + 1] - dof[dd]);
-      }
-      dl[dd] = len;
-      if (len == 0 && lane == 0) p.exact[oj] = 0.f;   // below the cut, or an empty document (search.rs:86-90 scores it 0)
-    }
-  }
-  auto len_of = [&](int dd) { return dd == 0 ? dl[0] : (dd == 1 ? dl[1] : (dd == 2 ? dl[2] : dl[3])); };
-  auto off_of = [&](int dd) { return dd == 0 ? dof[0] : (dd == 1 ? dof[1] : (dd == 2 ? dof[2] : dof[3])); };
-  // tile cursors (document slot, first token): current, +1, +2
-  auto settle = [&](int& dd, int& t0) {
-    while (dd < DPW && t0 >= len_of(dd)) {
-      ++dd;
-      t0 = 0;
-    }
-  };
-  int d0 = 0, t0 = 0;
-  settle(d0, t0);
-  if (d0 >= DPW) return;
-  int d1 = d0, t1 = t0 + 32;
-  settle(d1, t1);
-  int d2 = d1, t2 = t1 + 32;
-  settle(d2, t2);
-
-  struct Stream {
-    uint32_t code;
-    float rn;
-    uint32_t rw[NW];
-  };
-  auto stream = [&](int dd, int tt0, Stream& o) {   // unconditional: a tile past the end re-reads a valid token, rn = NaN
-    const bool live = dd < DPW;
-    const int ddc = live ? dd : d0;
-    const int len = len_of(ddc);
-    const int tt = tt0 + li;
-    const bool valid = live && tt < len;
-    const int64_t tok = off_of(ddc) + (valid ? tt : len - 1);
-    o.code = p.codes[tok];
-    const float rn = p.inv_norm[tok];
-    o.rn = valid ? rn : __builtin_nanf("");   // rows past the end become NaN and drop out of fmaxf
-    const uint32_t* rp = reinterpret_cast<const uint32_t*>(p.residuals + tok * PD + kk * PH);
-    if constexpr (NW % 4 == 0) {
-#pragma unroll
-      for (int w4 = 0; w4 < NW / 4; ++w4) {
-        const uint4 v = reinterpret_cast<const uint4*>(rp)[w4];
-        o.rw[4 * w4] = v.x; o.rw[4 * w4 + 1] = v.y; o.rw[4 * w4 + 2] = v.z; o.rw[4 * w4 + 3] = v.w;
-      }
-    } else if constexpr (NW % 2 == 0) {
-#pragma unroll
-      for (int w2 = 0; w2 < NW / 2; ++w2) {
-        const uint2 v = reinterpret_cast<const uint2*>(rp)[w2];
-        o.rw[2 * w2] = v.x; o.rw[2 * w2 + 1] = v.y;
-      }
-    } else {
-#pragma unroll
-      for (int w1 = 0; w1 < NW; ++w1) o.rw[w1] = rp[w1];
-    }
-  };
-  auto cin = [&](uint32_t code, f32x16& acc) {   // rows q = 8g + 4kk + (0..3) are one float4 of the token's QCT row
-    const char* qrow = QCb + code * row_bytes;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = *reinterpret_cast<const float4*>(qrow + (8 * g + 4 * kk) * 4);
-      acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
-    }
-  };
-
-  Stream sc, sa, sb;
-  f32x16 acc_c, acc_n;
-  stream(d0, t0, sc);
-  stream(d1, t1, sa);
-  cin(sc.code, acc_c);
-  float m[NQT][16];
-#pragma unroll
-  for (int x = 0; x < NQT; ++x)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m[x][r] = NP_NEG_INF;
-
-  while (d0 < DPW) {
-    stream(d2, t2, sb);        // S(t+2)
-    cin(sa.code, acc_n);       // C(t+1)
-    // ---- tile t: residual bytes -> bf16 A fragments (8 dims = 8*NBITS/8 bytes per k-step), built k-step by k-step
-    // right before the MFMAs that consume them (all 16 fragments at once would cost 64 VGPRs and a wave per SIMD)
-    auto frag = [&](int s, bf16x8& fh, bf16x8& fl) {
-      uint32_t wh[4], wl[4];
-      if constexpr (NBITS == 4) {
-        const uint32_t word = sc.rw[s];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint2 e = lut2[(word >> (8 * i)) & 0xFFu];
-          wh[i] = e.x;
-          wl[i] = e.y;
-        }
-      } else {
-        const uint32_t word = sc.rw[s >> 1] >> (16 * (s & 1));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint32_t byte = (word >> (8 * i)) & 0xFFu;
-          const uint2 e0 = lut2[byte * 2], e1 = lut2[byte * 2 + 1];
-          wh[2 * i] = e0.x; wl[2 * i] = e0.y;
-          wh[2 * i + 1] = e1.x; wl[2 * i + 1] = e1.y;
-        }
-      }
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 vh = {wh[0], wh[1], wh[2], wh[3]};
-      fh = __builtin_bit_cast(bf16x8, vh);
-      u32x4 vl = {wl[0], wl[1], wl[2], wl[3]};
-      fl = __builtin_bit_cast(bf16x8, vl);
-    };
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) {
-      if (qt < nqt) {
-        f32x16 acc;
-        if (qt == 0) {
-          acc = acc_c;
-        } else {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(QCb + (sc.code * row_bytes + qt * 128 + (8 * g + 4 * kk) * 4));
-            acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
-          }
-        }
-        // three independent accumulation chains (hi.hi on top of the C-in, lo.hi, hi.lo): a 32x32x16 MFMA that
-        // accumulates into the previous one's result issues every 64 cycles, independent ones every 32
-        f32x16 accl, acch;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          bf16x8 bh, bl;
-          if (qt == 0) {
-            bh = bh0[s];
-            if constexpr (SPLIT == 3) bl = *reinterpret_cast<const bf16x8*>(sQlk + 8 * s);
-          } else {
-            bh = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)(qt * 32 + li) * DIM + 8 * s);
-            if constexpr (SPLIT == 3) bl = *reinterpret_cast<const bf16x8*>(Ql + (int64_t)(qt * 32 + li) * DIM + 8 * s);
-          }
-          bf16x8 fh, fl;
-          frag(s, fh, fl);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fh, acc, 0, 0, 0);   // rows = q, cols = tokens
-          if constexpr (SPLIT == 3) {
-            if (s == 0) {
-              const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-              accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fl, z, 0, 0, 0);
-              acch = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, fh, z, 0, 0, 0);
-            } else {
-              accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fl, accl, 0, 0, 0);
-              acch = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, fh, acch, 0, 0, 0);
-            }
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[r];
-          if constexpr (SPLIT == 3) v += accl[r] + acch[r];
-          const float x = v * sc.rn;
-          // maxsim.rs:284-291 ignores non-finite entries: x + (x - x) is x when finite and NaN for
-          // +-inf / NaN (rn is NaN for tokens past the end), and fmaxf never returns a NaN operand
-          m[qt][r] = fmaxf(m[qt][r], x + (x - x));
-        }
-      }
-    }
-    // ---- last tile of its document: max over the tokens, q-ordered sum (maxsim.rs:284-291), next document
-    if (d1 != d0) {
-      float total = 0.f;
-#pragma unroll
-      for (int qt = 0; qt < NQT; ++qt) {
-        if (qt < nqt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = m[qt][r];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
-            m[qt][r] = v;
-          }
-          // q = 8g + 4kk + e lives in register 4g + e of half kk
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int q = qt * 32 + 8 * g + 4 * hk + e;
-                const float x = readlane_f(m[qt][4 * g + e], hk * 32);
-                if (q < Lq && x > NP_NEG_INF) total += x;
-              }
-        }
-      }
-      if (lane == 0) p.exact[(int64_t)b * p.n_sel + j0 + d0] = total;
-#pragma unroll
-      for (int x = 0; x < NQT; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[x][r] = NP_NEG_INF;
-    }
-    // ---- rotate the pipeline
-    sc = sa;
-    sa = sb;
-    acc_c = acc_n;
-    d0 = d1; t0 = t1;
-    d1 = d2; t1 = t2;
-    t2 += 32;
-    settle(d2, t2);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

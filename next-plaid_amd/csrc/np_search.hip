@@ -250,15 +250,8 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
         px.gx = (int)gx;
         grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
       }
-      if (ix->tune.s6_pipe) {   // software-pipelined form (same arithmetic)
-        constexpr int NQ = NQT <= 2 ? NQT : 1;
-        if (precision == 1) exact_qcp_kernel<DIM, NBITS, NQ, 1, (NQ == 1 ? 3 : 2)><<<grid, 256, 0, st>>>(px);
-        else if (NQ == 1 && ix->tune.s6_waves >= 3) exact_qcp_kernel<DIM, NBITS, NQ, 3, (NQ == 1 ? 3 : 2)><<<grid, 256, 0, st>>>(px);
-        else exact_qcp_kernel<DIM, NBITS, NQ, 3, 2><<<grid, 256, 0, st>>>(px);
-      } else {
-        if (precision == 1) exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<grid, 256, 0, st>>>(px);
-        else exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<grid, 256, 0, st>>>(px);
-      }
+      if (precision == 1) exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<grid, 256, 0, st>>>(px);
+      else exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<grid, 256, 0, st>>>(px);
     } else {
       if (precision == 1) exact_qc_kernel<DIM, NBITS, NQT, 1><<<dim3(gx, B), 256, 0, st>>>(p);
       else exact_qc_kernel<DIM, NBITS, NQT, 3><<<dim3(gx, B), 256, 0, st>>>(p);
