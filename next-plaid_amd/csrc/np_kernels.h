@@ -1871,6 +1871,203 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Batched path (K > centroid_batch_size): approximate scores in the reference's arithmetic.
+// search.rs:259-272 does not reuse the probe's GEMM: it recomputes Q.c for every distinct centroid of the candidates
+// as an ndarray mat-vec, i.e. per (q, c) numeric_util::unrolled_dot -- eight partial sums p_j += x[8i+j] * y[8i+j]
+// (multiply, then add: no FMA), then ((p0+p4) + (p1+p5)) + (p2+p6) + (p3+p7) folded into 0 one pair at a time.  That
+// rounds differently from S1's k-ordered FMA chain (~1e-7), so the selection by approximate score can differ from the
+// dense path's at near-ties.  The values are order-exact here too:
+//   * ub_cut's survivors get the GEMM-valued score G as on the dense path (the u8 bound brackets both G and R);
+//   * gcut_kernel keeps the documents with G >= (n_sel-th largest G) - 2e, where e >= |G - R| per document
+//     (rounding analysis of both dot-product orders: (152 Lq + 2 Lq^2) 2^-24 ||q|| max||c||, x1.5): every document of
+//     the R-ordered top n_sel is among them, typically n_sel plus a handful;
+//   * approx_matvec_kernel recomputes R = sum_q max_c unrolled_dot(Q[q], C[c]) for those only, S5 selects on R.
+// debug_trace skips the bounds and recomputes R for every candidate.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one wave per listed document; lanes (q = lane & 31, half = lane >> 5): half h takes the document's distinct codes
+// h, h+2, ...; 32 query tokens at a time
+template <int DIM>
+__global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restrict__ qrows, const int32_t* __restrict__ qoff,
+                                                            const float* __restrict__ centroids,
+                                                            const uint4* __restrict__ meta, const int32_t* __restrict__ n_list,
+                                                            RoundPlan rp, int round, const uint32_t* __restrict__ codes,
+                                                            float* __restrict__ approx) {
+#pragma clang fp contract(off)
+  constexpr int QS = DIM + 4;   // LDS row stride (floats): conflict-free b128 reads across 32 rows
+  __shared__ float sQ[32 * QS];
+  __shared__ float sC[4][2][DIM];
+  __shared__ float sM[4][64];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (rp.round_of[b] != round) return;
+  const int n = n_list[b];
+  const int64_t pbase = rp.cand_base[b];
+  const int q0 = qoff[b], Lq = qoff[b + 1] - q0;
+  const int ql = lane & 31, half = lane >> 5;
+  const int ndoc_iter = (n + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
+  for (int it = 0; it < ndoc_iter; ++it) {           // block-uniform trip count (barriers inside)
+    const int i = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+    const bool live = i < n;
+    const uint4 m = meta[pbase + (live ? i : 0)];
+    const int nd = live ? (int)m.y : 0;
+    const uint32_t* cl = codes + ((int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32));
+    float score = 0.f;
+    for (int qt = 0; qt < Lq; qt += 32) {
+      __syncthreads();
+      for (int w = tid; w < 32 * (DIM / 4); w += 256) {
+        const int r = w / (DIM / 4), c4 = w - r * (DIM / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qt + r < Lq) v = *reinterpret_cast<const float4*>(qrows + (int64_t)(q0 + qt + r) * DIM + 4 * c4);
+        *reinterpret_cast<float4*>(&sQ[r * QS + 4 * c4]) = v;
+      }
+      __syncthreads();
+      float mx = NP_NEG_INF;
+      for (int j0 = 0; j0 < nd; j0 += 2) {
+        const int j = j0 + half;
+        // the two centroid rows of this step, one per half-wave, through LDS
+        {
+          const uint32_t c = cl[min(j, nd - 1)];
+          const float4* src = reinterpret_cast<const float4*>(centroids + (int64_t)c * DIM);
+          if (ql < DIM / 4) *reinterpret_cast<float4*>(&sC[wave][half][4 * ql]) = src[ql];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, p45 = {0.f, 0.f}, p67 = {0.f, 0.f};
+        const float* xq = &sQ[ql * QS];
+        const float* yc = &sC[wave][half][0];
+#pragma unroll 4
+        for (int k = 0; k < DIM; k += 8) {
+          const float4 x0 = *reinterpret_cast<const float4*>(xq + k), x1 = *reinterpret_cast<const float4*>(xq + k + 4);
+          const float4 y0 = *reinterpret_cast<const float4*>(yc + k), y1 = *reinterpret_cast<const float4*>(yc + k + 4);
+          p01 = p01 + (f32x2){x0.x, x0.y} * (f32x2){y0.x, y0.y};
+          p23 = p23 + (f32x2){x0.z, x0.w} * (f32x2){y0.z, y0.w};
+          p45 = p45 + (f32x2){x1.x, x1.y} * (f32x2){y1.x, y1.y};
+          p67 = p67 + (f32x2){x1.z, x1.w} * (f32x2){y1.z, y1.w};
+        }
+        float sum = 0.f;
+        sum = sum + (p01.x + p45.x);
+        sum = sum + (p01.y + p45.y);
+        sum = sum + (p23.x + p67.x);
+        sum = sum + (p23.y + p67.y);
+        if (j < nd && sum > mx) mx = sum;          // search.rs:286-291: `if centroid_score > max_score`
+        __builtin_amdgcn_wave_barrier();            // sC is rewritten by the next step
+      }
+      // the two halves saw disjoint codes: combine with the same '>' rule, then the q-ordered sum (search.rs:294-297)
+      sM[wave][lane] = mx;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+        const int nq = min(32, Lq - qt);
+        for (int qq = 0; qq < nq; ++qq) {
+          const float a0 = sM[wave][qq], a1 = sM[wave][32 + qq];
+          const float mm = (a1 > a0) ? a1 : a0;
+          if (mm > NP_NEG_INF) score = score + mm;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (live && lane == 0) approx[pbase + i] = score;
+  }
+}
+
+// work counters (candidate tokens / distinct codes) of a record list, for the paths whose scoring kernel carries none
+__global__ void __launch_bounds__(256) count_work_kernel(const uint4* __restrict__ meta, const int32_t* __restrict__ n_list,
+                                                         RoundPlan rp, int round, Counters* ctr) {
+  __shared__ unsigned long long s_cnt[2];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  if (rp.round_of[b] != round) return;
+  const int n = n_list[b];
+  const int64_t pbase = rp.cand_base[b];
+  if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
+  __syncthreads();
+  unsigned long long toks = 0, ucnt = 0;
+  for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+    const uint4 m = meta[pbase + i];
+    toks += (unsigned long long)(m.w >> 8);
+    ucnt += (unsigned long long)m.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    toks += __shfl_xor(toks, o);
+    ucnt += __shfl_xor(ucnt, o);
+  }
+  if (lane == 0 && toks) {
+    atomicAdd(&s_cnt[0], toks);
+    atomicAdd(&s_cnt[1], ucnt);
+  }
+  __syncthreads();
+  if (tid == 0 && s_cnt[0]) {
+    atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
+    atomicAdd(&ctr->n_cand_codes, s_cnt[1]);
+  }
+}
+
+// per query: threshold on the GEMM-valued scores, list2 = survivors with G >= tau_G - 2 eps (see above)
+__global__ void __launch_bounds__(1024) gcut_kernel(const float* __restrict__ approx, const uint4* __restrict__ in_meta,
+                                                    const int32_t* __restrict__ n_in, RoundPlan rp, int round, int n_sel,
+                                                    const float* __restrict__ qinv, const uint32_t* __restrict__ qflag,
+                                                    const int32_t* __restrict__ qoff, uint4* __restrict__ out_meta,
+                                                    int32_t* __restrict__ n_out) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_prefix, s_rem, s_cnt;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (rp.round_of[b] != round) return;
+  const int n = n_in[b];
+  const int64_t pbase = rp.cand_base[b];
+  const float* ap = approx + pbase;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  bool all = n <= n_sel || qflag[b] != 0 || n_sel <= 0;
+  float thr = NP_NEG_INF;
+  if (!all) {
+    if (tid == 0) {
+      s_prefix = 0;
+      s_rem = (uint32_t)n_sel;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const uint32_t pre = s_prefix;
+      for (int i = tid; i < n; i += 1024) {
+        const uint32_t key = okey(ap[i]);
+        if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t rem = s_rem, cum = 0;
+        int bin = 255;
+        for (; bin > 0; --bin) {
+          if (cum + hist[bin] >= rem) break;
+          cum += hist[bin];
+        }
+        s_prefix = (pre << 8) | (uint32_t)bin;
+        s_rem = rem - cum;
+      }
+      __syncthreads();
+    }
+    const uint32_t tau = s_prefix;
+    if (tau == 0) {
+      all = true;   // the cut sits among non-finite scores: keep everything
+    } else {
+      const int Lq = qoff[b + 1] - qoff[b];
+      const float s = 1.0f / qinv[b];
+      const float eps = 1.5f * (152.0f * (float)Lq + 2.0f * (float)Lq * (float)Lq) * 5.9604645e-8f * s;
+      thr = unkey(tau) - 2.0f * eps;
+    }
+  }
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool keep = i < n && (all || !(ap[i] < thr));   // NaN scores are kept (never dropped by a bound)
+    if (keep) out_meta[pbase + atomicAdd(&s_cnt, 1u)] = in_meta[pbase + i];
+  }
+  __syncthreads();
+  if (tid == 0) n_out[b] = (int32_t)s_cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
 // block bitonic sort, descending, n = power of two, in LDS
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t* s, int n, int tid, int nthreads) {

@@ -15,7 +15,7 @@ namespace np {
 
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
-      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
+      cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, n_list2, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
       subset_bits, elig, misc, cut;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
@@ -23,7 +23,7 @@ struct Workspace {
   bool done_valid = false;
   void release_all() {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &sel_keys, &sel_doc,
+                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
                      &cut};
     for (DevBuf* b : all) b->release();
@@ -323,6 +323,18 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
   }
 }
 
+// Batched path (search.rs:259-272): approximate scores of the listed documents in the reference's mat-vec arithmetic
+static void launch_matvec(hipStream_t st, const DeviceIndex* ix, Workspace& w, const float* d_q, const int32_t* d_qoff, int B,
+                          const uint4* meta, const int32_t* n, const RoundPlan& rp, int round) {
+  const dim3 grid(64, (unsigned)B);
+  switch (ix->dim) {
+    case 32: approx_matvec_kernel<32><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
+    case 64: approx_matvec_kernel<64><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
+    case 96: approx_matvec_kernel<96><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
+    default: approx_matvec_kernel<128><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
+  }
+}
+
 // S1..S5 for queries [0,B) whose rows live in d_q (absolute offsets d_qoff/h_qoff).
 static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
                    const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len) {
@@ -379,6 +391,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.round_of.reserve((size_t)B * 4));
   NP_TRY(w.round_tab.reserve((size_t)(2 * max_rounds + 1) * 4));
   NP_TRY(w.q_order.reserve((size_t)B * 4));
+  NP_TRY(w.n_list2.reserve((size_t)B * 4));
   NP_TRY(w.xcd_slots.reserve((size_t)(8 * (B + 1) + 1) * 4));
   // S4 upper-bound filter (np_kernels.h): off for debug traces (every candidate keeps its exact score) and for
   // indices with a non-finite centroid value
@@ -563,7 +576,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       }
 #undef NP_LAUNCH_UB_RB
 #undef NP_LAUNCH_UB
-      ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
+      // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
+      ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2 + (batched ? 1 : 0), cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
                                        w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
       const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
       ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), w.ub_thr.as<uint32_t>(), hshift,
@@ -575,9 +589,25 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       sp.cand_step = 4;
       sp.n_cand = w.n_surv.as<int32_t>();
       sp.ctr = w.ctr.as<Counters>();
+      if (batched) {
+        // reference arithmetic of the batched path: G-valued cut with a rounding margin, then the mat-vec scores
+        // of what is left (the candidate records of this round are consumed: their array takes the second list)
+        gcut_kernel<<<B, 1024, 0, st>>>(w.approx.as<float>(), w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), rp, r, cs->n_sel,
+                                        w.qinv.as<float>(), w.qflag.as<uint32_t>(), d_qoff, w.cand_meta.as<uint4>(),
+                                        w.n_list2.as<int32_t>());
+        launch_matvec(st, ix, w, d_q, d_qoff, B, w.cand_meta.as<uint4>(), w.n_list2.as<int32_t>(), rp, r);
+        sp.cand = reinterpret_cast<const uint32_t*>(w.cand_meta.p);
+        sp.n_cand = w.n_list2.as<int32_t>();
+      }
     } else if (ix->T > 0) {
-      launch_approx(st, ix, w, d_qoff, B, LQP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r, max_rounds,
-                    w.ctr.as<Counters>());
+      if (batched) {   // debug trace / filter off: the mat-vec score of every candidate
+        launch_matvec(st, ix, w, d_q, d_qoff, B, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r);
+        count_work_kernel<<<dim3(32, (unsigned)B), 256, 0, st>>>(w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r,
+                                                                 w.ctr.as<Counters>());
+      } else {
+        launch_approx(st, ix, w, d_qoff, B, LQP, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r, max_rounds,
+                      w.ctr.as<Counters>());
+      }
     }
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[4], st));
     if (cs->n_sel > 0) {

@@ -198,6 +198,27 @@ def test_mixed_length_batch_and_slicing(prec):
         assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, rtol_of(prec), f"q{i}")
 
 
+def test_batched_path_selection_at_size(mid, tuned):
+    """K > centroid_batch_size on the production path (u8 bound -> GEMM-valued scores -> margin cut -> mat-vec scores of
+    what is left): with top_k = n_sel the whole selected set comes back, and it must be the oracle's (whose approximate
+    scores are all mat-vec valued); the GEMM-valued dense path is allowed to select differently at near-ties."""
+    spec, a, ox, hx, qs, src = mid
+    for nfs, nprobe, thr in ((512, 32, None), (2048, 16, 0.4)):
+        k = nfs // 4
+        p = P(n_full_scores=nfs, top_k=k, n_ivf_probe=nprobe, centroid_score_threshold=thr, centroid_batch_size=1000)
+        got = hx.search_batch(qs[:24], p)
+        st = dict(hx.last_stats)
+        ref = ox.search_batch(qs[:24], to_oracle_params(p))
+        for i, (g, o) in enumerate(zip(got, ref)):
+            assert set(g.passage_ids.tolist()) == set(o.passage_ids.tolist()), f"nfs={nfs} q{i}: selected set differs"
+            assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"batched nfs={nfs} q{i}")
+        assert 0 < st["n_survivors"] < st["n_candidates"]
+        hx.tune("s4_filter", 0)     # unfiltered: every candidate gets the mat-vec score
+        for g, o in zip(hx.search_batch(qs[:24], p), got):
+            assert np.array_equal(g.passage_ids, o.passage_ids) and np.array_equal(g.scores, o.scores)
+        hx.tune("s4_filter", 1)
+
+
 def test_s4_filter_preserves_selection(mid, tuned):
     """The u8 upper-bound filter in front of S4 must not change WHICH documents are selected nor their order:
     with top_k = n_sel the whole selected set is returned, so filtered and unfiltered runs must agree bit for bit
@@ -397,10 +418,13 @@ def test_batched_probe_semantics():
                     assert ob.trace.used_batched
                     assert np.array_equal(tb["cells"], ob.trace.cells), f"thr={thr} np={nprobe} cbs={cbs} q{qi}: cells"
                     assert np.array_equal(tb["cand"], ob.trace.cand)
-                    # approx scores: the reference's batched path uses mat-vec summation order (search.rs:259-272)
-                    assert np.allclose(tb["approx"], ob.trace.approx, rtol=0, atol=2e-5)
+                    # approx scores in the reference's batched arithmetic: mat-vec = unrolled_dot order (search.rs:259-272),
+                    # NOT the probe GEMM's -- bit for bit, and therefore the same selection in the same order
+                    bad = np.nonzero(tb["approx"].view(np.uint32) != ob.trace.approx.view(np.uint32))[0]
+                    assert bad.size == 0, f"batched approx not bit-exact at {bad[:5]}: {tb['approx'][bad[:5]]} vs {ob.trace.approx[bad[:5]]}"
+                    assert np.array_equal(tb["sel"], ob.trace.sel), f"thr={thr} np={nprobe} cbs={cbs} q{qi}: selection"
                     r = hx.search(q, pb)
-                    assert_ranking_close(r.passage_ids, r.scores, ob.passage_ids, ob.scores, 5e-5, f"batched q{qi}")
+                    assert_ranking_close(r.passage_ids, r.scores, ob.passage_ids, ob.scores, RTOL_F32, f"batched q{qi}")
                     n_diff += int(not np.array_equal(ob.trace.cells, ox.search(q, to_oracle_params(pd_), trace=True).trace.cells))
     assert n_diff > 0, "test data never separated batched from dense threshold semantics"
     # subset in batched mode only filters candidates (search.rs:542-545)
