@@ -89,6 +89,10 @@ def cpu_model():
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON: everything else this process (or a C library inside it -- RCCL prints
+    # a version banner through C stdio) writes to fd 1 goes to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import next_plaid_amd as npa
     from next_plaid_amd import api, synth
@@ -342,10 +346,11 @@ def main():
         "index_build_s": round(t_build, 2), "hbm_index_bytes": int(ix.info.device_bytes),
         "hbm_bytes_per_token": round(ix.info.device_bytes / max(int(ix.info.shard_embeddings), 1), 2),
     }
-    print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -1554,7 +1554,12 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 #define NP_UB_NBX 96       // workgroups per XCD: 3 per CU (48 KB of LDS each)
 
 // CT = uint16_t when every code fits 16 bits (K <= 65536), else uint32_t.
-template <int ROWB, typename CT, bool NT>   // NT: records / code lists are read once -> non-temporal loads
+// MODE 0: plain loads, every position of the lockstep walk gathers a row (positions past a list repeat its first code).
+// MODE 1: as 0 with non-temporal loads of the records / code lists (read once).
+// MODE 2: the table is read through a buffer descriptor and positions past a document's list carry an out-of-range
+//         offset: the bounds check returns zeros (u >= 1, so 0 is the identity of the max) WITHOUT a memory request, so
+//         the padding of the lockstep walk costs no L2 request slot.
+template <int ROWB, typename CT, int MODE>
 __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
                                                         const uint4* __restrict__ cand_meta,
                                                         const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
@@ -1570,6 +1575,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // distinct codes of one document staged per pass (32 KB of LDS per
                                                     // workgroup either way; longer lists take further passes)
   constexpr int CPS = CAP / 32;                     // codes a staging lane loads (half a wave per document)
+  constexpr bool NT = MODE == 1, OOB = MODE == 2;
   static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128 || ROWB == 256, "row = power-of-two bytes >= LQP");
   // A document's distinct-code list is read from memory ONCE, coalesced, into LDS (half a wave per document, 16 B
   // per lane), and the gathers take their codes from there.  (Reading it 16 B at a time per lane as the walk
@@ -1594,13 +1600,19 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     __syncthreads();
     if (tid == 0) s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re);
     __syncthreads();
-    const int b = s_q;
+    const int b = __builtin_amdgcn_readfirstlane(s_q);
     if (b < 0) break;
     const int64_t n = n_cand[b];
     if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
     const int64_t pbase = rp.cand_base[b];
     const uint4* metab = cand_meta + pbase;
     const char* Tb = reinterpret_cast<const char*>(QCU + (int64_t)b * KP * ROWB) + jl * 16;
+    // MODE 2: this query's table as a bounds-checked buffer (descriptor built from wave-uniform values only)
+    const uint64_t tb64 = reinterpret_cast<uint64_t>(QCU + (int64_t)b * KP * ROWB);
+    const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb64);
+    const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tb64 >> 32));
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uint64_t)thi << 32) | tlo), 0, (int)(KP * ROWB), 0x00020000);
     uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
     const bool big = n / NBX >= 60000;   // a block could see >= 2^16 documents of one bin: count in memory instead
     __syncthreads();
@@ -1700,8 +1712,18 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
             c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w;
             c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
           }
+          if constexpr (OOB) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Tb + (size_t)c[k] * ROWB);
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t off = (p0 + t + k < nd) ? c[k] * (uint32_t)ROWB + (uint32_t)(jl * 16) : 0x7FFFFFF0u;
+              const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)off, 0, 0);
+              v[k] = make_uint4(r.x, r.y, r.z, r.w);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Tb + (size_t)c[k] * ROWB);
+          }
         };
         auto fold = [&](uint4 (&v)[8]) {
           asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));

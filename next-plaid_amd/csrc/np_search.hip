@@ -567,12 +567,15 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     else if (RB == 128) NP_LAUNCH_UB(128, CT, NT); \
     else NP_LAUNCH_UB(256, CT, NT);             \
   } while (0)
+      const bool oob = ix->tune.ub_nt == 2 && KP * RB < ((int64_t)1 << 30);   // the table behind a 32-bit buffer offset
       if (ix->K <= 65536) {
-        if (ix->tune.ub_nt) NP_LAUNCH_UB_RB(uint16_t, true);
-        else NP_LAUNCH_UB_RB(uint16_t, false);
+        if (oob) NP_LAUNCH_UB_RB(uint16_t, 2);
+        else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint16_t, 1);
+        else NP_LAUNCH_UB_RB(uint16_t, 0);
       } else {
-        if (ix->tune.ub_nt) NP_LAUNCH_UB_RB(uint32_t, true);
-        else NP_LAUNCH_UB_RB(uint32_t, false);
+        if (oob) NP_LAUNCH_UB_RB(uint32_t, 2);
+        else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint32_t, 1);
+        else NP_LAUNCH_UB_RB(uint32_t, 0);
       }
 #undef NP_LAUNCH_UB_RB
 #undef NP_LAUNCH_UB

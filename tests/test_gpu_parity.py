@@ -90,7 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 2), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0)):
+    for k, v in (("s4_mode", 2), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 0)):
         hx.tune(k, v)
 
 
@@ -235,15 +235,20 @@ def test_s4_filter_preserves_selection(mid, tuned):
         ref = hx.search_batch(batch, p)
         st0 = dict(hx.last_stats)
         hx.tune("s4_filter", 1)
-        got = hx.search_batch(batch, p)
-        st1 = dict(hx.last_stats)
-        for i, (g, r) in enumerate(zip(got, ref)):
-            assert np.array_equal(g.passage_ids, r.passage_ids), f"nfs={nfs} q{i}: selected set / order changed"
-            assert np.array_equal(g.scores, r.scores), f"nfs={nfs} q{i}"
-        assert st1["n_candidates"] == st0["n_candidates"] and st1["n_cand_tokens"] == st0["n_cand_tokens"]
-        assert 0 < st1["n_survivors"] <= st1["n_candidates"]
-        if nfs == 512:
-            assert st1["n_survivors"] < st1["n_candidates"] // 2, st1
+        surv = set()
+        for ub_mode in (0, 1, 2):      # plain / non-temporal / bounds-checked buffer loads of the u8 table
+            hx.tune("ub_nt", ub_mode)
+            got = hx.search_batch(batch, p)
+            st1 = dict(hx.last_stats)
+            for i, (g, r) in enumerate(zip(got, ref)):
+                assert np.array_equal(g.passage_ids, r.passage_ids), f"nfs={nfs} ub={ub_mode} q{i}: selected set / order changed"
+                assert np.array_equal(g.scores, r.scores), f"nfs={nfs} ub={ub_mode} q{i}"
+            assert st1["n_candidates"] == st0["n_candidates"] and st1["n_cand_tokens"] == st0["n_cand_tokens"]
+            assert 0 < st1["n_survivors"] <= st1["n_candidates"]
+            if nfs == 512:
+                assert st1["n_survivors"] < st1["n_candidates"] // 2, st1
+            surv.add(st1["n_survivors"])
+        assert len(surv) == 1, surv       # the integer bounds U(d) do not depend on the load flavour
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got[:8], orc):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
@@ -343,6 +348,29 @@ def test_float16_index_files(tmp_path):
     p = P(n_full_scores=128, top_k=10, n_ivf_probe=8)
     for r1, r2 in zip(hd.search_batch(qs, p), ha.search_batch(qs, p)):
         assert np.array_equal(r1.passage_ids, r2.passage_ids) and np.array_equal(r1.scores, r2.scores)
+
+
+def test_token_sorted_layout_is_transparent(monkeypatch):
+    """NP_TOK_SORT=1 stores every document's tokens ordered by code (opt-in S6 gather locality): search results,
+    decompress_documents and export are unchanged."""
+    spec, a = make_arrays(num_docs=700, num_centroids=128, dim=64, nbits=4, doc_len_min=3, doc_len_max=60, seed=23)
+    plain = hip_index(a)
+    monkeypatch.setenv("NP_TOK_SORT", "1")
+    srt = hip_index(a)
+    monkeypatch.delenv("NP_TOK_SORT")
+    assert srt.info.device_bytes > plain.info.device_bytes          # the position array
+    qs, _ = synth.make_queries(spec, 4, n_tokens=24, cen=a["centroids"])
+    p = P(n_full_scores=256, top_k=10, n_ivf_probe=8)
+    for r1, r2 in zip(plain.search_batch(qs, p), srt.search_batch(qs, p)):
+        assert np.array_equal(r1.passage_ids, r2.passage_ids)
+        np.testing.assert_allclose(r1.scores, r2.scores, rtol=2e-6)     # max over tokens is order-free; sums are per query token
+    ids = np.array([0, 5, 699, 17], np.int64)
+    e1, l1 = plain.decompress_documents(ids)
+    e2, l2 = srt.decompress_documents(ids)
+    assert np.array_equal(l1, l2) and np.array_equal(e1, e2)
+    x1, x2 = plain.export(), srt.export()
+    for k in ("codes", "residuals", "ivf", "ivf_lengths", "doc_lengths"):
+        assert np.array_equal(x1[k], x2[k]), k
 
 
 def test_synth_device_generator_matches_numpy_spec():
