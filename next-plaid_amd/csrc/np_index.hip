@@ -73,7 +73,9 @@ void read_tuning_env(Tuning* t) {
   t->s4_swz = env("NP_S4_SWZ", t->s4_swz) != 0;
   t->s4_filter = env("NP_S4_FILTER", t->s4_filter) != 0;
   t->ub_nt = env("NP_UB_NT", t->ub_nt);
+  t->ub_steal = env("NP_UB_STEAL", t->ub_steal);
   t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
+  t->s6_rep = env("NP_S6_REP", t->s6_rep) != 0;
   t->gemm_cpw = env("NP_GEMM_CPW", t->gemm_cpw) == 2 ? 2 : 1;
   t->exact_rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
 }
@@ -1039,7 +1041,9 @@ int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
   else if (n == "s4_swz") t.s4_swz = value != 0;
   else if (n == "s4_filter") t.s4_filter = value != 0;
   else if (n == "ub_nt") t.ub_nt = value < 0 || value > 2 ? 0 : value;
+  else if (n == "ub_steal") t.ub_steal = value < 1 ? 1 : value;
   else if (n == "s6_xcd") t.s6_xcd = value != 0;
+  else if (n == "s6_rep") t.s6_rep = value != 0;
   else if (n == "gemm_cpw") t.gemm_cpw = value == 2 ? 2 : 1;
   else if (n == "exact_rowmax") t.exact_rowmax = value != 0;
   else {

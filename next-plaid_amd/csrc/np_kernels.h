@@ -832,13 +832,17 @@ __global__ void __launch_bounds__(256) plan_rounds_kernel(const int32_t* __restr
 // at step j every workgroup of XCD x works on the query in slot[x][j], which the first of them to arrive fills with
 // the next entry of the heaviest-first order (global ticket).  -1 = empty, -2 = being filled, -3 = no query left.
 // The workgroup that fills a slot is running, so nobody waits on a workgroup that is not resident.
+// Once the order is exhausted the filling workgroup calls `steal()`: it may name a query that another XCD is still
+// working on (its documents are claimed from a shared cursor, so any number of XCDs can share one query) or return -3.
+template <class Steal>
 __device__ __forceinline__ int xcd_next_query(int32_t* slots, int32_t* ticket, int x, int step, int B,
-                                              const int32_t* order, int rb, int re) {
+                                              const int32_t* order, int rb, int re, Steal&& steal) {
+  if (step > B) return -3;   // slots hold B + 1 steps per XCD
   int32_t* slot = slots + (int64_t)x * (B + 1) + step;
   int v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (v == -1 && atomicCAS(slot, -1, -2) == -1) {
     const int t = atomicAdd(ticket, 1);
-    v = (t < re - rb) ? order[rb + t] : -3;
+    v = (t < re - rb) ? order[rb + t] : steal();
     __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
   }
@@ -1569,6 +1573,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         uint32_t* __restrict__ cursor /* [B] zeroed: next unclaimed candidate */,
                                                         int32_t* __restrict__ slots /* [8][B+1] = -1 */,
                                                         int32_t* __restrict__ ticket /* [1] = 0 */, int B,
+                                                        int steal_min /* unclaimed documents worth joining a query for */,
                                                         Counters* ctr) {
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
@@ -1598,7 +1603,24 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   __shared__ int s_q;
   for (int step = 0;; ++step) {
     __syncthreads();
-    if (tid == 0) s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re);
+    if (tid == 0)
+      s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
+        // no query left to start: join the one with the most unclaimed documents, if that is worth pulling its table
+        // into this XCD's L2 (the end of the launch otherwise waits for the XCDs that drew the last queries)
+        int best = -3;
+        int64_t most = steal_min;
+        for (int j = rb; j < re; ++j) {
+          const int b2 = rp.order[j];
+          const int64_t n2 = n_cand[b2];
+          if (qflag[b2] || n2 <= (int64_t)n_sel) continue;
+          const int64_t left = n2 - (int64_t)__hip_atomic_load(&cursor[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (left >= most) {
+            most = left;
+            best = b2;
+          }
+        }
+        return best;
+      });
     __syncthreads();
     const int b = __builtin_amdgcn_readfirstlane(s_q);
     if (b < 0) break;
@@ -1851,26 +1873,39 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
   const bool all = thr == 0;
   if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
   unsigned long long toks = 0, ucnt = 0;   // work counters of the queries the filter kernel skipped
-  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {   // block-uniform trip count
-    const int64_t i = i0 + tid;
-    const bool keep = i < n && (all || ((uint32_t)U[pbase + i] >> hshift) >= thr);
-    const unsigned long long bal = __ballot(keep);
-    if (lane == 0) s_wcnt[wave] = (int)__popcll(bal);
+  // 8 candidates per thread and step: one append (same-address atomic) and two barriers per 2048 candidates
+  constexpr int PT = 8;
+  for (int64_t i0 = (int64_t)blockIdx.x * (256 * PT); i0 < n; i0 += (int64_t)gridDim.x * (256 * PT)) {   // block-uniform trip count
+    bool keep[PT];
+    unsigned long long bal[PT];
+    int wtot = 0;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const int64_t i = i0 + k * 256 + tid;
+      keep[k] = i < n && (all || ((uint32_t)U[pbase + i] >> hshift) >= thr);
+      bal[k] = __ballot(keep[k]);
+      wtot += (int)__popcll(bal[k]);
+    }
+    if (lane == 0) s_wcnt[wave] = wtot;
     __syncthreads();
-    if (tid == 0) {   // one append per workgroup and step
+    if (tid == 0) {
       const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
       s_base = tot ? atomicAdd(&n_surv[b], tot) : 0;
     }
     __syncthreads();
-    if (keep) {
-      int pos = s_base + (int)__popcll(bal & ((1ull << lane) - 1ull));
-      for (int k = 0; k < wave; ++k) pos += s_wcnt[k];
-      const uint4 m = cand_meta[pbase + i];
-      surv_meta[pbase + pos] = m;
-      if (all) {
-        toks += (unsigned long long)(m.w >> 8);
-        ucnt += (unsigned long long)m.y;
+    int pos = s_base;
+    for (int k = 0; k < wave; ++k) pos += s_wcnt[k];
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      if (keep[k]) {
+        const uint4 m = cand_meta[pbase + i0 + k * 256 + tid];
+        surv_meta[pbase + pos + (int)__popcll(bal[k] & ((1ull << lane) - 1ull))] = m;
+        if (all) {
+          toks += (unsigned long long)(m.w >> 8);
+          ucnt += (unsigned long long)m.y;
+        }
       }
+      pos += (int)__popcll(bal[k]);
     }
     __syncthreads();
   }
@@ -2684,8 +2719,13 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
   (void)ndocs;
 }
 
-template <int DIM, int NBITS, int NQT, int SPLIT>
-__global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
+// REP: copies of the byte -> bf16 LUT in LDS, lane l reads copy l % REP.  With one copy the 32 lanes of a half-wave hit
+// 256 random 8-B entries over 32 bank pairs: ~3.5 passes per ds_read_b64 and the LUT reads are the kernel's largest
+// term (measured: 57 % of LDS cycles are bank conflicts).  REP = 32 (64 KB, entry e of copy r at word 64 e + 2 r) gives
+// every lane of a half-wave its own bank pair whatever the bytes are: conflict-free.  WPK = waves per workgroup (6 with
+// REP = 32: two 64-KB workgroups per CU = the 12 waves per CU the register count allows anyway).
+template <int DIM, int NBITS, int NQT, int SPLIT, int REP, int WPK>
+__global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
   constexpr int NS = DIM / 16;            // MFMA k-steps
   constexpr int PD = DIM * NBITS / 8;     // bytes per token
   constexpr int PH = PD / 2;              // bytes per lane: lane (tok, kk) owns dims [kk*DIM/2, +DIM/2)
@@ -2693,7 +2733,8 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
   constexpr int WPB = (NBITS == 4) ? 1 : 2;  // u32 words of packed bf16 per residual byte (2 or 4 values)
   static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0, "unsupported DIM/NBITS");
   // byte -> {hi words, lo words}: one LDS read per residual byte returns both halves of the split
-  __shared__ uint32_t lut[256 * WPB * 2];
+  static_assert(REP == 1 || (REP == 32 && NBITS == 4), "replicated LUT: 8-B entries only");
+  __shared__ uint32_t lut[256 * WPB * 2 * REP];
   // S6 gathers one 128-B row of the query's score table per token (the MFMA C-in): the same L2-miss-bound
   // access as S4.  With xcd_B set, all workgroups of a query run on ONE XCD (workgroup w -> XCD w % 8), so rows
   // are reused out of that XCD's L2 instead of being refetched by eight.
@@ -2705,7 +2746,7 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
     if (b >= p.xcd_B) return;
   }
   const int tid = threadIdx.x;
-  {
+  if (tid < 256) {
     constexpr int PER = 8 / NBITS;
     constexpr uint32_t MASK = (1u << NBITS) - 1u;
     uint16_t hh[4] = {0, 0, 0, 0}, ll[4] = {0, 0, 0, 0};
@@ -2719,12 +2760,13 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
     }
 #pragma unroll
     for (int w2 = 0; w2 < WPB; ++w2) {
-      lut[(tid * WPB + w2) * 2 + 0] = (uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16);
-      lut[(tid * WPB + w2) * 2 + 1] = (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16);
+      const uint2 e = make_uint2((uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16),
+                                 (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16));
+      for (int r = 0; r < REP; ++r) reinterpret_cast<uint2*>(lut)[(tid * WPB + w2) * REP + r] = e;
     }
   }
   __syncthreads();
-  const uint2* lut2 = reinterpret_cast<const uint2*>(lut);
+  const uint2* lut2 = reinterpret_cast<const uint2*>(lut) + (REP > 1 ? (threadIdx.x & (REP - 1)) : 0);
   const int LQP = p.LQP;
   const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
   const int Lq = p.qoff[b + 1] - p.qoff[b];
@@ -2744,7 +2786,7 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
   }
   unsigned long long toks = 0, ndocs = 0;
   for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
-    const int j = (bx * 4 + wave) * NP_EXACT_DPW + dd;
+    const int j = (bx * WPK + wave) * NP_EXACT_DPW + dd;
     if (j >= nsel) break;
     const int64_t oj = (int64_t)b * p.n_sel + j;
     if (p.sel_keys[oj] < cut) {
@@ -2818,7 +2860,7 @@ __global__ void __launch_bounds__(256) exact_qct_kernel(ExactP p) {
           const uint32_t word = rw[s];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const uint2 e = lut2[(word >> (8 * i)) & 0xFFu];
+            const uint2 e = lut2[((word >> (8 * i)) & 0xFFu) * REP];
             wh[i] = e.x;
             wl[i] = e.y;
           }

@@ -244,14 +244,26 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
     // row-max form, whose running maxima need one register per query tile instead of sixteen
     if (NQT <= 2 && !ix->tune.exact_rowmax) {
       ExactP px = p;
-      dim3 grid(gx, B);
+      // conflict-free replicated LUT (64 KB, six waves per workgroup) for 4-bit residuals; see exact_qct_kernel
+      const bool rep = NBITS == 4 && ix->tune.s6_rep;
+      const unsigned wpk = rep ? 6 : 4;
+      const unsigned gq = (unsigned)((p.n_sel + wpk * NP_EXACT_DPW - 1) / (wpk * NP_EXACT_DPW));
+      dim3 grid(gq, B);
       if (B >= 8 && ix->tune.s6_xcd) {   // one XCD per query (see exact_qct_kernel)
         px.xcd_B = B;
-        px.gx = (int)gx;
-        grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
+        px.gx = (int)gq;
+        grid = dim3(8u * (unsigned)((B + 7) / 8) * gq, 1);
       }
-      if (precision == 1) exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 1><<<grid, 256, 0, st>>>(px);
-      else exact_qct_kernel<DIM, NBITS, (NQT <= 2 ? NQT : 1), 3><<<grid, 256, 0, st>>>(px);
+      constexpr int NQ = NQT <= 2 ? NQT : 1;
+      if constexpr (NBITS == 4) {
+        if (rep) {
+          if (precision == 1) exact_qct_kernel<DIM, NBITS, NQ, 1, 32, 6><<<grid, 384, 0, st>>>(px);
+          else exact_qct_kernel<DIM, NBITS, NQ, 3, 32, 6><<<grid, 384, 0, st>>>(px);
+          return NP_OK;
+        }
+      }
+      if (precision == 1) exact_qct_kernel<DIM, NBITS, NQ, 1, 1, 4><<<grid, 256, 0, st>>>(px);
+      else exact_qct_kernel<DIM, NBITS, NQ, 3, 1, 4><<<grid, 256, 0, st>>>(px);
     } else {
       if (precision == 1) exact_qc_kernel<DIM, NBITS, NQT, 1><<<dim3(gx, B), 256, 0, st>>>(p);
       else exact_qc_kernel<DIM, NBITS, NQT, 3><<<dim3(gx, B), 256, 0, st>>>(p);
@@ -559,7 +571,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
                                                           w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,     \
                                                           w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),       \
                                                           w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(), \
-                                                          xslots, xticket, B, w.ctr.as<Counters>())
+                                                          xslots, xticket, B, ix->tune.ub_steal, w.ctr.as<Counters>())
 #define NP_LAUNCH_UB_RB(CT, NT)                 \
   do {                                          \
     if (RB == 32) NP_LAUNCH_UB(32, CT, NT);     \
