@@ -111,7 +111,7 @@ struct Tuning {
   int ub_steal = 16384;  // filter: an idle XCD joins a running query that has at least this many unclaimed documents (0x7fffffff = never)
   int ub_nt = 2;         // filter loads: 0 plain, 1 non-temporal records / code lists, 2 bounds-checked buffer loads of the table
   int s6_xcd = 1;        // one XCD per query in S6
-  int s6_rep = 1;        // S6 QC-reuse kernel: 32 bank-aligned copies of the byte LUT (4-bit residuals)
+  int s6_rep = 0;        // S6 QC-reuse kernel: 16 bank-aligned copies of the byte LUT (4-bit residuals)
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };

@@ -1569,7 +1569,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
                                                         int max_rounds, const uint32_t* __restrict__ codes,
                                                         const uint32_t* __restrict__ qflag, int n_sel,
-                                                        uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift,
+                                                        uint16_t* __restrict__ U,
                                                         uint32_t* __restrict__ cursor /* [B] zeroed: next unclaimed candidate */,
                                                         int32_t* __restrict__ slots /* [8][B+1] = -1 */,
                                                         int32_t* __restrict__ ticket /* [1] = 0 */, int B,
@@ -1586,25 +1586,25 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   // per lane), and the gathers take their codes from there.  (Reading it 16 B at a time per lane as the walk
   // proceeds keeps ~3 lines per document live for the whole walk -- 6 MB per XCD next to the 2 MB table: measured
   // 30 M L2 misses and 8x over-fetch per launch.)
-  __shared__ uint32_t s_hist[NP_UB_BINS / 2];          // two u16 counters per word (a block sees < 65536 docs per query)
   __shared__ CT s_codes[4][DPW][CAP];
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
-  const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
+  const int x = blockIdx.x & 7;
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
   unsigned long long toks = 0, ucnt = 0;
   const int half = lane >> 5, hl = lane & 31;   // staging: half-wave `half` loads 4 codes per lane of one document
-  // The waves of an XCD claim the query's documents DPW at a time from a per-query cursor, so every workgroup of
-  // the XCD finishes a query within one claim of the others and moves on together: with a fixed share per
-  // workgroup the fast ones run ahead, two queries' tables (2 x 2 MB) are live in the 4 MB L2 and the gathers miss.
-  __shared__ int s_q;
+  // The waves of an XCD claim the query's documents DPW at a time from a per-query cursor, so every wave of the XCD
+  // finishes a query within one claim of the others and moves on: with a fixed share per workgroup the fast ones run
+  // ahead, two queries' tables (2 x 2 MB) are live in the 4 MB L2 and the gathers miss.  Waves are independent (no
+  // workgroup barrier per query: at 18 k documents per query a wave gets one or two claims and would wait for its
+  // slowest sibling at every query); the histogram of U is taken afterwards by ub_hist_kernel.
   for (int step = 0;; ++step) {
-    __syncthreads();
-    if (tid == 0)
-      s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
+    int bq = 0;
+    if (lane == 0)
+      bq = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
         // no query left to start: join the one with the most unclaimed documents, if that is worth pulling its table
         // into this XCD's L2 (the end of the launch otherwise waits for the XCDs that drew the last queries)
         int best = -3;
@@ -1621,8 +1621,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         }
         return best;
       });
-    __syncthreads();
-    const int b = __builtin_amdgcn_readfirstlane(s_q);
+    const int b = __builtin_amdgcn_readfirstlane(bq);
     if (b < 0) break;
     const int64_t n = n_cand[b];
     if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
@@ -1635,11 +1634,6 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tb64 >> 32));
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((uint64_t)thi << 32) | tlo), 0, (int)(KP * ROWB), 0x00020000);
-    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
-    const bool big = n / NBX >= 60000;   // a block could see >= 2^16 documents of one bin: count in memory instead
-    __syncthreads();
-    for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
-    __syncthreads();
     uint32_t inext = 0;
     if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
     for (;;) {
@@ -1780,19 +1774,8 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
       for (int k = 0; k < 16; ++k) sum += st[k];
 #pragma unroll
       for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
-      if (valid && jl == 0) {
-        U[pbase + i] = (uint16_t)sum;
-        const uint32_t bin = min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1));
-        if (big) atomicAdd(&hb[bin], 1u);
-        else atomicAdd(&s_hist[bin >> 1], 1u << (16 * (bin & 1)));
-      }
+      if (valid && jl == 0) U[pbase + i] = (uint16_t)sum;
       __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next one
-    }
-    __syncthreads();
-    for (int i = tid; i < NP_UB_BINS / 2; i += 256) {
-      const uint32_t v = s_hist[i];
-      if (v & 0xFFFFu) atomicAdd(&hb[2 * i], v & 0xFFFFu);
-      if (v >> 16) atomicAdd(&hb[2 * i + 1], v >> 16);
     }
   }
 #pragma unroll
@@ -1813,6 +1796,30 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   if (tid == 0 && s_cnt[0]) {
     atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
     atomicAdd(&ctr->n_cand_codes, s_cnt[1]);
+  }
+}
+
+// Histogram of the bounds U >> hshift per query (NP_UB_BINS bins, zeroed by the host): blocks (x, b) sweep the query's
+// candidates, count in LDS and add their non-empty bins to memory.
+__global__ void __launch_bounds__(256) ub_hist_kernel(const uint16_t* __restrict__ U, int hshift,
+                                                      const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
+                                                      const uint32_t* __restrict__ qflag, int n_sel,
+                                                      uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_hist[NP_UB_BINS];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (rp.round_of[b] != round) return;
+  const int64_t n = n_cand[b];
+  if (qflag[b] != 0 || n <= (int64_t)n_sel) return;
+  for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  const uint16_t* Ub = U + rp.cand_base[b];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256)
+    atomicAdd(&s_hist[min((uint32_t)Ub[i] >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
+  __syncthreads();
+  uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+  for (int i = tid; i < NP_UB_BINS; i += 256) {
+    const uint32_t v = s_hist[i];
+    if (v) atomicAdd(&hb[i], v);
   }
 }
 
@@ -2720,10 +2727,10 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
 }
 
 // REP: copies of the byte -> bf16 LUT in LDS, lane l reads copy l % REP.  With one copy the 32 lanes of a half-wave hit
-// 256 random 8-B entries over 32 bank pairs: ~3.5 passes per ds_read_b64 and the LUT reads are the kernel's largest
-// term (measured: 57 % of LDS cycles are bank conflicts).  REP = 32 (64 KB, entry e of copy r at word 64 e + 2 r) gives
-// every lane of a half-wave its own bank pair whatever the bytes are: conflict-free.  WPK = waves per workgroup (6 with
-// REP = 32: two 64-KB workgroups per CU = the 12 waves per CU the register count allows anyway).
+// 256 random 8-B entries over 32 bank pairs (~3.5 passes per ds_read_b64; 57 % of the kernel's LDS cycles are bank
+// conflicts).  REP = 16 (32 KB, entry e of copy r at word 32 e + 2 r): two lanes share a copy and collide only when
+// their bytes differ with equal parity -> 2 passes at most.  (REP = 32 / 64 KB / six waves per workgroup is
+// conflict-free but measured SLOWER, 0.91 vs 0.64 ms: two 64-KB workgroups per CU.)  WPK = waves per workgroup.
 template <int DIM, int NBITS, int NQT, int SPLIT, int REP, int WPK>
 __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
   constexpr int NS = DIM / 16;            // MFMA k-steps
@@ -2733,7 +2740,7 @@ __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
   constexpr int WPB = (NBITS == 4) ? 1 : 2;  // u32 words of packed bf16 per residual byte (2 or 4 values)
   static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0, "unsupported DIM/NBITS");
   // byte -> {hi words, lo words}: one LDS read per residual byte returns both halves of the split
-  static_assert(REP == 1 || (REP == 32 && NBITS == 4), "replicated LUT: 8-B entries only");
+  static_assert(REP == 1 || ((REP == 16 || REP == 32) && NBITS == 4), "replicated LUT: 8-B entries only");
   __shared__ uint32_t lut[256 * WPB * 2 * REP];
   // S6 gathers one 128-B row of the query's score table per token (the MFMA C-in): the same L2-miss-bound
   // access as S4.  With xcd_B set, all workgroups of a query run on ONE XCD (workgroup w -> XCD w % 8), so rows

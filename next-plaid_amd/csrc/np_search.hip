@@ -244,9 +244,9 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
     // row-max form, whose running maxima need one register per query tile instead of sixteen
     if (NQT <= 2 && !ix->tune.exact_rowmax) {
       ExactP px = p;
-      // conflict-free replicated LUT (64 KB, six waves per workgroup) for 4-bit residuals; see exact_qct_kernel
+      // 16 bank-aligned copies of the byte LUT (32 KB) for 4-bit residuals; see exact_qct_kernel
       const bool rep = NBITS == 4 && ix->tune.s6_rep;
-      const unsigned wpk = rep ? 6 : 4;
+      const unsigned wpk = 4;
       const unsigned gq = (unsigned)((p.n_sel + wpk * NP_EXACT_DPW - 1) / (wpk * NP_EXACT_DPW));
       dim3 grid(gq, B);
       if (B >= 8 && ix->tune.s6_xcd) {   // one XCD per query (see exact_qct_kernel)
@@ -257,8 +257,8 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
       constexpr int NQ = NQT <= 2 ? NQT : 1;
       if constexpr (NBITS == 4) {
         if (rep) {
-          if (precision == 1) exact_qct_kernel<DIM, NBITS, NQ, 1, 32, 6><<<grid, 384, 0, st>>>(px);
-          else exact_qct_kernel<DIM, NBITS, NQ, 3, 32, 6><<<grid, 384, 0, st>>>(px);
+          if (precision == 1) exact_qct_kernel<DIM, NBITS, NQ, 1, 16, 4><<<grid, 256, 0, st>>>(px);
+          else exact_qct_kernel<DIM, NBITS, NQ, 3, 16, 4><<<grid, 256, 0, st>>>(px);
           return NP_OK;
         }
       }
@@ -570,7 +570,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),            \
                                                           w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,     \
                                                           w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),       \
-                                                          w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(), \
+                                                          w.ub_cursor.as<uint32_t>(),                                   \
                                                           xslots, xticket, B, ix->tune.ub_steal, w.ctr.as<Counters>())
 #define NP_LAUNCH_UB_RB(CT, NT)                 \
   do {                                          \
@@ -591,10 +591,12 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       }
 #undef NP_LAUNCH_UB_RB
 #undef NP_LAUNCH_UB
+      const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
+      ub_hist_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), hshift, w.n_cand.as<int32_t>(), rp, r,
+                                                    w.qflag.as<uint32_t>(), cs->n_sel, w.ub_hist.as<uint32_t>());
       // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
       ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2 + (batched ? 1 : 0), cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
                                        w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
-      const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
       ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), w.ub_thr.as<uint32_t>(), hshift,
                                                    w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r,
                                                    w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), w.ctr.as<Counters>());
