@@ -72,6 +72,7 @@ void read_tuning_env(Tuning* t) {
   t->s4_nbx = std::min(std::max(env("NP_S4_NBX", t->s4_nbx), 8), 512);
   t->s4_swz = env("NP_S4_SWZ", t->s4_swz) != 0;
   t->s4_filter = env("NP_S4_FILTER", t->s4_filter) != 0;
+  t->s3_slices = env("NP_S3_SLICES", t->s3_slices) != 0;
   t->ub_nt = env("NP_UB_NT", t->ub_nt);
   t->ub_steal = env("NP_UB_STEAL", t->ub_steal);
   t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
@@ -1040,6 +1041,7 @@ int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
   else if (n == "s4_nbx") t.s4_nbx = std::min(std::max(value, 8), 512);
   else if (n == "s4_swz") t.s4_swz = value != 0;
   else if (n == "s4_filter") t.s4_filter = value != 0;
+  else if (n == "s3_slices") t.s3_slices = value != 0;
   else if (n == "ub_nt") t.ub_nt = value < 0 || value > 2 ? 0 : value;
   else if (n == "ub_steal") t.ub_steal = value < 1 ? 1 : value;
   else if (n == "s6_xcd") t.s6_xcd = value != 0;

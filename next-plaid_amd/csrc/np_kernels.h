@@ -743,6 +743,113 @@ __global__ void __launch_bounds__(256) mark_candidates_kernel(const uint32_t* __
 
 #define NP_CHUNK_WORDS 1024  // bitmap words per compaction block (32768 docs)
 
+// S3 without memory atomics: block (slice, b) owns a contiguous range of the query's document bitmap (a whole number
+// of compaction chunks, <= 128 KB) IN LDS, sweeps ALL of the query's posting lists and keeps the ids that fall into
+// its range (the lists come out of L2 for every slice after the first), then writes the range out coalesced together
+// with its chunk populations: no bitmap memset, no device-scope atomicOr over an 80 MB bitmap array (10 M documents
+// x 64 queries: those ran at ~30 G atomics/s), no separate count pass.  Work items are 512 consecutive entries of one
+// list, dealt round-robin to the 16 waves.
+#define NP_MARK_CELLS 1024   // probed cells staged per pass
+__global__ void __launch_bounds__(1024) mark_slices_kernel(const uint32_t* __restrict__ cells,
+                                                           const int32_t* __restrict__ n_cells, int64_t KP,
+                                                           const int64_t* __restrict__ ivf_off,
+                                                           const uint32_t* __restrict__ ivf,
+                                                           const uint32_t* __restrict__ subset_bits, int64_t NW,
+                                                           int slice_chunks, int nchunks, uint32_t* __restrict__ docbits,
+                                                           int32_t* __restrict__ chunk_counts, Counters* ctr) {
+  extern __shared__ uint32_t s_bits[];   // slice_chunks * NP_CHUNK_WORDS words
+  __shared__ int64_t s_start[NP_MARK_CELLS];
+  __shared__ uint32_t s_len[NP_MARK_CELLS];
+  __shared__ uint32_t s_items[NP_MARK_CELLS + 1];   // exclusive prefix of the lists' item counts
+  __shared__ uint32_t s_wsum[16];
+  const int b = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t w0 = (int64_t)sl * slice_chunks * NP_CHUNK_WORDS;
+  const int nw = (int)min((int64_t)slice_chunks * NP_CHUNK_WORDS, NW - w0);
+  const uint32_t lo = (uint32_t)(w0 * 32), span = (uint32_t)nw * 32u;
+  for (int i = tid; i < slice_chunks * NP_CHUNK_WORDS; i += 1024) s_bits[i] = 0;
+  const int nc = n_cells[b];
+  unsigned long long ids = 0;
+  for (int c0 = 0; c0 < nc; c0 += NP_MARK_CELLS) {
+    __syncthreads();   // the previous pass's tables are no longer read; s_bits zeroed
+    const int m = min(NP_MARK_CELLS, nc - c0);
+    uint32_t len = 0;
+    if (tid < m) {
+      const uint32_t c = cells[(int64_t)b * KP + c0 + tid];
+      const int64_t s0 = ivf_off[c];
+      len = (uint32_t)(ivf_off[c + 1] - s0);
+      s_start[tid] = s0;
+      s_len[tid] = len;
+      ids += len;
+    }
+    // exclusive scan of the item counts over the block
+    const uint32_t items = (len + 511u) >> 9;
+    uint32_t incl = items;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < wave; ++k) woff += s_wsum[k];
+    s_items[tid] = woff + incl - items;
+    if (tid == 1023) s_items[1024] = woff + incl;
+    __syncthreads();
+    const uint32_t total = s_items[1024];
+    for (uint32_t it = (uint32_t)wave; it < total; it += 16) {
+      int a = 0, z = m;   // the list this item belongs to: largest t with s_items[t] <= it (empty lists have no items)
+      while (z - a > 1) {
+        const int mid = (a + z) >> 1;
+        if (s_items[mid] <= it) a = mid;
+        else z = mid;
+      }
+      const uint32_t off = (it - s_items[a]) << 9, ln = s_len[a];
+      const uint32_t* src = ivf + s_start[a] + off;
+      uint32_t d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t j = k * 64 + lane;
+        d[k] = (off + j < ln) ? src[j] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t rel = d[k] - lo;
+        if (d[k] != 0xFFFFFFFFu && rel < span) {
+          const uint32_t bit = 1u << (d[k] & 31);
+          if (subset_bits && !(subset_bits[d[k] >> 5] & bit)) continue;   // search.rs:434-437
+          atomicOr(&s_bits[rel >> 5], bit);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // write the range out and count its chunks: wave w takes chunks w, w + 16, ...
+  uint32_t* bits = docbits + (int64_t)b * NW + w0;
+  for (int ch = wave; ch < slice_chunks; ch += 16) {
+    const int64_t gch = (int64_t)sl * slice_chunks + ch;
+    if (gch >= nchunks) break;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < NP_CHUNK_WORDS / 64; ++k) {
+      const int w = ch * NP_CHUNK_WORDS + k * 64 + lane;
+      if (w < nw) {
+        const uint32_t v = s_bits[w];
+        bits[w] = v;
+        cnt += __popc(v);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) chunk_counts[(int64_t)b * nchunks + gch] = cnt;
+  }
+  if (sl == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ids += __shfl_xor(ids, o);
+    if (lane == 0 && ids) atomicAdd(&ctr->n_ivf_ids, ids);
+  }
+}
+
 __global__ void __launch_bounds__(256) count_chunks_kernel(const uint32_t* __restrict__ docbits, int64_t NW,
                                                            int nchunks, int32_t* __restrict__ chunk_counts) {
   __shared__ int s_cnt;
@@ -1569,7 +1676,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
                                                         int max_rounds, const uint32_t* __restrict__ codes,
                                                         const uint32_t* __restrict__ qflag, int n_sel,
-                                                        uint16_t* __restrict__ U,
+                                                        uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift,
                                                         uint32_t* __restrict__ cursor /* [B] zeroed: next unclaimed candidate */,
                                                         int32_t* __restrict__ slots /* [8][B+1] = -1 */,
                                                         int32_t* __restrict__ ticket /* [1] = 0 */, int B,
@@ -1586,25 +1693,25 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   // per lane), and the gathers take their codes from there.  (Reading it 16 B at a time per lane as the walk
   // proceeds keeps ~3 lines per document live for the whole walk -- 6 MB per XCD next to the 2 MB table: measured
   // 30 M L2 misses and 8x over-fetch per launch.)
+  __shared__ uint32_t s_hist[NP_UB_BINS / 2];          // two u16 counters per word (a block sees < 65536 docs per query)
   __shared__ CT s_codes[4][DPW][CAP];
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
-  const int x = blockIdx.x & 7;
+  const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
   unsigned long long toks = 0, ucnt = 0;
   const int half = lane >> 5, hl = lane & 31;   // staging: half-wave `half` loads 4 codes per lane of one document
-  // The waves of an XCD claim the query's documents DPW at a time from a per-query cursor, so every wave of the XCD
-  // finishes a query within one claim of the others and moves on: with a fixed share per workgroup the fast ones run
-  // ahead, two queries' tables (2 x 2 MB) are live in the 4 MB L2 and the gathers miss.  Waves are independent (no
-  // workgroup barrier per query: at 18 k documents per query a wave gets one or two claims and would wait for its
-  // slowest sibling at every query); the histogram of U is taken afterwards by ub_hist_kernel.
+  // The waves of an XCD claim the query's documents DPW at a time from a per-query cursor, so every workgroup of
+  // the XCD finishes a query within one claim of the others and moves on together: with a fixed share per
+  // workgroup the fast ones run ahead, two queries' tables (2 x 2 MB) are live in the 4 MB L2 and the gathers miss.
+  __shared__ int s_q;
   for (int step = 0;; ++step) {
-    int bq = 0;
-    if (lane == 0)
-      bq = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
+    __syncthreads();
+    if (tid == 0)
+      s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
         // no query left to start: join the one with the most unclaimed documents, if that is worth pulling its table
         // into this XCD's L2 (the end of the launch otherwise waits for the XCDs that drew the last queries)
         int best = -3;
@@ -1621,7 +1728,8 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         }
         return best;
       });
-    const int b = __builtin_amdgcn_readfirstlane(bq);
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(s_q);
     if (b < 0) break;
     const int64_t n = n_cand[b];
     if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
@@ -1634,6 +1742,11 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tb64 >> 32));
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((uint64_t)thi << 32) | tlo), 0, (int)(KP * ROWB), 0x00020000);
+    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+    const bool big = n / NBX >= 60000;   // a block could see >= 2^16 documents of one bin: count in memory instead
+    __syncthreads();
+    for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
+    __syncthreads();
     uint32_t inext = 0;
     if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
     for (;;) {
@@ -1774,8 +1887,19 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
       for (int k = 0; k < 16; ++k) sum += st[k];
 #pragma unroll
       for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
-      if (valid && jl == 0) U[pbase + i] = (uint16_t)sum;
+      if (valid && jl == 0) {
+        U[pbase + i] = (uint16_t)sum;
+        const uint32_t bin = min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1));
+        if (big) atomicAdd(&hb[bin], 1u);
+        else atomicAdd(&s_hist[bin >> 1], 1u << (16 * (bin & 1)));
+      }
       __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next one
+    }
+    __syncthreads();
+    for (int i = tid; i < NP_UB_BINS / 2; i += 256) {
+      const uint32_t v = s_hist[i];
+      if (v & 0xFFFFu) atomicAdd(&hb[2 * i], v & 0xFFFFu);
+      if (v >> 16) atomicAdd(&hb[2 * i + 1], v >> 16);
     }
   }
 #pragma unroll
@@ -1796,30 +1920,6 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   if (tid == 0 && s_cnt[0]) {
     atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
     atomicAdd(&ctr->n_cand_codes, s_cnt[1]);
-  }
-}
-
-// Histogram of the bounds U >> hshift per query (NP_UB_BINS bins, zeroed by the host): blocks (x, b) sweep the query's
-// candidates, count in LDS and add their non-empty bins to memory.
-__global__ void __launch_bounds__(256) ub_hist_kernel(const uint16_t* __restrict__ U, int hshift,
-                                                      const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
-                                                      const uint32_t* __restrict__ qflag, int n_sel,
-                                                      uint32_t* __restrict__ hist) {
-  __shared__ uint32_t s_hist[NP_UB_BINS];
-  const int b = blockIdx.y, tid = threadIdx.x;
-  if (rp.round_of[b] != round) return;
-  const int64_t n = n_cand[b];
-  if (qflag[b] != 0 || n <= (int64_t)n_sel) return;
-  for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
-  __syncthreads();
-  const uint16_t* Ub = U + rp.cand_base[b];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256)
-    atomicAdd(&s_hist[min((uint32_t)Ub[i] >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
-  __syncthreads();
-  uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
-  for (int i = tid; i < NP_UB_BINS; i += 256) {
-    const uint32_t v = s_hist[i];
-    if (v) atomicAdd(&hb[i], v);
   }
 }
 

@@ -438,7 +438,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_HIP(hipMemsetAsync(w.nsel.p, 0, (size_t)B * 4, st));
   NP_HIP(hipMemsetAsync(w.cellbits.p, 0, (size_t)B * G * 4, st));
   NP_HIP(hipMemsetAsync(w.tauq.p, 0, (size_t)B * LQP * 4, st));
-  if (NW > 0) NP_HIP(hipMemsetAsync(w.docbits.p, 0, (size_t)B * NW * 4, st));
+  if (NW > 0 && !ix->tune.s3_slices) NP_HIP(hipMemsetAsync(w.docbits.p, 0, (size_t)B * NW * 4, st));   // mark_slices_kernel writes every word
   if (cs->n_sel > 0) NP_HIP(hipMemsetAsync(w.sel_keys.p, 0, (size_t)B * cs->n_sel * 8, st));
   if (use_filter && B > 0) {
     NP_HIP(hipMemsetAsync(w.ub_hist.p, 0, (size_t)B * NP_UB_BINS * 4, st));
@@ -525,12 +525,30 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   rp.order = w.q_order.as<int32_t>();
   const bool have_cands = !cs->empty_subset && ix->n_docs > 0;
   if (have_cands) {
-    mark_candidates_kernel<<<dim3(128, B), 256, 0, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
-                                                         ix->d_ivf_offsets, ix->d_ivf,
-                                                         have_subset ? w.subset_bits.as<uint32_t>() : nullptr, NW,
-                                                         w.docbits.as<uint32_t>(), w.ctr.as<Counters>());
-    count_chunks_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
-                                                          w.chunk_counts.as<int32_t>());
+    if (ix->tune.s3_slices) {
+      // bitmap ranges in LDS (mark_slices_kernel): ranges of <= 32 chunks, enough of them to fill the chip, at most 16
+      // sweeps of the posting lists per query beyond what the range size forces
+      const int smin = (nchunks + 31) / 32, swant = std::min(16, (512 + B - 1) / B);
+      const int ns0 = std::max(smin, std::min(swant, nchunks));
+      const int slice_chunks = (nchunks + ns0 - 1) / ns0;
+      const int nslices = (nchunks + slice_chunks - 1) / slice_chunks;
+      const size_t lds = (size_t)slice_chunks * NP_CHUNK_WORDS * 4;
+      if (lds > 32 * 1024)
+        NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mark_slices_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      mark_slices_kernel<<<dim3(nslices, B), 1024, lds, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
+                                                              ix->d_ivf_offsets, ix->d_ivf,
+                                                              have_subset ? w.subset_bits.as<uint32_t>() : nullptr, NW,
+                                                              slice_chunks, nchunks, w.docbits.as<uint32_t>(),
+                                                              w.chunk_counts.as<int32_t>(), w.ctr.as<Counters>());
+    } else {
+      mark_candidates_kernel<<<dim3(128, B), 256, 0, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
+                                                           ix->d_ivf_offsets, ix->d_ivf,
+                                                           have_subset ? w.subset_bits.as<uint32_t>() : nullptr, NW,
+                                                           w.docbits.as<uint32_t>(), w.ctr.as<Counters>());
+      count_chunks_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
+                                                            w.chunk_counts.as<int32_t>());
+    }
     plan_rounds_kernel<<<1, 256, 0, st>>>(w.chunk_counts.as<int32_t>(), nchunks, B, pool, max_rounds, rp,
                                           w.ctr.as<Counters>());
   }
@@ -570,7 +588,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),            \
                                                           w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,     \
                                                           w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),       \
-                                                          w.ub_cursor.as<uint32_t>(),                                   \
+                                                          w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(), \
                                                           xslots, xticket, B, ix->tune.ub_steal, w.ctr.as<Counters>())
 #define NP_LAUNCH_UB_RB(CT, NT)                 \
   do {                                          \
@@ -592,8 +610,6 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
 #undef NP_LAUNCH_UB_RB
 #undef NP_LAUNCH_UB
       const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
-      ub_hist_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), hshift, w.n_cand.as<int32_t>(), rp, r,
-                                                    w.qflag.as<uint32_t>(), cs->n_sel, w.ub_hist.as<uint32_t>());
       // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
       ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2 + (batched ? 1 : 0), cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
                                        w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
