@@ -573,7 +573,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   // the candidates overflow the pool; later rounds are charged to S5)
   for (int r = 0; r < (have_cands ? max_rounds : 0); ++r) {
     compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
-                                                     w.chunk_counts.as<int32_t>(), w.cand.as<uint32_t>(), rp, r,
+                                                     w.chunk_counts.as<int32_t>(), use_filter ? nullptr : w.cand.as<uint32_t>(), rp, r,
                                                      ix->d_doc_meta, w.cand_meta.as<uint4>());
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
     if (use_filter) {
