@@ -103,7 +103,8 @@ struct Context {
 // NP_S4_SWZ, NP_S4_FILTER, NP_S6_XCD, NP_GEMM_CPW, NP_EXACT_ROWMAX); np_hip_index_tune() changes them on a live handle
 // for sweep tools and the kernel-variant parity tests.  Every setting produces identical results.
 struct Tuning {
-  int s4_mode = 2;       // 0 approx_kernel; 1..4 approx_xcd_kernel with 8/4/2/1 phases; 5..8 approx_stream_kernel
+  int s4_mode = 4;       // 0 approx_kernel; 1..4 approx_xcd_kernel with 8/4/2/1 phases; 5..8 approx_stream_kernel (the survivor lists
+                         // of the filter are short: one phase measured best; 2 was best on unfiltered 18 k-document lists)
   int s4_minb = 8;       // smallest batch that takes the per-XCD kernels
   int s4_nbx = 128;      // workgroups per XCD
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast

@@ -285,6 +285,7 @@ struct ProbeP {
   const int32_t* n_elig;   // popcount of elig, else NULL
   int has_thr;
   float thr;
+  int lds_gm;              // probe_mark_kernel was launched with KP/32 * NP_PROBE_QW * 4 bytes of dynamic LDS
   int64_t slab;            // > 0: batched-probe semantics (search.rs:140-254) with this centroid_batch_size
   uint32_t* cellbits;      // [B][KP/32] zeroed
   uint32_t* tauq;          // [B][LQP] per token: okey of its n_probe-th best centroid (0 = everything)
@@ -299,31 +300,43 @@ struct ProbeP {
 // Per-token tail of the probe: among the elements of the surviving groups find the n_probe best and
 // mark them.  One WAVE per token; element keys (+1, 0 = absent) live in 32 registers per lane and the
 // n_probe-th largest is found by a 32-step bitwise search with ballot/popcount counting.
+// Number of (slot, lane) keys satisfying `pred`, over the whole wave.  Each lane counts its own slots with VALU
+// compares (<= 32, six bits), then six ballots weigh the bits: one ballot -> s_bcnt1 round trip per SLOT (32 per
+// counting step, each ~100 cycles of VALU -> SALU latency with one wave per SIMD) made this search 75 % of
+// probe_mark_kernel's time.
+template <class Pred>
+__device__ __forceinline__ uint32_t wave_count(int nslots, const uint32_t (&keys)[32], Pred&& pred) {
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) mine += (j < nslots && pred(keys[j])) ? 1u : 0u;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) cnt += (uint32_t)__popcll(__ballot((mine >> b) & 1u)) << b;
+  return cnt;
+}
+
 __device__ __forceinline__ void wave_select_mark(int nslots, uint32_t n_probe, const uint32_t (&keys)[32],
                                                  uint32_t& tau, uint32_t& rem) {
   uint32_t prefix = 0;
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t trial = prefix | (1u << bit);
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) cnt += (uint32_t)__popcll(__ballot(j < nslots && keys[j] >= trial));
-    if (cnt >= n_probe) prefix = trial;
+    if (wave_count(nslots, keys, [&](uint32_t k) { return k >= trial; }) >= n_probe) prefix = trial;
   }
-  uint32_t gt = 0;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) gt += (uint32_t)__popcll(__ballot(j < nslots && keys[j] > prefix));
+  const uint32_t gt = wave_count(nslots, keys, [&](uint32_t k) { return k > prefix; });
   tau = prefix;
   rem = n_probe > gt ? n_probe - gt : 0u;
 }
 
-#define NP_PROBE_QW 8   // query tokens per probe block: grid = (LQP / 8, B)
+#define NP_PROBE_QW 4   // query tokens per probe block: grid = (LQP / 4, B): one token per wave, two blocks per CU
 __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
   constexpr int QW = NP_PROBE_QW;
   __shared__ uint32_t hist[256 * QW];
   __shared__ uint32_t part[256];
   __shared__ uint32_t s_prefix[QW], s_rem[QW], s_taug[QW], s_gcnt[QW];
   __shared__ uint32_t s_glist[QW * NP_PROBE_CAPG];
+  extern __shared__ uint32_t s_gm[];   // [G][QW] group maxima of the block's tokens when the launch provides the space
   constexpr int NR = 256 / QW;
+  const bool lds_gm = p.lds_gm != 0;
   const int b = blockIdx.y, qc = blockIdx.x, tid = threadIdx.x, q = tid % QW, r = tid / QW;
   const int wave = tid >> 6, lane = tid & 63;
   const int Lq = p.qoff[b + 1] - p.qoff[b];
@@ -352,22 +365,40 @@ __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
       if (qc * QW >= Lq) return;
       const int qq = qc * QW + q;
       const bool qvalid = qq < Lq;
-      // ---- phase 1 (block, 32 tokens at once): tau_g[q] = n_probe-th largest group maximum
+      // ---- phase 1 (block, QW tokens at once): tau_g[q] = n_probe-th largest group maximum
+      // The group maxima are read five times (four radix passes + the survivor list): with lds_gm (K <= 65536: the
+      // block's QW x G keys are 64 KB) they come from memory ONCE, 16 loads in flight per thread, and the passes read
+      // LDS (s_gm[g * QW + q]: conflict-free) -- the kernel was bound by the latency of those strided re-reads.
       const bool use_groups = G > (int64_t)n_probe;
+      if (lds_gm) {
+        for (int64_t g0 = r; g0 < G; g0 += 16 * NR) {
+          uint32_t kv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) kv[u] = (qvalid && g0 + NR * u < G) ? gm[(g0 + NR * u) * LQP + qq] : 0u;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (g0 + NR * u < G) s_gm[(g0 + NR * u) * QW + q] = kv[u];
+        }
+        __syncthreads();
+      }
+      auto each_group = [&](auto&& cb) {   // cb(group, key) over this thread's groups of its token
+        if (!qvalid) return;
+        if (lds_gm) {
+          for (int64_t g = r; g < G; g += NR) cb(g, s_gm[g * QW + q]);
+        } else {
+          for (int64_t g = r; g < G; g += 8 * NR) {   // 8 independent loads in flight
+            uint32_t kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kv[u] = (g + NR * u < G) ? gm[(g + NR * u) * LQP + qq] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (g + NR * u < G) cb(g + NR * u, kv[u]);
+          }
+        }
+      };
       if (use_groups) {
-        radix_select<QW>(
-            [&](auto&& cb) {
-              if (qvalid)
-                for (int64_t g = r; g < G; g += 8 * NR) {   // 8 independent loads in flight
-                  uint32_t kv[8];
-#pragma unroll
-                  for (int u = 0; u < 8; ++u) kv[u] = (g + NR * u < G) ? gm[(g + NR * u) * LQP + qq] : 0u;
-#pragma unroll
-                  for (int u = 0; u < 8; ++u)
-                    if (g + NR * u < G) cb(kv[u]);
-                }
-            },
-            n_probe, hist, part, s_prefix, s_rem, tid);
+        radix_select<QW>([&](auto&& cb) { each_group([&](int64_t, uint32_t key) { cb(key); }); }, n_probe, hist, part,
+                         s_prefix, s_rem, tid);
         if (r == 0) s_taug[q] = s_prefix[q];
       } else if (r == 0) {
         s_taug[q] = 0;
@@ -375,20 +406,14 @@ __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
       if (r == 0) s_gcnt[q] = 0;
       __syncthreads();
       // ---- surviving groups -> per-token lists (order irrelevant)
-      if (qvalid) {
+      {
         const uint32_t taug = s_taug[q];
-        for (int64_t g = r; g < G; g += 8 * NR) {
-          uint32_t kv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) kv[u] = (g + NR * u < G) ? gm[(g + NR * u) * LQP + qq] : 0u;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (g + NR * u < G && kv[u] >= taug) {
-              const uint32_t pos = atomicAdd(&s_gcnt[q], 1u);
-              if (pos < NP_PROBE_CAPG) s_glist[q * NP_PROBE_CAPG + pos] = (uint32_t)(g + NR * u);
-            }
+        each_group([&](int64_t g, uint32_t key) {
+          if (key >= taug) {
+            const uint32_t pos = atomicAdd(&s_gcnt[q], 1u);
+            if (pos < NP_PROBE_CAPG) s_glist[q * NP_PROBE_CAPG + pos] = (uint32_t)g;
           }
-        }
+        });
       }
       __syncthreads();
       // ---- phases 2+3: one wave per token
@@ -402,19 +427,23 @@ __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
           const int nslots = (int)((ng * 32 + 63) / 64);
           uint32_t keys[32];
           uint32_t cids[32];
+          // all of the lane's element loads are issued before the first is used (unconditional, clamped addresses): a
+          // load inside the validity branch was waited for on the spot, 32 memory round trips per token
+          float raw[32];
 #pragma unroll
           for (int j = 0; j < 32; ++j) {
-            keys[j] = 0;
-            cids[j] = 0;
             const uint32_t e = (uint32_t)j * 64 + lane;
-            if (j < nslots && e < ng * 32) {
-              const int64_t c = (int64_t)s_glist[t * NP_PROBE_CAPG + (e >> 5)] * 32 + (e & 31);
-              const bool ok = c < p.K && (!p.elig || ((p.elig[c >> 5] >> (c & 31)) & 1u));
-              if (ok) {
-                keys[j] = okey(col[c * LQP]) + 1u;
-                cids[j] = (uint32_t)c;
-              }
-            }
+            const bool in = j < nslots && e < ng * 32;
+            const int64_t c = in ? (int64_t)s_glist[t * NP_PROBE_CAPG + (e >> 5)] * 32 + (e & 31) : 0;
+            cids[j] = (in && c < p.K) ? (uint32_t)c : 0xFFFFFFFFu;
+            raw[j] = col[(cids[j] != 0xFFFFFFFFu ? (int64_t)cids[j] : 0) * LQP];
+          }
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            const uint32_t c = cids[j];
+            const bool ok = c != 0xFFFFFFFFu && (!p.elig || ((p.elig[c >> 5] >> (c & 31)) & 1u));
+            keys[j] = ok ? okey(raw[j]) + 1u : 0u;
+            cids[j] = ok ? c : 0u;
           }
           uint32_t tau, rem;
           wave_select_mark(nslots, n_probe, keys, tau, rem);
@@ -422,9 +451,7 @@ __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
           // ties at the cut: select_nth_unstable leaves them unspecified (search.rs:405-409); the batched path's
           // heaps keep the LOWEST centroid ids (entries are (Reverse(score), id), search.rs:164-199), so both
           // paths take the `rem` smallest ids among the equal scores
-          uint32_t neq = 0;
-#pragma unroll
-          for (int j = 0; j < 32; ++j) neq += (uint32_t)__popcll(__ballot(j < nslots && keys[j] == tau && tau != 0));
+          const uint32_t neq = wave_count(nslots, keys, [&](uint32_t k) { return k == tau && tau != 0; });
 #pragma unroll
           for (int j = 0; j < 32; ++j) {
             if (j < nslots) {
