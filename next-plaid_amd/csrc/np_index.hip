@@ -76,7 +76,6 @@ void read_tuning_env(Tuning* t) {
   t->ub_nt = env("NP_UB_NT", t->ub_nt);
   t->ub_steal = env("NP_UB_STEAL", t->ub_steal);
   t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
-  t->s6_rep = env("NP_S6_REP", t->s6_rep) != 0;
   t->gemm_cpw = env("NP_GEMM_CPW", t->gemm_cpw) == 2 ? 2 : 1;
   t->exact_rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
 }
@@ -195,6 +194,9 @@ static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bu
   const int nb = 1 << ix->nbits;
   std::vector<float> wl(nb);
   for (int s = 0; s < nb; ++s) wl[s] = bucket_weights[bitrev((uint32_t)s, ix->nbits)];
+  bool wok = true;
+  for (int s = 0; s < nb; ++s) wok = wok && std::isfinite(wl[s]) && std::fabs(wl[s]) < 1e6f;
+  ix->s6_fast_ok = ix->filter_ok && ix->cmax < 1e6f && wok;
   NP_TRY(dev_alloc(&ix->d_wlut, nb, &ix->device_bytes));
   NP_HIP(hipMemcpy(ix->d_wlut, wl.data(), nb * sizeof(float), hipMemcpyHostToDevice));
   return NP_OK;
@@ -1045,7 +1047,6 @@ int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
   else if (n == "ub_nt") t.ub_nt = value < 0 || value > 2 ? 0 : value;
   else if (n == "ub_steal") t.ub_steal = value < 1 ? 1 : value;
   else if (n == "s6_xcd") t.s6_xcd = value != 0;
-  else if (n == "s6_rep") t.s6_rep = value != 0;
   else if (n == "gemm_cpw") t.gemm_cpw = value == 2 ? 2 : 1;
   else if (n == "exact_rowmax") t.exact_rowmax = value != 0;
   else {

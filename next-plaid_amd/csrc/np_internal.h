@@ -113,7 +113,6 @@ struct Tuning {
   int ub_steal = 16384;  // filter: an idle XCD joins a running query that has at least this many unclaimed documents (0x7fffffff = never)
   int ub_nt = 2;         // filter loads: 0 plain, 1 non-temporal records / code lists, 2 bounds-checked buffer loads of the table
   int s6_xcd = 1;        // one XCD per query in S6
-  int s6_rep = 0;        // S6 QC-reuse kernel: 16 bank-aligned copies of the byte LUT (4-bit residuals)
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };
@@ -138,6 +137,8 @@ struct DeviceIndex {
   bool sliced_ok = false;         // every document's distinct-code list is sorted and < 65536 long
   float cmax = 0.f;               // upper bound of the centroid row norms (derived; scales the S4 u8 score table)
   bool filter_ok = false;         // every centroid value is finite: the S4 upper-bound filter may run
+  bool s6_fast_ok = false;        // centroids and bucket weights finite and < 1e6 in magnitude: with an unflagged query no S6
+                                  // product can overflow, so the QC-reuse kernel drops its non-finite guard
   float* d_inv_norm = nullptr;    // [T] 1 / max(||centroid[code] + residual||, 1e-12) per token (derived)
   uint16_t* d_tok_pos = nullptr;  // [T] original position (inside its document) of the token stored here (derived; see below)
   bool tok_sorted = false;        // codes / residuals / inv_norm hold every document's tokens ORDERED BY CODE

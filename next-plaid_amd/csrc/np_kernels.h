@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
     const float m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
     float sc = sqrtf(m) * cmax * 1.001f;
     int isbad = s_bad;
-    if (!finitef(sc)) isbad = 1;
+    if (!finitef(sc) || !(sqrtf(m) < 1e12f)) isbad = 1;   // huge norms: products could overflow (S6 fast epilogue)
     if (!(sc > 0.f)) sc = 1.0f;   // an all-zero query: every score is 0
     qinv[b] = isbad ? 0.f : 1.0f / sc;
     qflag[b] = isbad ? 1u : 0u;
@@ -2414,6 +2414,8 @@ struct ExactP {
   Counters* ctr;
   int xcd_B;                // > 0: 1-D grid, workgroup w serves query (w/8/gx)*8 + w%8 so a query stays on one XCD
   int gx;                   // workgroups per query
+  const uint32_t* qflag;    // [B] query has a non-finite or huge value (prep_queries_kernel)
+  int fast_ok;              // index values finite and bounded: with an unflagged query every S6 product is finite
 };
 
 #define NP_EXACT_DPW 4   // documents per wave
@@ -2855,13 +2857,12 @@ __global__ void __launch_bounds__(256) exact_qc_kernel(ExactP p) {
   (void)ndocs;
 }
 
-// REP: copies of the byte -> bf16 LUT in LDS, lane l reads copy l % REP.  With one copy the 32 lanes of a half-wave hit
-// 256 random 8-B entries over 32 bank pairs (~3.5 passes per ds_read_b64; 57 % of the kernel's LDS cycles are bank
-// conflicts).  REP = 16 (32 KB, entry e of copy r at word 32 e + 2 r): two lanes share a copy and collide only when
-// their bytes differ with equal parity -> 2 passes at most.  (REP = 32 / 64 KB / six waves per workgroup is
-// conflict-free but measured SLOWER, 0.91 vs 0.64 ms: two 64-KB workgroups per CU.)  WPK = waves per workgroup.
-template <int DIM, int NBITS, int NQT, int SPLIT, int REP, int WPK>
-__global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
+// The byte -> packed-bf16 LUT holds {hi word, lo word} per byte: one ds_read_b64 per residual byte.  The MFMA operands want
+// four hi words (and four lo words) in consecutive registers, so each k-step pays 6 v_mov to un-interleave the pairs;
+// separate hi / lo arrays do not help (the compiler fuses the two reads into ds_read2st64_b32, same pairs).  Replicating
+// the LUT to avoid bank conflicts (16 or 32 bank-aligned copies) was measured and does not pay: 0.64 -> 0.65 / 0.91 ms.
+template <int DIM, int NBITS, int NQT, int SPLIT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQT == 1 ? 3 : 2))) exact_qct_kernel(ExactP p) {
   constexpr int NS = DIM / 16;            // MFMA k-steps
   constexpr int PD = DIM * NBITS / 8;     // bytes per token
   constexpr int PH = PD / 2;              // bytes per lane: lane (tok, kk) owns dims [kk*DIM/2, +DIM/2)
@@ -2869,8 +2870,7 @@ __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
   constexpr int WPB = (NBITS == 4) ? 1 : 2;  // u32 words of packed bf16 per residual byte (2 or 4 values)
   static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0, "unsupported DIM/NBITS");
   // byte -> {hi words, lo words}: one LDS read per residual byte returns both halves of the split
-  static_assert(REP == 1 || ((REP == 16 || REP == 32) && NBITS == 4), "replicated LUT: 8-B entries only");
-  __shared__ uint32_t lut[256 * WPB * 2 * REP];
+  __shared__ uint32_t lut[256 * WPB * 2];
   // S6 gathers one 128-B row of the query's score table per token (the MFMA C-in): the same L2-miss-bound
   // access as S4.  With xcd_B set, all workgroups of a query run on ONE XCD (workgroup w -> XCD w % 8), so rows
   // are reused out of that XCD's L2 instead of being refetched by eight.
@@ -2882,7 +2882,7 @@ __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
     if (b >= p.xcd_B) return;
   }
   const int tid = threadIdx.x;
-  if (tid < 256) {
+  {
     constexpr int PER = 8 / NBITS;
     constexpr uint32_t MASK = (1u << NBITS) - 1u;
     uint16_t hh[4] = {0, 0, 0, 0}, ll[4] = {0, 0, 0, 0};
@@ -2896,19 +2896,19 @@ __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
     }
 #pragma unroll
     for (int w2 = 0; w2 < WPB; ++w2) {
-      const uint2 e = make_uint2((uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16),
-                                 (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16));
-      for (int r = 0; r < REP; ++r) reinterpret_cast<uint2*>(lut)[(tid * WPB + w2) * REP + r] = e;
+      lut[(tid * WPB + w2) * 2 + 0] = (uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16);
+      lut[(tid * WPB + w2) * 2 + 1] = (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16);
     }
   }
   __syncthreads();
-  const uint2* lut2 = reinterpret_cast<const uint2*>(lut) + (REP > 1 ? (threadIdx.x & (REP - 1)) : 0);
+  const uint2* lut2 = reinterpret_cast<const uint2*>(lut);
   const int LQP = p.LQP;
   const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
   const int Lq = p.qoff[b + 1] - p.qoff[b];
   const int nqt = (Lq + 31) >> 5;
   const int nsel = p.nsel[b];
   const uint64_t cut = p.cut ? p.cut[b] : 0ull;
+  const bool fast = p.fast_ok != 0 && p.qflag[b] == 0;   // workgroup-uniform
   // slot (s, kk, e) of the MFMA k dimension <-> dim kk*DIM/2 + 8s + e, for A (tokens) and B (query) alike
   const __bf16* Qb = p.Qb + (int64_t)b * LQP * DIM + kk * (DIM / 2);
   const __bf16* Ql = p.Qb_lo + (int64_t)b * LQP * DIM + kk * (DIM / 2);
@@ -2922,7 +2922,7 @@ __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
   }
   unsigned long long toks = 0, ndocs = 0;
   for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
-    const int j = (bx * WPK + wave) * NP_EXACT_DPW + dd;
+    const int j = (bx * 4 + wave) * NP_EXACT_DPW + dd;
     if (j >= nsel) break;
     const int64_t oj = (int64_t)b * p.n_sel + j;
     if (p.sel_keys[oj] < cut) {
@@ -2996,7 +2996,7 @@ __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
           const uint32_t word = rw[s];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const uint2 e = lut2[((word >> (8 * i)) & 0xFFu) * REP];
+            const uint2 e = lut2[(word >> (8 * i)) & 0xFFu];
             wh[i] = e.x;
             wl[i] = e.y;
           }
@@ -3047,12 +3047,23 @@ __global__ void __launch_bounds__(64 * WPK) exact_qct_kernel(ExactP p) {
               acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[s], acc, 0, 0, 0);
             }
           }
+          if (fast) {
+            // every value is finite by construction (finite, bounded index and query: p.fast_ok / qflag), only the rows
+            // past the end are NaN (rn): one multiply and one v_max_f32 per element -- the raw instruction returns the
+            // non-NaN operand, and fmaxf() would add a canonicalising v_max of the loop-carried maximum
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float x = acc[r] * rn;
-            // maxsim.rs:284-291 ignores non-finite entries: x + (x - x) is x when finite and NaN for
-            // +-inf / NaN (rn is NaN for tokens past the end), and fmaxf never returns a NaN operand
-            m[qt][r] = fmaxf(m[qt][r], x + (x - x));
+            for (int r = 0; r < 16; ++r) {
+              const float x = acc[r] * rn;
+              asm("v_max_f32 %0, %1, %2" : "=v"(m[qt][r]) : "v"(m[qt][r]), "v"(x));
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float x = acc[r] * rn;
+              // maxsim.rs:284-291 ignores non-finite entries: x + (x - x) is x when finite and NaN for
+              // +-inf / NaN (rn is NaN for tokens past the end), and fmaxf never returns a NaN operand
+              m[qt][r] = fmaxf(m[qt][r], x + (x - x));
+            }
           }
         }
       }

@@ -244,26 +244,15 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
     // row-max form, whose running maxima need one register per query tile instead of sixteen
     if (NQT <= 2 && !ix->tune.exact_rowmax) {
       ExactP px = p;
-      // 16 bank-aligned copies of the byte LUT (32 KB) for 4-bit residuals; see exact_qct_kernel
-      const bool rep = NBITS == 4 && ix->tune.s6_rep;
-      const unsigned wpk = 4;
-      const unsigned gq = (unsigned)((p.n_sel + wpk * NP_EXACT_DPW - 1) / (wpk * NP_EXACT_DPW));
-      dim3 grid(gq, B);
+      dim3 grid(gx, B);
       if (B >= 8 && ix->tune.s6_xcd) {   // one XCD per query (see exact_qct_kernel)
         px.xcd_B = B;
-        px.gx = (int)gq;
-        grid = dim3(8u * (unsigned)((B + 7) / 8) * gq, 1);
+        px.gx = (int)gx;
+        grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
       }
       constexpr int NQ = NQT <= 2 ? NQT : 1;
-      if constexpr (NBITS == 4) {
-        if (rep) {
-          if (precision == 1) exact_qct_kernel<DIM, NBITS, NQ, 1, 16, 4><<<grid, 256, 0, st>>>(px);
-          else exact_qct_kernel<DIM, NBITS, NQ, 3, 16, 4><<<grid, 256, 0, st>>>(px);
-          return NP_OK;
-        }
-      }
-      if (precision == 1) exact_qct_kernel<DIM, NBITS, NQ, 1, 1, 4><<<grid, 256, 0, st>>>(px);
-      else exact_qct_kernel<DIM, NBITS, NQ, 3, 1, 4><<<grid, 256, 0, st>>>(px);
+      if (precision == 1) exact_qct_kernel<DIM, NBITS, NQ, 1><<<grid, 256, 0, st>>>(px);
+      else exact_qct_kernel<DIM, NBITS, NQ, 3><<<grid, 256, 0, st>>>(px);
     } else {
       if (precision == 1) exact_qc_kernel<DIM, NBITS, NQT, 1><<<dim3(gx, B), 256, 0, st>>>(p);
       else exact_qc_kernel<DIM, NBITS, NQT, 3><<<dim3(gx, B), 256, 0, st>>>(p);
@@ -694,6 +683,8 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.ctr = w.ctr.as<Counters>();
     ep.xcd_B = 0;
     ep.gx = 0;
+    ep.qflag = w.qflag.as<uint32_t>();
+    ep.fast_ok = ix->s6_fast_ok ? 1 : 0;
     switch (ix->dim) {
       case 32: NP_TRY((launch_exact_nb<32>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
       case 64: NP_TRY((launch_exact_nb<64>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;

@@ -90,8 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384),
-                 ("s6_rep", 0)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384)):
         hx.tune(k, v)
 
 
@@ -221,15 +220,14 @@ def test_batched_path_selection_at_size(mid, tuned):
 
 
 def test_s6_kernel_variants_identical(mid, tuned):
-    """S6 launch shapes (one XCD per query or not; one LUT copy / 4 waves or 32 bank-aligned copies / 6 waves per
-    workgroup; end-of-launch query sharing in the filter) only move documents between waves: scores are bit-identical."""
+    """S6 launch shapes (one XCD per query or not) and end-of-launch query sharing in the filter only move documents
+    between waves: scores are bit-identical."""
     spec, a, ox, hx, qs, src = mid
     for prec in (2, 1):
         p = P(n_full_scores=1024, top_k=32, n_ivf_probe=16, precision=prec)
         ref = None
-        for xcd, rep, steal in ((1, 1, 16384), (1, 0, 16384), (0, 1, 1), (0, 0, 0x7FFFFFFF)):
+        for xcd, rep, steal in ((1, 0, 16384), (0, 0, 1), (0, 0, 0x7FFFFFFF)):
             hx.tune("s6_xcd", xcd)
-            hx.tune("s6_rep", rep)
             hx.tune("ub_steal", steal)
             got = hx.search_batch(qs[:24], p)
             if ref is None:
