@@ -285,7 +285,7 @@ struct ProbeP {
   const int32_t* n_elig;   // popcount of elig, else NULL
   int has_thr;
   float thr;
-  int lds_gm;              // probe_mark_kernel was launched with KP/32 * NP_PROBE_QW * 4 bytes of dynamic LDS
+  int lds_gm;              // probe_mark_kernel<4> was launched with KP/32 * 4 * 4 bytes of dynamic LDS
   int64_t slab;            // > 0: batched-probe semantics (search.rs:140-254) with this centroid_batch_size
   uint32_t* cellbits;      // [B][KP/32] zeroed
   uint32_t* tauq;          // [B][LQP] per token: okey of its n_probe-th best centroid (0 = everything)
@@ -327,9 +327,10 @@ __device__ __forceinline__ void wave_select_mark(int nslots, uint32_t n_probe, c
   rem = n_probe > gt ? n_probe - gt : 0u;
 }
 
-#define NP_PROBE_QW 4   // query tokens per probe block: grid = (LQP / 4, B): one token per wave, two blocks per CU
+// QW = query tokens per probe block, grid = (LQP / QW, B).  4 (one token per wave, two blocks per CU) with the group maxima
+// in LDS; 8 when they are re-read from memory (K > 65536: measured 0.36 vs 0.51 ms at K = 2^18).
+template <int QW>
 __global__ void __launch_bounds__(256) probe_mark_kernel(ProbeP p) {
-  constexpr int QW = NP_PROBE_QW;
   __shared__ uint32_t hist[256 * QW];
   __shared__ uint32_t part[256];
   __shared__ uint32_t s_prefix[QW], s_rem[QW], s_taug[QW], s_gcnt[QW];

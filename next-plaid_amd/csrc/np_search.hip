@@ -500,13 +500,11 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     pp.cells = w.cells.as<uint32_t>();
     pp.n_cells = w.n_cells.as<int32_t>();
     pp.ctr = w.ctr.as<Counters>();
-    // K <= 65536: the block's group maxima (KP/32 x 8 tokens x 4 B <= 64 KB) are staged in LDS once
-    const size_t gm_lds = (size_t)(KP / 32) * NP_PROBE_QW * 4;
-    pp.lds_gm = gm_lds <= 64 * 1024 ? 1 : 0;
-    if (pp.lds_gm)
-      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_mark_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm_lds));
-    probe_mark_kernel<<<dim3((unsigned)(LQP / NP_PROBE_QW), B), 256, pp.lds_gm ? gm_lds : 0, st>>>(pp);
+    // K <= 65536: the block's group maxima (KP/32 x 4 tokens x 4 B <= 32 KB) are staged in LDS once
+    const size_t gm_lds = (size_t)(KP / 32) * 4 * 4;
+    pp.lds_gm = gm_lds <= 32 * 1024 ? 1 : 0;
+    if (pp.lds_gm) probe_mark_kernel<4><<<dim3((unsigned)(LQP / 4), B), 256, gm_lds, st>>>(pp);
+    else probe_mark_kernel<8><<<dim3((unsigned)(LQP / 8), B), 256, 0, st>>>(pp);
     probe_finish_kernel<<<dim3(NP_PROBE_NF, B), 256, 0, st>>>(pp);
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));

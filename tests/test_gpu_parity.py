@@ -241,6 +241,18 @@ def test_s6_kernel_variants_identical(mid, tuned):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_BF16)
 
 
+def test_huge_norm_query_keeps_reference_semantics(mid):
+    """A query whose norm exceeds 1e12 is flagged like a non-finite one: the S4 filter is skipped and S6 keeps its
+    non-finite guard (products could overflow).  Scores scale with the query, rankings equal the oracle's."""
+    spec, a, ox, hx, qs, src = mid
+    big = [qs[0] * np.float32(3e13), qs[1], qs[2] * np.float32(1e-20)]
+    p = P(n_full_scores=512, top_k=10, n_ivf_probe=8)
+    res = hx.search_batch(big, p)
+    ref = ox.search_batch(big, to_oracle_params(p))
+    for i, (r, o) in enumerate(zip(res, ref)):
+        assert_ranking_close(r.passage_ids, r.scores, o.passage_ids, o.scores, RTOL_F32, f"scaled query {i}")
+
+
 def test_s4_filter_preserves_selection(mid, tuned):
     """The u8 upper-bound filter in front of S4 must not change WHICH documents are selected nor their order:
     with top_k = n_sel the whole selected set is returned, so filtered and unfiltered runs must agree bit for bit
