@@ -75,6 +75,7 @@ void read_tuning_env(Tuning* t) {
   t->s3_slices = env("NP_S3_SLICES", t->s3_slices) != 0;
   t->ub_nt = env("NP_UB_NT", t->ub_nt);
   t->ub_steal = env("NP_UB_STEAL", t->ub_steal);
+  t->ub_nbx = std::min(std::max(env("NP_UB_NBX", t->ub_nbx), 8), 256);
   t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
   t->gemm_cpw = env("NP_GEMM_CPW", t->gemm_cpw) == 2 ? 2 : 1;
   t->exact_rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
@@ -1046,6 +1047,7 @@ int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
   else if (n == "s3_slices") t.s3_slices = value != 0;
   else if (n == "ub_nt") t.ub_nt = value < 0 || value > 2 ? 0 : value;
   else if (n == "ub_steal") t.ub_steal = value < 1 ? 1 : value;
+  else if (n == "ub_nbx") t.ub_nbx = std::min(std::max(value, 8), 256);
   else if (n == "s6_xcd") t.s6_xcd = value != 0;
   else if (n == "gemm_cpw") t.gemm_cpw = value == 2 ? 2 : 1;
   else if (n == "exact_rowmax") t.exact_rowmax = value != 0;

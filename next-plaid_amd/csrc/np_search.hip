@@ -571,7 +571,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
     if (use_filter) {
       const int hshift = RB == 32 ? 0 : (RB == 64 ? 1 : (RB == 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
-      const unsigned nbx = NP_UB_NBX;
+      const unsigned nbx = (unsigned)ix->tune.ub_nbx;
       // query hand-out state of this launch: slots = -1 (empty), ticket = 0
       int32_t* xslots = w.xcd_slots.as<int32_t>();
       int32_t* xticket = xslots + 8 * (B + 1);

@@ -90,7 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 64)):
         hx.tune(k, v)
 
 
@@ -272,6 +272,7 @@ def test_s4_filter_preserves_selection(mid, tuned):
         surv = set()
         for ub_mode in (0, 1, 2):      # plain / non-temporal / bounds-checked buffer loads of the u8 table
             hx.tune("ub_nt", ub_mode)
+            hx.tune("ub_nbx", (96, 8, 64)[ub_mode])    # workgroups per XCD: any number walks the same claims
             got = hx.search_batch(batch, p)
             st1 = dict(hx.last_stats)
             for i, (g, r) in enumerate(zip(got, ref)):
