@@ -110,7 +110,8 @@ struct Tuning {
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
-  int ub_nbx = 64;       // filter workgroups per XCD: 2 per CU (3 fit; measured S4 0.70 vs 0.73 ms at 1 M, 4.44 vs 4.55 ms at 10 M documents)
+  int ub_nbx = 96;       // filter workgroups per XCD: 3 per CU (48 KB of LDS each).  64 makes the stage itself 3 % faster (0.70 vs 0.73 ms at
+                         // 1 M, 4.43 vs 4.57 ms at 10 M documents) but the sustained 3-stream rate at 10 M drops 10.8 k -> 10.3 k queries/s
   int ub_steal = 16384;  // filter: an idle XCD joins a running query that has at least this many unclaimed documents (0x7fffffff = never)
   int ub_nt = 2;         // filter loads: 0 plain, 1 non-temporal records / code lists, 2 bounds-checked buffer loads of the table
   int s6_xcd = 1;        // one XCD per query in S6
