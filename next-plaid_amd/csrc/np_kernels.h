@@ -160,16 +160,27 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
           (__attribute__((address_space(3))) void*)(&sQ[buf][(j * 256 + wave * 64) * 4]), 16, 0, 0);
     }
   };
+  // Epilogue through LDS.  A lane holds one token (li) of 16 centroid rows, so storing straight from the accumulators is
+  // 16 dword + 16 byte store instructions per tile, each a full 64-lane address pass of the CU's single vector-memory
+  // port.  The tile is transposed in LDS instead (16 ds_write_b32 + 16 ds_write_b8, wave-private) and leaves as 4 dwordx4
+  // stores of 8 rows each plus ONE dwordx4 store of the 32 u8 rows: 6 vector-memory instructions per tile instead of 33
+  // (S1 0.48 -> 0.46 ms).  What remains (cycle-stamped build): the ~250 VALU / LDS instructions of the epilogue issue at
+  // one per 25-30 cycles while the sibling wave's back-to-back f32 MFMA chain holds the SIMD -- per SIMD the kernel is
+  // MFMA time plus epilogue time; placing element r of tile t-1 after MFMA 4r+3 of tile t (the wave's own MFMA shadow) did
+  // not change that (0.48 ms).
+  constexpr int TS = 36;   // f32 tile row stride in words: 16-B aligned rows, halves land on different banks
+  __shared__ __attribute__((aligned(16))) float sT[4][32 * TS];
+  __shared__ __attribute__((aligned(16))) uint8_t sU[4][32 * 32];
   auto epilogue = [&](const f32x16 (&acc)[CPW], int tile) {
     const int b = tile / nqt, qt = tile - b * nqt;
+    const int h = lane >> 5, rr = (lane & 31) >> 3, c4 = lane & 7;   // store role: half, row in the group of 4, 16-B chunk
 #pragma unroll
     for (int f = 0; f < CPW; ++f) {
-      float* out = QCT + ((int64_t)b * KP + c0 + 32 * f) * LQP + qt * 32 + li;
       uint32_t k0 = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mfma_row(r, kk);
-        out[(int64_t)row * LQP] = acc[f][r];
+        sT[wave][row * TS + li] = acc[f][r];
         k0 = max(k0, (c0 + 32 * f + row < K) ? okey(acc[f][r]) : 0u);
       }
       k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
@@ -180,14 +191,28 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
         // padding tokens q >= Lq.  One RB-byte row per centroid (bytes LQP .. RB-1 are zeroed by the host).
         const float inv = qinv[b];
         const bool qv = qt * 32 + li < qoff[b + 1] - qoff[b];
-        uint8_t* o8 = QCU + ((int64_t)b * KP + c0 + 32 * f) * RB + qt * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float h = fmaf(acc[f][r] * inv, 127.5f, 127.5f);
-          const uint32_t u = qv ? min((uint32_t)h + 1u, 255u) : 0u;
-          o8[(int64_t)mfma_row(r, kk) * RB] = (uint8_t)u;
+          const float hh = fmaf(acc[f][r] * inv, 127.5f, 127.5f);
+          const uint32_t u = qv ? min((uint32_t)hh + 1u, 255u) : 0u;
+          sU[wave][mfma_row(r, kk) * 32 + li] = (uint8_t)u;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // the wave's own LDS writes are visible to its other lanes
+      float* outb = QCT + ((int64_t)b * KP + c0 + 32 * f) * LQP + qt * 32 + 4 * c4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 8 * g + 4 * h + rr;
+        const float4 v = *reinterpret_cast<const float4*>(&sT[wave][row * TS + 4 * c4]);
+        *reinterpret_cast<float4*>(outb + (int64_t)row * LQP) = v;
+      }
+      if (QCU) {
+        const int row = lane >> 1, half = lane & 1;   // two lanes per 32-B row piece
+        const uint4 v = *reinterpret_cast<const uint4*>(&sU[wave][row * 32 + 16 * half]);
+        *reinterpret_cast<uint4*>(QCU + ((int64_t)b * KP + c0 + 32 * f + row) * RB + qt * 32 + 16 * half) = v;
+      }
+      __builtin_amdgcn_wave_barrier();   // the next fragment / tile overwrites sT and sU
     }
   };
   if (ntiles > 0) dma_tile(0, 0);
