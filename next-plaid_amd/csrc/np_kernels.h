@@ -172,16 +172,27 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float sT[4][32 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t sU[4][32 * 32];
   auto epilogue = [&](const f32x16 (&acc)[CPW], int tile) {
-    const int b = tile / nqt, qt = tile - b * nqt;
+    const int b = nqt == 1 ? tile : tile / nqt, qt = tile - b * nqt;
     const int h = lane >> 5, rr = (lane & 31) >> 3, c4 = lane & 7;   // store role: half, row in the group of 4, 16-B chunk
 #pragma unroll
     for (int f = 0; f < CPW; ++f) {
-      uint32_t k0 = 0;
+      // group key maximum.  Fragments wholly inside [0, K) whose 16 values are finite in every lane (their sum is) take
+      // the key of the float maximum: okey() is strictly increasing on finite values and the accumulators start at +0,
+      // so no -0 can appear.  Anything else (rows past K, a non-finite value) takes the key of every element.
+      float vsum = 0.f, vmax = acc[f][0];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = mfma_row(r, kk);
-        sT[wave][row * TS + li] = acc[f][r];
-        k0 = max(k0, (c0 + 32 * f + row < K) ? okey(acc[f][r]) : 0u);
+        sT[wave][mfma_row(r, kk) * TS + li] = acc[f][r];
+        vsum += acc[f][r];
+        vmax = fmaxf(vmax, acc[f][r]);
+      }
+      uint32_t k0;
+      if (c0 + 32 * f + 32 <= K && __ballot(!finitef(vsum)) == 0ull) {
+        k0 = okey(vmax);
+      } else {
+        k0 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) k0 = max(k0, (c0 + 32 * f + mfma_row(r, kk) < K) ? okey(acc[f][r]) : 0u);
       }
       k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
       if (kk == 0) gmax[((int64_t)b * G + ((c0 >> 5) + f)) * LQP + qt * 32 + li] = k0;
@@ -193,8 +204,8 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
         const bool qv = qt * 32 + li < qoff[b + 1] - qoff[b];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float hh = fmaf(acc[f][r] * inv, 127.5f, 127.5f);
-          const uint32_t u = qv ? min((uint32_t)hh + 1u, 255u) : 0u;
+          const float hh = fmaf(acc[f][r] * inv, 127.5f, 127.5f);   // < 254.9 (|x| <= s / 1.001): u <= 255 without a clamp,
+          const uint32_t u = qv ? (uint32_t)hh + 1u : 0u;            // and the byte store keeps the low 8 bits anyway
           sU[wave][mfma_row(r, kk) * 32 + li] = (uint8_t)u;
         }
       }
