@@ -393,7 +393,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.round_tab.reserve((size_t)(2 * max_rounds + 1) * 4));
   NP_TRY(w.q_order.reserve((size_t)B * 4));
   NP_TRY(w.n_list2.reserve((size_t)B * 4));
-  NP_TRY(w.xcd_slots.reserve((size_t)(8 * (B + 1) + 1) * 4));
+  NP_TRY(w.xcd_slots.reserve((size_t)max_rounds * (8 * (B + 1) + 1) * 4));   // hand-out slots + ticket per round
   // S4 upper-bound filter (np_kernels.h): off for debug traces (every candidate keeps its exact score) and for
   // indices with a non-finite centroid value
   const bool use_filter = ix->tune.s4_filter && ix->filter_ok && !cs->trace && cs->n_sel > 0 && ix->T > 0;
@@ -421,20 +421,35 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.misc.reserve(64));
 
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[0], st));
-  NP_HIP(hipMemsetAsync(w.ctr.p, 0, sizeof(Counters), st));
-  NP_HIP(hipMemsetAsync(w.n_cells.p, 0, (size_t)B * 4, st));
-  NP_HIP(hipMemsetAsync(w.n_cand.p, 0, (size_t)B * 4, st));
-  NP_HIP(hipMemsetAsync(w.nsel.p, 0, (size_t)B * 4, st));
-  NP_HIP(hipMemsetAsync(w.cellbits.p, 0, (size_t)B * G * 4, st));
-  NP_HIP(hipMemsetAsync(w.tauq.p, 0, (size_t)B * LQP * 4, st));
-  if (NW > 0 && !ix->tune.s3_slices) NP_HIP(hipMemsetAsync(w.docbits.p, 0, (size_t)B * NW * 4, st));   // mark_slices_kernel writes every word
-  if (cs->n_sel > 0) NP_HIP(hipMemsetAsync(w.sel_keys.p, 0, (size_t)B * cs->n_sel * 8, st));
-  if (use_filter && B > 0) {
-    NP_HIP(hipMemsetAsync(w.ub_hist.p, 0, (size_t)B * NP_UB_BINS * 4, st));
-    NP_HIP(hipMemsetAsync(w.n_surv.p, 0, (size_t)B * 4, st));
-    NP_HIP(hipMemsetAsync(w.ub_cursor.p, 0, (size_t)B * 4, st));
-    if (RB != LQP) NP_HIP(hipMemsetAsync(w.QCU.p, 0, (size_t)B * KP * RB, st));   // row bytes LQP .. RB-1 stay 0
+  {
+    // every small region of the call in ONE launch (a dozen stream memsets were ~50 us per batch)
+    ClearList cl;
+    cl.n = 0;
+    auto add = [&](void* p, size_t bytes, uint32_t fill) {
+      if (bytes == 0) return;
+      cl.p[cl.n] = static_cast<uint32_t*>(p);
+      cl.words[cl.n] = (uint32_t)(bytes / 4);
+      cl.fill[cl.n] = fill;
+      ++cl.n;
+    };
+    static_assert(sizeof(Counters) % 4 == 0, "Counters is cleared by words");
+    add(w.ctr.p, sizeof(Counters), 0);
+    add(w.n_cells.p, (size_t)B * 4, 0);
+    add(w.n_cand.p, (size_t)B * 4, 0);
+    add(w.nsel.p, (size_t)B * 4, 0);
+    add(w.cellbits.p, (size_t)B * G * 4, 0);
+    add(w.tauq.p, (size_t)B * LQP * 4, 0);
+    if (cs->n_sel > 0) add(w.sel_keys.p, (size_t)B * cs->n_sel * 8, 0);
+    if (use_filter && B > 0) {
+      add(w.ub_hist.p, (size_t)B * NP_UB_BINS * 4, 0);
+      add(w.n_surv.p, (size_t)B * 4, 0);
+      add(w.ub_cursor.p, (size_t)B * 4, 0);
+      add(w.xcd_slots.p, (size_t)max_rounds * (8 * (B + 1) + 1) * 4, 0xFFFFFFFFu);   // slots and tickets of every round: -1
+    }
+    if (cl.n > 0) clear_regions_kernel<<<128, 256, 0, st>>>(cl);
   }
+  if (NW > 0 && !ix->tune.s3_slices) NP_HIP(hipMemsetAsync(w.docbits.p, 0, (size_t)B * NW * 4, st));   // mark_slices_kernel writes every word
+  if (use_filter && B > 0 && RB != LQP) NP_HIP(hipMemsetAsync(w.QCU.p, 0, (size_t)B * KP * RB, st));   // row bytes LQP .. RB-1 stay 0
   if (B == 0) return NP_OK;
 
   // ---- S1
@@ -573,10 +588,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       const int hshift = RB == 32 ? 0 : (RB == 64 ? 1 : (RB == 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
       const unsigned nbx = (unsigned)ix->tune.ub_nbx;
       // query hand-out state of this launch: slots = -1 (empty), ticket = 0
-      int32_t* xslots = w.xcd_slots.as<int32_t>();
+      int32_t* xslots = w.xcd_slots.as<int32_t>() + (size_t)r * (8 * (B + 1) + 1);   // cleared to -1 with the call's regions
       int32_t* xticket = xslots + 8 * (B + 1);
-      NP_HIP(hipMemsetAsync(xslots, 0xFF, (size_t)8 * (B + 1) * 4, st));
-      NP_HIP(hipMemsetAsync(xticket, 0, 4, st));
 #define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                    \
   approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),            \
                                                           w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,     \
