@@ -168,11 +168,13 @@ int np_hip_index_export(const np_index* index, int64_t* doc_lengths, int64_t* co
                         int64_t* ivf, int32_t* ivf_lengths);
 int64_t np_hip_index_ivf_size(const np_index* index);
 
-/* Kernel-selection knobs (no reference counterpart).  They are read from the environment once, at open
- * (NP_S4_MODE, NP_S4_MINB, NP_S4_NBX, NP_S4_SWZ, NP_S4_FILTER, NP_S6_XCD, NP_GEMM_CPW, NP_EXACT_ROWMAX); this call changes
- * one ("s4_mode", "s4_minb", "s4_nbx", "s4_swz", "s4_filter", "s6_xcd", "gemm_cpw", "exact_rowmax") on a live handle for
- * sweep tools and the kernel-variant parity tests.  Results are identical for every setting; not synchronised
- * with concurrent searches. */
+/* Kernel-selection knobs (no reference counterpart).  Each knob is read from the environment once, at open, as
+ * NP_<UPPER-CASE NAME>, and can be changed on a live handle with this call (sweep tools, kernel-variant parity tests);
+ * both paths clamp through one table.  Knobs: "s4_mode" 0..8, "s4_minb" >= 1, "s4_nbx" 8..512, "s4_swz" 0/1,
+ * "s4_filter" 0/1, "s4_hot" 0..500 (per-mille of hot centroids in the first filter level; 0 = single-level filter),
+ * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "s6_xcd" 0/1, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
+ * Results are identical for every setting; not synchronised with concurrent searches.  Unknown name:
+ * NP_ERR_INVALID_ARGUMENT. */
 int np_hip_index_tune(np_index* index, const char* name, int32_t value);
 
 void np_hip_index_close(np_index* index);               /* Drop for MmapIndex */

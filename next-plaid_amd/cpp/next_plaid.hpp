@@ -13,8 +13,10 @@
 // Accelerator policy (the crate's precedent for its CUDA feature, lib.rs:71-84 and cuda.rs:52-182):
 //   NEXT_PLAID_FORCE_GPU=1|true   a device failure is an Error, never a fallback            (is_force_gpu)
 //   NEXT_PLAID_FORCE_CPU=1|true   the HIP library is not touched at all (unless FORCE_GPU)  (is_force_cpu)
-//   is_hip_broken / mark_hip_broken / clear_hip_broken: once DeviceUnavailable / OutOfMemory is seen the flag makes
-//   every later call skip the device until it is cleared (CUDA_BROKEN, get_global_context's fast path).
+//   is_hip_broken / mark_hip_broken / clear_hip_broken: once DeviceUnavailable is seen the flag makes every later call
+//   skip the device until it is cleared (CUDA_BROKEN, get_global_context's fast path).  OutOfMemory hands THAT call (or
+//   that index) to the CPU hook without raising the process-wide flag: one oversized index must not take the device away
+//   from every other index of the process.
 // The CPU implementation itself is the crate's existing Rust path; here it is a hook (set_cpu_fallback) that the
 // DeviceUnavailable hand-off calls -- this header ships NO CPU search of its own, and with no hook installed a
 // device failure stays an Error (nothing is papered over).
@@ -124,7 +126,7 @@ class MmapIndex {
     np_index* h = nullptr;
     const int rc = np_hip_index_open(index_path.c_str(), opts, &h);
     if (is_device_failure(rc)) {
-      mark_hip_broken();
+      if (rc == NP_ERR_DEVICE_UNAVAILABLE) mark_hip_broken();   // OutOfMemory concerns this index only
       if (!is_force_gpu() && cpu_fallback()) {
         std::fprintf(stderr, "[next-plaid] HIP device unavailable: %s. Falling back to CPU. Set NEXT_PLAID_FORCE_CPU=1 to "
                              "skip the GPU and silence this warning.\n", np_hip_last_error());
@@ -182,7 +184,7 @@ class MmapIndex {
     for (size_t i = 0; i < n; ++i) out[i].query_id = i;
     if (rc != NP_OK) {
       if (is_device_failure(rc)) {   // mid-flight device loss: flag it, hand this call to the CPU unless FORCE_GPU
-        mark_hip_broken();
+        if (rc == NP_ERR_DEVICE_UNAVAILABLE) mark_hip_broken();   // an OutOfMemory of one call leaves the device usable
         if (!is_force_gpu() && cpu_fallback()) return cpu_search(queries, n, params, parallel, subset);
       }
       if (parallel && rc == NP_ERR_SEARCH) return out;
@@ -197,6 +199,7 @@ class MmapIndex {
 
   // index.rs:1197-1245 decompress_documents: (embeddings [sum len, dim], lengths)
   std::pair<std::vector<float>, std::vector<int64_t>> decompress_documents(const std::vector<int64_t>& doc_ids) const {
+    require_device("decompress_documents");
     std::vector<int64_t> lens(std::max<size_t>(doc_ids.size(), 1));
     check(np_hip_decompress_documents(h_, doc_ids.data(), (int64_t)doc_ids.size(), nullptr, 0, lens.data()));
     lens.resize(doc_ids.size());
@@ -211,6 +214,7 @@ class MmapIndex {
   // index.rs:289-371 encode_index_chunk for a flat [n, dim] batch: (codes, packed residuals [n, dim*nbits/8])
   std::pair<std::vector<int64_t>, std::vector<uint8_t>> encode_tokens(const float* embeddings, size_t n,
                                                                       const std::vector<float>& bucket_cutoffs) const {
+    require_device("encode_tokens");
     const size_t pd = embedding_dim() * (size_t)info_.nbits / 8;
     std::vector<int64_t> codes(std::max<size_t>(n, 1));
     std::vector<uint8_t> packed(std::max<size_t>(n * pd, 1));
@@ -233,16 +237,22 @@ class MmapIndex {
 
   std::string path;
   mutable np_stats last_stats{};
-  size_t cpu_dim = 0;   // embedding dim for the CPU hand-off when no device handle exists (set by the caller)
+  size_t cpu_dim = 0;   // overrides the embedding dim handed to the CPU hook (0 = the index's own, from metadata)
 
  private:
   MmapIndex(np_index* h, std::string p) : path(std::move(p)), h_(h) {
     if (h_) check(np_hip_index_info(h_, &info_));
+    // CPU hand-off mode: the geometry accessors (index.rs:1290-1312) stay valid -- host-only parse of the same directory
+    else check(np_hip_index_probe_dir(path.c_str(), &info_));
+  }
+  void require_device(const char* what) const {
+    if (!h_)
+      throw Error(NP_ERR_DEVICE_UNAVAILABLE, (std::string(what) + ": this index runs on the CPU hand-off (no device handle)").c_str());
   }
   std::vector<QueryResult> cpu_search(const Query* queries, size_t n, const SearchParameters& params, bool parallel,
                                       const std::vector<int64_t>* subset) const {
     if (!cpu_fallback()) throw Error(NP_ERR_DEVICE_UNAVAILABLE, "HIP device unavailable and no CPU fallback installed");
-    return cpu_fallback()(path, queries, n, h_ ? embedding_dim() : cpu_dim, params, parallel, subset);
+    return cpu_fallback()(path, queries, n, cpu_dim ? cpu_dim : embedding_dim(), params, parallel, subset);
   }
   void close() {
     if (h_) np_hip_index_close(h_);

@@ -53,7 +53,8 @@ static NcclApi* nccl_api() {
       if (!n || !*n) continue;
       api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (api.lib) break;
-      api.err = dlerror() ? dlerror() : "dlopen failed";
+      const char* e = dlerror();   // one call: dlerror() clears the message it returns
+      api.err = e ? e : "dlopen failed";
     }
     if (!api.lib) return;
     api.GetUniqueId = (int (*)(NcclUniqueId*))dlsym(api.lib, "ncclGetUniqueId");
@@ -183,14 +184,32 @@ int np_hip_search_batch_sharded(const np_index* ix, np_comm* c, const float* d_q
   const int G = c->nranks;
   const int n_sel = np_hip_n_sel(params), ns1 = std::max(n_sel, 1), k = params->top_k, k1 = std::max(k, 1);
 
+  // Every allocation of the communicator happens BEFORE the first collective: a rank that returned on an allocation
+  // failure between two all-gathers would leave its peers blocked in RCCL.  (Phase A's own workspace is reserved at its
+  // start, ahead of gather 1; an error there is reported to the caller, who must treat the communicator as poisoned --
+  // np_hip_comm_destroy and re-create -- because the peers' gather cannot complete.)
+  const bool batched = params->centroid_batch_size > 0 && ix->K > params->centroid_batch_size;
+  const bool need_elig = subset_len > 0 && !batched;
+  const size_t o_keys = (size_t)B * k1 * 8, o_sc = o_keys * 2, o_cnt = o_sc + (size_t)B * k1 * 4;
+  const size_t rec = (o_cnt + (size_t)B * 4 + 15) / 16 * 16;
+  {
+    const int64_t words = np_hip_elig_words(ix);
+    if (need_elig) {
+      NP_TRY(c->elig_local.reserve((size_t)words * 4));
+      NP_TRY(c->elig_all.reserve((size_t)G * words * 4));
+      NP_TRY(c->elig_global.reserve((size_t)words * 4));
+    }
+    NP_TRY(c->keys_local.reserve((size_t)B * ns1 * 8));
+    NP_TRY(c->keys_all.reserve((size_t)G * B * ns1 * 8));
+    NP_TRY(c->cut.reserve((size_t)B * 8));
+    NP_TRY(c->pack_local.reserve(rec));
+    NP_TRY(c->pack_all.reserve((size_t)G * rec));
+  }
+
   // ---- eligible centroids of the subset, OR-ed over the shards (dense path only: search.rs:350-364 vs :542-545)
   const uint32_t* elig = nullptr;
-  const bool batched = params->centroid_batch_size > 0 && ix->K > params->centroid_batch_size;
-  if (subset_len > 0 && !batched) {
+  if (need_elig) {
     const int64_t words = np_hip_elig_words(ix);
-    NP_TRY(c->elig_local.reserve((size_t)words * 4));
-    NP_TRY(c->elig_all.reserve((size_t)G * words * 4));
-    NP_TRY(c->elig_global.reserve((size_t)words * 4));
     NP_TRY(np_hip_subset_eligible(ix, d_subset, subset_len, c->elig_local.as<uint32_t>(), st));
     NP_TRY(all_gather(c, c->elig_local.p, c->elig_all.p, (size_t)words * 4, st));
     NP_TRY(np_hip_or_bitmaps(ix, c->elig_all.as<uint32_t>(), G, words, c->elig_global.as<uint32_t>(), st));
@@ -198,9 +217,6 @@ int np_hip_search_batch_sharded(const np_index* ix, np_comm* c, const float* d_q
   }
 
   // ---- phase A + gather 1 + cut
-  NP_TRY(c->keys_local.reserve((size_t)B * ns1 * 8));
-  NP_TRY(c->keys_all.reserve((size_t)G * B * ns1 * 8));
-  NP_TRY(c->cut.reserve((size_t)B * 8));
   void* state = nullptr;
   NP_TRY(np_hip_search_phase_a(ix, d_queries, d_q_tok_offsets, h_q_tok_offsets, B, dim, params, d_subset, subset_len,
                                elig, c->keys_local.as<uint64_t>(), st, &state));
@@ -215,10 +231,6 @@ int np_hip_search_batch_sharded(const np_index* ix, np_comm* c, const float* d_q
   }
 
   // ---- phase B into one packed record: ids [B*k] i64 | keys [B*k] u64 | scores [B*k] f32 | counts [B] i32
-  const size_t o_keys = (size_t)B * k1 * 8, o_sc = o_keys * 2, o_cnt = o_sc + (size_t)B * k1 * 4;
-  const size_t rec = (o_cnt + (size_t)B * 4 + 15) / 16 * 16;
-  NP_TRY(c->pack_local.reserve(rec));
-  NP_TRY(c->pack_all.reserve((size_t)G * rec));
   char* pl = c->pack_local.as<char>();
   NP_TRY(np_hip_search_phase_b(ix, state, n_sel > 0 ? c->cut.as<uint64_t>() : nullptr, (int64_t*)pl, (float*)(pl + o_sc),
                                (uint64_t*)(pl + o_keys), (int32_t*)(pl + o_cnt), st));

@@ -62,23 +62,36 @@ int normalise_opts(const np_open_opts* in, np_open_opts* o) {
   return NP_OK;
 }
 
+// One clamp table for the environment (read once at open) and np_hip_index_tune().  Returns false for an unknown name.
+bool set_tuning(Tuning* t, const std::string& n, int value) {
+  auto clamp = [](int v, int lo, int hi) { return std::min(std::max(v, lo), hi); };
+  if (n == "s4_mode") t->s4_mode = clamp(value, 0, 8);
+  else if (n == "s4_minb") t->s4_minb = std::max(value, 1);
+  else if (n == "s4_nbx") t->s4_nbx = clamp(value, 8, 512);
+  else if (n == "s4_swz") t->s4_swz = value != 0;
+  else if (n == "s4_filter") t->s4_filter = value != 0;
+  else if (n == "s4_hot") t->s4_hot = clamp(value, 0, 500);
+  else if (n == "s3_slices") t->s3_slices = value != 0;
+  else if (n == "ub_nt") t->ub_nt = value < 0 || value > 2 ? 0 : value;
+  else if (n == "ub_steal") t->ub_steal = value < 1 ? 1 : value;
+  else if (n == "ub_nbx") t->ub_nbx = clamp(value, 8, 256);
+  else if (n == "s6_xcd") t->s6_xcd = value != 0;
+  else if (n == "gemm_cpw") t->gemm_cpw = value == 2 ? 2 : 1;
+  else if (n == "exact_rowmax") t->exact_rowmax = value != 0;
+  else return false;
+  return true;
+}
+
 void read_tuning_env(Tuning* t) {
-  auto env = [](const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-  };
-  t->s4_mode = std::min(std::max(env("NP_S4_MODE", t->s4_mode), 0), 8);
-  t->s4_minb = std::max(env("NP_S4_MINB", t->s4_minb), 1);
-  t->s4_nbx = std::min(std::max(env("NP_S4_NBX", t->s4_nbx), 8), 512);
-  t->s4_swz = env("NP_S4_SWZ", t->s4_swz) != 0;
-  t->s4_filter = env("NP_S4_FILTER", t->s4_filter) != 0;
-  t->s3_slices = env("NP_S3_SLICES", t->s3_slices) != 0;
-  t->ub_nt = env("NP_UB_NT", t->ub_nt);
-  t->ub_steal = env("NP_UB_STEAL", t->ub_steal);
-  t->ub_nbx = std::min(std::max(env("NP_UB_NBX", t->ub_nbx), 8), 256);
-  t->s6_xcd = env("NP_S6_XCD", t->s6_xcd) != 0;
-  t->gemm_cpw = env("NP_GEMM_CPW", t->gemm_cpw) == 2 ? 2 : 1;
-  t->exact_rowmax = getenv("NP_EXACT_ROWMAX") != nullptr;
+  static const char* const knobs[][2] = {
+      {"NP_S4_MODE", "s4_mode"}, {"NP_S4_MINB", "s4_minb"}, {"NP_S4_NBX", "s4_nbx"}, {"NP_S4_SWZ", "s4_swz"},
+      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
+      {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_GEMM_CPW", "gemm_cpw"},
+      {"NP_EXACT_ROWMAX", "exact_rowmax"}};
+  for (const auto& k : knobs) {
+    const char* e = getenv(k[0]);
+    if (e && *e) (void)set_tuning(t, k[1], atoi(e));
+  }
 }
 
 static int check_device(int dev) {
@@ -1037,21 +1050,7 @@ int np_hip_index_tune(np_index* ix, const char* name, int32_t value) {
     set_error("np_hip_index_tune: NULL argument");
     return NP_ERR_INVALID_ARGUMENT;
   }
-  Tuning& t = ix->tune;
-  const std::string n(name);
-  if (n == "s4_mode") t.s4_mode = std::min(std::max(value, 0), 8);
-  else if (n == "s4_minb") t.s4_minb = std::max(value, 1);
-  else if (n == "s4_nbx") t.s4_nbx = std::min(std::max(value, 8), 512);
-  else if (n == "s4_swz") t.s4_swz = value != 0;
-  else if (n == "s4_filter") t.s4_filter = value != 0;
-  else if (n == "s3_slices") t.s3_slices = value != 0;
-  else if (n == "ub_nt") t.ub_nt = value < 0 || value > 2 ? 0 : value;
-  else if (n == "ub_steal") t.ub_steal = value < 1 ? 1 : value;
-  else if (n == "ub_nbx") t.ub_nbx = std::min(std::max(value, 8), 256);
-  else if (n == "s6_xcd") t.s6_xcd = value != 0;
-  else if (n == "gemm_cpw") t.gemm_cpw = value == 2 ? 2 : 1;
-  else if (n == "exact_rowmax") t.exact_rowmax = value != 0;
-  else {
+  if (!set_tuning(&ix->tune, name, value)) {
     set_error("np_hip_index_tune: unknown knob '%s'", name);
     return NP_ERR_INVALID_ARGUMENT;
   }

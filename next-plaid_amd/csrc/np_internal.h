@@ -99,9 +99,9 @@ struct Context {
   uint64_t last_use = 0;   // acquisition stamp: idle contexts are handed out least-recently-used first
 };
 
-// Kernel-selection knobs.  Read from the environment ONCE, at index open (NP_S4_MODE, NP_S4_MINB, NP_S4_NBX,
-// NP_S4_SWZ, NP_S4_FILTER, NP_S6_XCD, NP_GEMM_CPW, NP_EXACT_ROWMAX); np_hip_index_tune() changes them on a live handle
-// for sweep tools and the kernel-variant parity tests.  Every setting produces identical results.
+// Kernel-selection knobs.  Read from the environment ONCE, at index open (NP_<NAME>, e.g. NP_S4_MODE); np_hip_index_tune()
+// changes them on a live handle for sweep tools and the kernel-variant parity tests; both go through set_tuning()'s one
+// clamp table.  Every setting produces identical results.
 struct Tuning {
   int s4_mode = 4;       // 0 approx_kernel; 1..4 approx_xcd_kernel with 8/4/2/1 phases; 5..8 approx_stream_kernel (the survivor lists
                          // of the filter are short: one phase measured best; 2 was best on unfiltered 18 k-document lists)
@@ -110,6 +110,7 @@ struct Tuning {
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
+  int s4_hot = 50;       // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level filter)
   int ub_nbx = 96;       // filter workgroups per XCD: 3 per CU (48 KB of LDS each).  64 makes the stage itself 3 % faster (0.70 vs 0.73 ms at
                          // 1 M, 4.43 vs 4.57 ms at 10 M documents) but the sustained 3-stream rate at 10 M drops 10.8 k -> 10.3 k queries/s
   int ub_steal = 16384;  // filter: an idle XCD joins a running query that has at least this many unclaimed documents (0x7fffffff = never)
@@ -164,6 +165,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts, DeviceIndex
 void destroy_device_index(DeviceIndex* ix);
 int normalise_opts(const np_open_opts* in, np_open_opts* out);
 void read_tuning_env(Tuning* t);
+bool set_tuning(Tuning* t, const std::string& name, int value);   // shared clamp table (environment + np_hip_index_tune)
 void shard_range(int64_t n_total, int rank, int count, int64_t* b, int64_t* e);
 
 // np_search.hip

@@ -34,6 +34,16 @@ int main(int argc, char** argv) {
     std::printf("again %s\n", again.on_device() ? "device" : "cpu");
     next_plaid::clear_hip_broken();
     std::printf("cleared broken=%d\n", (int)next_plaid::is_hip_broken());
+    // geometry accessors stay valid on the CPU hand-off (host-only parse), device-only methods say so
+    std::printf("geom %zu %zu %zu\n", again.num_documents(), again.embedding_dim(), again.num_partitions());
+    if (!again.on_device()) {
+      try {
+        (void)again.decompress_documents({0});
+        std::printf("decompress ok\n");
+      } catch (const next_plaid::Error& e) {
+        std::printf("decompress error %d\n", (int)e.kind);
+      }
+    }
   } catch (const next_plaid::Error& e) {
     std::printf("error %d\n", (int)e.kind);
   }

@@ -141,3 +141,24 @@ def test_one_hip_runtime_per_process_whatever_the_import_order():
         "assert len(libs) == 1, libs\n" % os.path.join(ROOT, "next-plaid_amd"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_bad_rccl_override_is_an_error_code_not_a_crash():
+    """np_dist.hip resolves librccl with dlopen; a candidate that fails to load (here NEXTPLAID_RCCL_LIB pointing nowhere)
+    must leave a message and move on to the next candidate -- dlerror() returns NULL on its second call, and assigning that
+    to a std::string crashed the process (ADVICE r2).  Whatever the outcome (a later candidate loads, or none does), the
+    entry returns a status code."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from next_plaid_amd import api\n"
+            "L = api.lib(); buf = C.create_string_buffer(128)\n"
+            "rc = L.np_hip_comm_unique_id(buf)\n"
+            "print('rc', rc, L.np_hip_last_error().decode() if rc else '')\n") % (ROOT, os.path.join(ROOT, "next-plaid_amd"))
+    env = dict(os.environ, NEXTPLAID_RCCL_LIB="/nonexistent/librccl.so.9")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rc = int(r.stdout.split()[1])
+    assert rc in (0, 6), r.stdout          # NP_OK (a later candidate loaded) or NP_ERR_DEVICE_UNAVAILABLE
+    if rc == 6:
+        assert "librccl is not available" in r.stdout or "ncclGetUniqueId" in r.stdout

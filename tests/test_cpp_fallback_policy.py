@@ -43,6 +43,9 @@ def test_device_failure_hands_off_to_cpu_and_raises_the_flag(exe, index_dir, gpu
         assert lines[1] == "again cpu"                                 # flag raised: the device is not retried
         assert "Falling back to CPU" in r.stderr
     assert lines[2] == "cleared broken=0"
+    assert lines[3] == "geom 200 64 64", r.stdout          # accessors valid with or without a device handle
+    if not gpu_available:
+        assert lines[4] == "decompress error 6"            # device-only method: a clear Error, not a NULL handle in the ABI
 
 
 def test_force_gpu_never_falls_back(exe, index_dir, gpu_available):

@@ -20,4 +20,4 @@ for r in rows:
     out.append(f"| `{n}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                f"{float(r['MaxNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e3/nb:.1f} | {float(r['Percentage']):.2f} |")
 open(sys.argv[2], "w").write("\n".join(out) + "\n")
-print("\n".join(out[:14]))
+print("\n".join(out[:40]))

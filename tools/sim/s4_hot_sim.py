@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""CPU simulation of the S4 'hot-centroid' upper bound on the metric corpus (design aid, not product code).
+
+For a few queries of the 10M-doc synthetic corpus: candidate documents (docs holding a probed cell), their distinct
+codes, the exact u8 bound U(d), and the cheap bound U'(d) = sum_q max(Lambda, max_{c in codes(d), hot} u[q,c]) for several
+hot fractions; reports rows gathered per document and survivor counts of the two-step cut.
+"""
+import os, sys, time
+import numpy as np
+from multiprocessing import Pool
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "next-plaid_amd"))
+from next_plaid_amd import synth
+
+NDOCS = int(os.environ.get("SIM_DOCS", "10000000"))
+NQ = int(os.environ.get("SIM_Q", "6"))
+LQ = int(os.environ.get("SIM_LQ", "32"))
+NTOP = int(os.environ.get("SIM_TOPICS", "8"))
+RAND = int(os.environ.get("SIM_RAND256", "51"))
+spec = synth.SynthSpec(num_docs=NDOCS, num_centroids=65536, dim=128, nbits=4, doc_len_min=300, doc_len_max=300,
+                       n_topics=NTOP, rand256=RAND, seed=1236)
+CH = 50000
+
+
+def codes_only(d0, d1):
+    L = 300
+    docs = np.repeat(np.arange(d0, d1, dtype=np.uint64), L)
+    t = np.tile(np.arange(L, dtype=np.uint64), d1 - d0)
+    r = synth.rnd(spec.seed, synth.S_TOK, docs * np.uint64(65536) + t)
+    is_rand = (r & np.uint64(0xFF)) < np.uint64(spec.rand256)
+    rand_code = ((r >> np.uint64(8)) & np.uint64(0xFFFFFFFF)) % np.uint64(spec.num_centroids)
+    top_code = synth._topic(spec, docs, (r >> np.uint64(40)) % np.uint64(spec.n_topics))
+    return np.where(is_rand, rand_code, top_code).astype(np.uint16).reshape(d1 - d0, L)
+
+
+def scan(args):
+    d0, d1, cellmasks = args
+    c = codes_only(d0, d1)
+    out = []
+    for cm in cellmasks:
+        hit = cm[c].any(axis=1)
+        idx = np.nonzero(hit)[0]
+        out.append((idx + d0, c[idx]))
+    return out
+
+
+def main():
+    cen = synth.centroids(spec)
+    qs, src = synth.make_queries(spec, NQ, n_tokens=LQ, cen=cen)
+    nprobe, tcs = 32, 0.4
+    cellmasks, tabs = [], []
+    for q in qs:
+        QC = q @ cen.T                                   # [Lq, K]
+        cells = set()
+        for row in QC:
+            cells |= set(np.argpartition(-row, nprobe)[:nprobe].tolist())
+        cells = np.array(sorted(cells))
+        cells = cells[QC[:, cells].max(axis=0) >= tcs]
+        m = np.zeros(65536, bool); m[cells] = True
+        cellmasks.append(m)
+        s = 1.001 * np.linalg.norm(q, axis=1).max() * 1.0001
+        u = (np.floor((QC / s + 1.0) * 127.5) + 1).astype(np.int32)   # [Lq,K] in [1,255]
+        tabs.append(u)
+        print("query cells", cells.size, flush=True)
+    t0 = time.time()
+    jobs = [(d, min(d + CH, NDOCS), cellmasks) for d in range(0, NDOCS, CH)]
+    with Pool(8) as p:
+        res = p.map(scan, jobs, chunksize=1)
+    print("scan", time.time() - t0, flush=True)
+    n_sel = 1024
+    for qi in range(NQ):
+        ids = np.concatenate([r[qi][0] for r in res]); C = np.concatenate([r[qi][1] for r in res])
+        u = tabs[qi]                                     # [Lq,K]
+        n = ids.size
+        # exact U
+        U = np.zeros(n, np.int64)
+        M = u.max(axis=0)                                # per-centroid max over tokens
+        nd = np.zeros(n, np.int64)
+        for i0 in range(0, n, 4096):
+            cc = C[i0:i0 + 4096].astype(np.int64)        # [m,300]
+            g = u[:, cc]                                 # [Lq,m,300]
+            U[i0:i0 + 4096] = g.max(axis=2).sum(axis=0)
+            s_ = np.sort(cc, axis=1)
+            nd[i0:i0 + 4096] = 1 + (np.diff(s_, axis=1) != 0).sum(axis=1)
+        thrU = np.sort(U)[-n_sel] - (LQ + 2)
+        survU = int((U >= thrU).sum())
+        print(f"q{qi}: cand {n} distinct/doc {nd.mean():.1f} exact-U survivors {survU} (thr {thrU}, U of n_sel-th {np.sort(U)[-n_sel]}, median {np.median(U)})")
+        for f in (0.02, 0.04, 0.08, 0.12, 0.16, 0.25):
+            lam = np.sort(M)[int((1 - f) * 65536) - 1]   # count(M > lam) <= f K
+            hot = M > lam
+            Up = np.zeros(n, np.int64); rows = 0
+            for i0 in range(0, n, 4096):
+                cc = C[i0:i0 + 4096].astype(np.int64)
+                h = hot[cc]                               # [m,300]
+                g = np.where(h[None], u[:, cc], 0)
+                Up[i0:i0 + 4096] = np.maximum(g.max(axis=2), lam).sum(axis=0)
+                s_ = np.sort(np.where(h, cc, -1), axis=1)
+                rows += int(((np.diff(s_, axis=1) != 0) & (s_[:, 1:] >= 0)).sum() + (s_[:, 0] >= 0).sum())
+            assert (Up >= U).all()
+            thr1 = np.sort(Up)[-n_sel]
+            S1 = Up >= thr1
+            tau = np.sort(U[S1])[-n_sel] - (LQ + 2)      # n_sel-th largest exact U inside S1, minus the bracket slack
+            S2 = Up >= tau
+            S3 = S2 & (U >= np.sort(U[S2])[-n_sel] - (LQ + 2))
+            assert (S2 | ~(U >= thrU)).all() or True
+            miss = int(((U >= thrU) & ~S2).sum())
+            print(f"   f={f:.2f} lam={lam} hot rows/doc {rows / n:.2f} slack mean {np.mean(Up - U):.1f} |S1| {int(S1.sum())} |S2| {int(S2.sum())} "
+                  f"|S3| {int(S3.sum())} missed-of-exactU-survivors {miss}")
+
+
+if __name__ == "__main__":
+    main()
