@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 2
+#define NP_ABI_VERSION 3
 
 typedef enum np_status {
   NP_OK = 0,
@@ -159,6 +159,9 @@ typedef struct np_synth_spec {
   uint64_t seed;
   const float* centroids;       /* [K, dim] */
   const float* bucket_weights;  /* [2^nbits] */
+  const int32_t* len_table;     /* optional: document length = len_table[hash(doc) % len_table_size] (a quantile table,
+                                   e.g. the clipped LogNormal of MS MARCO passages) instead of uniform [doc_len_min, doc_len_max] */
+  int32_t len_table_size;       /* 0 = none */
 } np_synth_spec;
 int np_hip_index_synth(const np_synth_spec* spec, const np_open_opts* opts, np_index** out);
 

@@ -103,7 +103,7 @@ class np_synth_spec(C.Structure):
     _fields_ = [("num_docs", C.c_int64), ("num_centroids", C.c_int64), ("dim", C.c_int32), ("nbits", C.c_int32),
                 ("doc_len_min", C.c_int32), ("doc_len_max", C.c_int32), ("n_topics", C.c_int32),
                 ("rand256", C.c_int32), ("seed", C.c_uint64), ("centroids", C.c_void_p),
-                ("bucket_weights", C.c_void_p)]
+                ("bucket_weights", C.c_void_p), ("len_table", C.c_void_p), ("len_table_size", C.c_int32)]
 
 
 EXPORTS = [
@@ -329,8 +329,10 @@ class MmapIndex:
         cen = np.ascontiguousarray(S.centroids(spec) if centroids is None else centroids, np.float32)
         _, w = S.bucket_tables(spec)
         w = np.ascontiguousarray(w, np.float32)
+        lt = None if spec.len_table is None else np.ascontiguousarray(spec.len_table, np.int32)
         s = np_synth_spec(spec.num_docs, spec.num_centroids, spec.dim, spec.nbits, spec.doc_len_min,
-                          spec.doc_len_max, spec.n_topics, spec.rand256, spec.seed, _ptr(cen), _ptr(w))
+                          spec.doc_len_max, spec.n_topics, spec.rand256, spec.seed, _ptr(cen), _ptr(w),
+                          None if lt is None else _ptr(lt), 0 if lt is None else int(lt.size))
         h = C.c_void_p()
         o = _opts(**opts)
         _check(lib().np_hip_index_synth(C.byref(s), C.byref(o), C.byref(h)))

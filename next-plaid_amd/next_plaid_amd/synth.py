@@ -6,7 +6,8 @@ lengths), used by bench.py to build BASELINE.json's config-2 index directly in H
 
 Spec (integer-hash form so host and device agree bit for bit):
   mix64 = splitmix64 finaliser; rnd(stream, i) = mix64(mix64(seed + stream) + i)  (u64 wrap)
-  doc length  : Lmin + rnd(LEN, doc) % (Lmax - Lmin + 1)
+  doc length  : Lmin + rnd(LEN, doc) % (Lmax - Lmin + 1), or with a quantile table (ragged corpora, e.g. the clipped
+                LogNormal of MS MARCO passages): len_table[rnd(LEN, doc) % len(len_table)]
   doc topics  : topic(doc, s) = ((r & 0xffffffff) % K) >> ((r >> 32) & 3),  r = rnd(TOPIC, doc*T + s)
                 (mixture of uniforms over [0,K), [0,K/2), [0,K/4), [0,K/8): a skewed, Zipf-like
                 popularity without floating point)
@@ -61,14 +62,28 @@ class SynthSpec:
     rand256: int = 51            # ~20 % of tokens get a uniformly random code
     sigma_r: float = 0.044       # per-dim residual std  (|r| ~ 0.5 at d=128)
     seed: int = 1236             # 1234 + config number (config 2)
+    len_table: object = None     # int32 quantile table of document lengths (see lognormal_len_table); None = uniform
 
     @property
     def packed_dim(self):
         return self.dim * self.nbits // 8
 
 
+def lognormal_len_table(mean: float = 73.0, sigma: float = 0.45, max_len: int = 180, min_len: int = 1,
+                        size: int = 1024) -> np.ndarray:
+    """Quantile table of a clipped LogNormal with the given mean (before clipping): MS MARCO passages under the
+    ColBERTv2 tokenizer are ~73 tokens on average, 180 at most."""
+    mu = float(np.log(mean)) - 0.5 * sigma * sigma
+    nd = NormalDist(0.0, 1.0)
+    q = np.array([nd.inv_cdf((i + 0.5) / size) for i in range(size)])
+    return np.clip(np.rint(np.exp(mu + sigma * q)), min_len, max_len).astype(np.int32)
+
+
 def doc_lengths(spec: SynthSpec, d0: int, d1: int) -> np.ndarray:
     docs = np.arange(d0, d1, dtype=np.uint64)
+    if spec.len_table is not None:
+        tab = np.asarray(spec.len_table, np.int64)
+        return tab[(rnd(spec.seed, S_LEN, docs) % np.uint64(tab.size)).astype(np.int64)]
     span = spec.doc_len_max - spec.doc_len_min + 1
     return (spec.doc_len_min + (rnd(spec.seed, S_LEN, docs) % np.uint64(span))).astype(np.int64)
 

@@ -1,0 +1,109 @@
+"""BASELINE.json configs 2 and 3 at KERNEL-SELECTING sizes, compared with the oracle under `pytest -m gpu`.
+
+The small fixtures of test_gpu_parity.py stop at K = 4096, so they never instantiate what the named configurations run:
+  * K = 65 536 (config 2 / the metric corpus): the last size whose group maxima fit probe_mark_kernel<4>'s 32 KB LDS
+    staging (`lds_gm`), u16 code lists at their maximum range, the filter's u16 staging (approx_ub_kernel<*, uint16_t, *>);
+  * K = 131 072 and 262 144 with centroid_batch_size = 100 000 (config 3, the MS MARCO shape: nbits = 2, ragged clipped
+    LogNormal lengths, nprobe 8 and 32): probe_mark_kernel<8> reading group maxima from memory, the batched slab-heap
+    threshold rule over 2-3 slabs, approx_ub_kernel<*, uint32_t, *>, gcut + approx_matvec_kernel at real K.
+Stage traces (cells, candidates, approximate scores, selection) must be bit-equal to the oracle's
+(search.rs:140-254, 327-640); the batched production path must select the oracle's set.  Corpora are generated in HBM by
+the seeded generator and exported to the host for the oracle, so each case stays well under a minute.
+"""
+import numpy as np
+import pytest
+
+from helpers import O, RTOL_F32, assert_ranking_close, synth, to_oracle_params
+
+import next_plaid_amd as npa
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (K, nbits, docs, length spec, centroid_batch_size)
+    "k65536_dense": (65536, 4, 200_000, (20, 60), 100_000),
+    "k131072_batched": (131072, 2, 250_000, "lognormal", 100_000),
+    "k262144_batched": (262144, 2, 300_000, "lognormal", 100_000),
+}
+
+
+def P(**kw):
+    return npa.SearchParameters(**kw)
+
+
+@pytest.fixture(scope="module", params=list(CASES), ids=list(CASES))
+def big(request):
+    K, nbits, docs, lens, cbs = CASES[request.param]
+    kw = dict(num_docs=docs, num_centroids=K, dim=128, nbits=nbits, seed=1237)
+    if lens == "lognormal":
+        spec = synth.SynthSpec(doc_len_min=1, doc_len_max=180, len_table=synth.lognormal_len_table(), **kw)
+    else:
+        spec = synth.SynthSpec(doc_len_min=lens[0], doc_len_max=lens[1], **kw)
+    cen = synth.centroids(spec)
+    hx = npa.MmapIndex.synth(spec, centroids=cen, max_batch=32, n_contexts=1)
+    e = hx.export()
+    if lens == "lognormal":   # the device generator follows the host statement of the length table
+        assert np.array_equal(e["doc_lengths"][:5000], synth.doc_lengths(spec, 0, 5000))
+        assert 60 < e["doc_lengths"].mean() < 80 and e["doc_lengths"].max() == 180
+    ox = O.OracleIndex(cen, synth.bucket_tables(spec)[1], e["ivf"], e["ivf_lengths"], e["doc_lengths"], e["codes"],
+                       e["residuals"], nbits)
+    qs, src = synth.make_queries(spec, 32, n_tokens=32, cen=cen)
+    yield request.param, spec, hx, ox, qs, src, cbs
+    hx.close()
+
+
+def trace_equal(hx, ox, q, p, what):
+    tr = hx.debug_trace(q, p)
+    r = ox.search(q, to_oracle_params(p), trace=True)
+    t = r.trace
+    assert np.array_equal(tr["cells"], t.cells), f"{what}: S2 cells differ ({tr['cells'].size} vs {t.cells.size})"
+    assert np.array_equal(tr["cand"], t.cand), f"{what}: S3 candidates differ ({tr['cand'].size} vs {t.cand.size})"
+    bad = np.nonzero(tr["approx"].view(np.uint32) != t.approx.view(np.uint32))[0]
+    assert bad.size == 0, f"{what}: S4 approx not bit-exact at {bad[:5]}: {tr['approx'][bad[:5]]} vs {t.approx[bad[:5]]}"
+    assert np.array_equal(tr["sel"], t.sel), f"{what}: S5 selection / order differs"
+    tol = RTOL_F32 * np.maximum(np.abs(t.sel_exact), 1.0)
+    assert np.all(np.abs(tr["sel_exact"] - t.sel_exact) <= tol), f"{what}: S6 exact scores"
+    return r
+
+
+def test_stage_traces_bit_equal(big):
+    name, spec, hx, ox, qs, src, cbs = big
+    for nprobe in (8, 32):
+        for thr in (0.4, None):
+            p = P(n_full_scores=1024, top_k=10, n_ivf_probe=nprobe, centroid_score_threshold=thr, centroid_batch_size=cbs)
+            for qi in (0, 1) if thr is None else (0, 1, 2, 3):
+                r = trace_equal(hx, ox, qs[qi], p, f"{name} nprobe={nprobe} thr={thr} q{qi}")
+                assert r.trace.used_batched == (spec.num_centroids > cbs)
+    # a short ragged query takes the same kernels with a partly empty 32-token tile
+    p = P(n_full_scores=256, top_k=5, n_ivf_probe=8, centroid_batch_size=cbs)
+    trace_equal(hx, ox, qs[4][:11], p, f"{name} 11-token query")
+
+
+def test_production_path_selects_the_oracles_set(big):
+    """The timed path (u8 filter -> exact approximate scores of the survivors [-> margin cut -> mat-vec scores on the batched
+    path] -> selection -> MaxSim) with top_k = n_sel returns the whole selected set: it must be the oracle's, scores within
+    the stated f32 tolerance; and the filter must actually have pruned."""
+    name, spec, hx, ox, qs, src, cbs = big
+    for nfs, nprobe, thr in ((1024, 32, 0.4), (2048, 8, None)):
+        k = nfs // 4
+        p = P(n_full_scores=nfs, top_k=k, n_ivf_probe=nprobe, centroid_score_threshold=thr, centroid_batch_size=cbs)
+        got = hx.search_batch(qs, p)
+        st = dict(hx.last_stats)
+        ref = ox.search_batch(qs, to_oracle_params(p))
+        for i, (g, o) in enumerate(zip(got, ref)):
+            assert set(g.passage_ids.tolist()) == set(o.passage_ids.tolist()), f"{name} nfs={nfs} q{i}: selected set differs"
+            assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} nfs={nfs} q{i}")
+        assert st["n_candidates"] > 0 and 0 < st["n_survivors"] <= st["n_candidates"]
+        hx.tune("s4_filter", 0)
+        try:
+            for g, o in zip(hx.search_batch(qs, p), got):   # the filter changes nothing
+                assert np.array_equal(g.passage_ids, o.passage_ids) and np.array_equal(g.scores, o.scores)
+        finally:
+            hx.tune("s4_filter", 1)
+    # default parameters of the configuration, top-10: ids identical to the oracle's, the source document first
+    p = P(n_full_scores=4096, top_k=10, n_ivf_probe=32, centroid_score_threshold=0.4, centroid_batch_size=cbs)
+    got = hx.search_batch(qs, p)
+    ref = ox.search_batch(qs, to_oracle_params(p))
+    for i, (g, o) in enumerate(zip(got, ref)):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} default q{i}")
+        assert g.passage_ids[0] == src[i]

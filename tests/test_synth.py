@@ -41,3 +41,18 @@ def test_queries_hit_their_source_centroids():
     for q in qs:
         assert q.shape == (32, 128) and np.allclose(np.linalg.norm(q, axis=1), 1, atol=1e-5)
         assert ((q @ cen.T).max(1) > 0.6).all()
+
+
+def test_lognormal_length_table_is_the_config3_shape():
+    """document lengths ~ clipped LogNormal(mean ~ 73, max 180); the table is the generator's
+    ragged-length mode (host statement; the device generator indexes the same table with the same hash)."""
+    tab = synth.lognormal_len_table()
+    assert tab.dtype == np.int32 and tab.size == 1024 and tab.min() >= 1 and tab.max() == 180
+    assert np.all(np.diff(tab) >= 0) and 68 < tab.mean() < 76
+    spec = synth.SynthSpec(num_docs=4000, num_centroids=64, dim=64, nbits=2, doc_len_min=1, doc_len_max=180, seed=3,
+                           len_table=tab)
+    l1 = synth.doc_lengths(spec, 0, 4000)
+    assert np.array_equal(l1[1000:3000], synth.doc_lengths(spec, 1000, 3000))      # shardable
+    assert 65 < l1.mean() < 80 and l1.max() <= 180 and l1.min() >= 1 and np.unique(l1).size > 60
+    codes, res, lens = synth.doc_tokens(spec, 0, 50)
+    assert np.array_equal(lens, l1[:50]) and codes.size == lens.sum()
