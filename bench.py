@@ -42,11 +42,18 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--docs", type=int, default=10_000_000, help="documents of the WHOLE corpus (sharded over --gpus)")
     ap.add_argument("--doc-len", type=int, default=300)
     ap.add_argument("--doc-len-min", type=int, default=0, help="> 0: ragged documents, uniform in [doc-len-min, doc-len]")
+    ap.add_argument("--len-dist", choices=["uniform", "lognormal"], default="uniform",
+                    help="lognormal: clipped LogNormal(mean ~73, max 180) document lengths, the MS MARCO passage shape (config 3)")
+    ap.add_argument("--topics", type=int, default=8, help="topic centroids per document (generator)")
+    ap.add_argument("--rand256", type=int, default=51,
+                    help="of 256: share of tokens with a uniformly random code (51 = 20 %%: ~68 distinct codes per 300-token "
+                         "document = 0.23 per token; 121 -> 0.5; 200 -> 0.8)")
+    ap.add_argument("--hot", type=int, default=-1, help="s4_hot per-mille (first filter level); -1 = library default")
     ap.add_argument("--centroids", type=int, default=65536)
     ap.add_argument("--nbits", type=int, default=4)
     ap.add_argument("--nprobe", type=int, default=32)
@@ -74,6 +81,16 @@ def parse():
                          "small launch-bound kernels of one batch overlap the memory-bound ones of the next)")
     ap.add_argument("--workspace-gib", type=float, default=0.0, help="per-context scratch budget (0 = library default)")
     return ap.parse_args()
+
+
+def kernels_sha():
+    """Identity of the kernel sources the loaded library was built from (PMC traffic figures are only valid for them)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("np_kernels.h", "np_search.hip", "np_index.hip", "np_internal.h"):
+        with open(os.path.join(ROOT, "next-plaid_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_model():
@@ -117,8 +134,12 @@ def main():
     dim = 128
     pd = dim * a.nbits // 8
     len_min = a.doc_len_min if a.doc_len_min > 0 else a.doc_len
+    gen = dict(n_topics=a.topics, rand256=a.rand256)
+    if a.len_dist == "lognormal":
+        gen["len_table"] = synth.lognormal_len_table()
+        len_min, a.doc_len = 1, 180
     spec = synth.SynthSpec(num_docs=a.docs, num_centroids=a.centroids, dim=dim, nbits=a.nbits,
-                           doc_len_min=len_min, doc_len_max=a.doc_len, seed=1236)
+                           doc_len_min=len_min, doc_len_max=a.doc_len, seed=1236, **gen)
     cen = synth.centroids(spec)
     opts = dict(device=local_rank, shard_rank=rank, shard_count=world, max_batch=a.batch, n_contexts=max(1, a.streams))
     if a.workspace_gib > 0:
@@ -126,6 +147,8 @@ def main():
     t0 = time.time()
     ix = npa.MmapIndex.synth(spec, centroids=cen, **opts)
     t_build = time.time() - t0
+    if a.hot >= 0:
+        ix.tune("s4_hot", a.hot)
     docs_local = int(ix.info.shard_doc_end - ix.info.shard_doc_begin)
     thr = None if a.threshold < 0 else a.threshold
     prm = npa.SearchParameters(n_full_scores=a.n_full_scores, top_k=a.top_k, n_ivf_probe=a.nprobe,
@@ -255,17 +278,19 @@ def main():
     dom = max(per_stage, key=lambda k: per_stage[k][0])
     ms, bound, units, unit, peak = per_stage[dom]
     achieved = units / (ms * 1e-3) if ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if collected
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("docs_per_gpu") == docs_local:           # counters belong to one workload: never carried over
+            # counters belong to one workload AND one build of the kernels: never carried over to another
+            if tj.get("docs_per_gpu") == docs_local and tj.get("kernels_sha") == kernels_sha():
                 traffic = tj.get(dom)
+                traffic_src = {"commit": tj.get("commit"), "kernels_sha": tj.get("kernels_sha")}
         except Exception:
             traffic = None
     roofline = dict(kernel=dom, bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
-                    frac=round(achieved / peak, 5), traffic=traffic, ms_per_launch=round(ms, 4),
+                    frac=round(achieved / peak, 5), traffic=traffic, traffic_source=traffic_src, ms_per_launch=round(ms, 4),
                     all={k: dict(ms=round(v[0], 4), bound=v[1], achieved=round(v[2] / (v[0] * 1e-3), 2) if v[0] > 0 else None,
                                  unit=v[3], frac=round(v[2] / (v[0] * 1e-3) / v[4], 4) if v[0] > 0 else None)
                          for k, v in per_stage.items()},
@@ -287,7 +312,7 @@ def main():
                 # bounded sample: the first cdocs documents of the same corpus (same generator, same seed)
                 cdocs = a.cpu_docs if 0 < a.cpu_docs < a.docs else min(a.docs, 1_000_000)
                 sspec = synth.SynthSpec(num_docs=cdocs, num_centroids=a.centroids, dim=dim, nbits=a.nbits,
-                                        doc_len_min=len_min, doc_len_max=a.doc_len, seed=1236)
+                                        doc_len_min=len_min, doc_len_max=a.doc_len, seed=1236, **gen)
                 cix = npa.MmapIndex.synth(sspec, centroids=cen, device=local_rank, max_batch=a.batch, n_contexts=1)
                 e = cix.export()
             ox = O.OracleIndex(cen, synth.bucket_tables(spec)[1], e["ivf"], e["ivf_lengths"], e["doc_lengths"],

@@ -104,10 +104,12 @@ typedef struct np_stats {
   int64_t n_cand_tokens; /* sum of candidate doc lengths (codes read by S4) */
   int64_t n_exact_docs;  /* documents exact-scored */
   int64_t n_exact_tokens;/* tokens decompressed by S6 */
-  int64_t n_cand_codes;  /* distinct (doc, code) pairs actually gathered by S4 (<= n_cand_tokens) */
+  int64_t n_cand_codes;  /* u8 table rows gathered by the S4 filter (both levels); without the filter: f32 rows */
   int32_t n_queries;
   int32_t n_rounds;      /* candidate-pool rounds (1 unless the batch's candidates overflowed workspace_bytes) */
   int64_t n_survivors;   /* candidates that passed the S4 upper-bound filter and got an exact approximate score */
+  int64_t n_cand_dcodes; /* distinct (document, code) pairs of the candidates (<= n_cand_tokens) */
+  int64_t n_level2;      /* two-level filter: documents that took the exact u8 bound after the hot bound */
 } np_stats;
 
 /* ---- runtime ------------------------------------------------------------------------------ */

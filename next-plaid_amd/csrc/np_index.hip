@@ -218,19 +218,30 @@ static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bu
 
 
 // ---- derived: per-document distinct codes (one block per document, bitonic sort in LDS) ------------------
+// Two passes over the same kernel: with ucodes == NULL it only counts (ulen[d]); the host then lays the lists out DENSELY
+// (exclusive scan of the lengths, each list start rounded up to NP_ULIST_ALIGN entries so that list reads of 8 bytes stay
+// aligned) and the second pass writes list d at uoff[d].  (Round 2 kept each list at its document's token offset: T
+// entries of 4 bytes for ~T/4 useful ones, 4 B per token of HBM.)
 #define NP_UNIQ_MAX 4096
-__global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __restrict__ doc_off,
-                                                           const uint32_t* __restrict__ codes,
-                                                           uint32_t* __restrict__ ucodes, int32_t* __restrict__ ulen) {
+#define NP_ULIST_ALIGN 4
+__global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __restrict__ doc_off, CodeArr codes,
+                                                           void* __restrict__ ucodes, const int64_t* __restrict__ uoff,
+                                                           int32_t* __restrict__ ulen) {
   __shared__ uint32_t s[NP_UNIQ_MAX];
   __shared__ int s_wave[4];
   const int64_t d = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t off = doc_off[d];
   const int len = (int)(doc_off[d + 1] - off);
+  const int64_t uo = ucodes ? uoff[d] : 0;
+  auto put = [&](int i, uint32_t c) {
+    if (codes.wide) static_cast<uint32_t*>(ucodes)[uo + i] = c;
+    else static_cast<uint16_t*>(ucodes)[uo + i] = (uint16_t)c;
+  };
   if (len > NP_UNIQ_MAX) {  // very long document: keep the full list (still correct, just not shorter)
-    for (int i = tid; i < len; i += 256) ucodes[off + i] = codes[off + i];
-    if (tid == 0) ulen[d] = len;
+    if (ucodes)
+      for (int i = tid; i < len; i += 256) put(i, codes[off + i]);
+    else if (tid == 0) ulen[d] = len;
     return;
   }
   int n = 1;
@@ -258,11 +269,16 @@ __global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __rest
     __syncthreads();
     int before = base;
     for (int k = 0; k < wave; ++k) before += s_wave[k];
-    if (head) ucodes[off + before + (int)__popcll(bal & ((1ull << lane) - 1ull))] = s[i];
+    if (head && ucodes) put(before + (int)__popcll(bal & ((1ull << lane) - 1ull)), s[i]);
     base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     __syncthreads();
   }
-  if (tid == 0) ulen[d] = base;
+  if (tid == 0 && !ucodes) ulen[d] = base;
+}
+
+__global__ void ulen_padded_kernel(const int32_t* __restrict__ ulen, int64_t n, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ((int64_t)ulen[i] + NP_ULIST_ALIGN - 1) / NP_ULIST_ALIGN * NP_ULIST_ALIGN;
 }
 
 
@@ -275,7 +291,8 @@ __global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __rest
 // decompress_documents and np_hip_index_export return the on-disk order.  Documents longer than NP_SORT_MAX tokens
 // stay as they are.  direction 1 = sort, 0 = restore the original order (export).
 #define NP_SORT_MAX 512
-__global__ void __launch_bounds__(256) sort_doc_tokens_kernel(const int64_t* __restrict__ doc_off, uint32_t* __restrict__ codes,
+template <typename CT>
+__global__ void __launch_bounds__(256) sort_doc_tokens_kernel(const int64_t* __restrict__ doc_off, CT* __restrict__ codes,
                                                               uint8_t* __restrict__ residuals, uint16_t* __restrict__ tok_pos,
                                                               int pd, int to_sorted) {
   extern __shared__ uint64_t s_keys[];                        // [NP_SORT_MAX] (code << 32 | position)
@@ -310,7 +327,7 @@ __global__ void __launch_bounds__(256) sort_doc_tokens_kernel(const int64_t* __r
       }
     __syncthreads();
     for (int i = tid; i < len; i += 256) {
-      codes[off + i] = (uint32_t)(s_keys[i] >> 32);
+      codes[off + i] = (CT)(s_keys[i] >> 32);
       tok_pos[off + i] = (uint16_t)(s_keys[i] & 0xFFFFu);
     }
     for (int w = tid; w < len * pw; w += 256) {
@@ -320,7 +337,7 @@ __global__ void __launch_bounds__(256) sort_doc_tokens_kernel(const int64_t* __r
   } else {
     for (int i = tid; i < len; i += 256) s_keys[i] = ((uint64_t)codes[off + i] << 32) | (uint64_t)tok_pos[off + i];
     __syncthreads();
-    for (int i = tid; i < len; i += 256) codes[off + (int)(s_keys[i] & 0xFFFFull)] = (uint32_t)(s_keys[i] >> 32);
+    for (int i = tid; i < len; i += 256) codes[off + (int)(s_keys[i] & 0xFFFFull)] = (CT)(s_keys[i] >> 32);
     for (int w = tid; w < len * pw; w += 256) {
       const int i = w / pw, c = w - i * pw;
       rows_g[(int)(s_keys[i] & 0xFFFFull) * pw + c] = s_rows[w];
@@ -331,13 +348,20 @@ __global__ void __launch_bounds__(256) sort_doc_tokens_kernel(const int64_t* __r
 static int permute_tokens(const DeviceIndex* ix, int to_sorted) {
   if (ix->n_docs == 0 || ix->T == 0 || (ix->pd & 3)) return NP_OK;
   const size_t lds = (size_t)NP_SORT_MAX * 8 + (size_t)NP_SORT_MAX * ix->pd;
-  if (lds > 48 * 1024)
-    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_doc_tokens_kernel),
+  if (lds > 48 * 1024) {
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_doc_tokens_kernel<uint16_t>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_doc_tokens_kernel<uint32_t>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   for (int64_t d0 = 0; d0 < ix->n_docs; d0 += (int64_t)1 << 30) {
     const int64_t n = std::min<int64_t>((int64_t)1 << 30, ix->n_docs - d0);
-    sort_doc_tokens_kernel<<<(unsigned)n, 256, lds>>>(ix->d_doc_offsets + d0, ix->d_codes, ix->d_residuals, ix->d_tok_pos,
-                                                      ix->pd, to_sorted);
+    if (ix->code_wide)
+      sort_doc_tokens_kernel<uint32_t><<<(unsigned)n, 256, lds>>>(ix->d_doc_offsets + d0, (uint32_t*)ix->d_codes, ix->d_residuals,
+                                                                  ix->d_tok_pos, ix->pd, to_sorted);
+    else
+      sort_doc_tokens_kernel<uint16_t><<<(unsigned)n, 256, lds>>>(ix->d_doc_offsets + d0, (uint16_t*)ix->d_codes, ix->d_residuals,
+                                                                  ix->d_tok_pos, ix->pd, to_sorted);
   }
   NP_HIP(hipGetLastError());
   NP_HIP(hipDeviceSynchronize());
@@ -359,7 +383,7 @@ static int sort_tokens(DeviceIndex* ix) {
 __global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim, int nbits, int pd,
                                                        const float* __restrict__ centroids,
                                                        const float* __restrict__ wlut,
-                                                       const uint32_t* __restrict__ codes,
+                                                       CodeArr codes,
                                                        const uint8_t* __restrict__ residuals,
                                                        float* __restrict__ inv_norm) {
   const int lane = threadIdx.x & 63;
@@ -393,7 +417,7 @@ static int build_inv_norm(DeviceIndex* ix) {
   NP_TRY(dev_alloc(&ix->d_inv_norm, (size_t)ix->T, &ix->device_bytes));
   if (ix->T > 0) {
     const int64_t nblk = (ix->T + 255) / 256;
-    inv_norm_kernel<<<(unsigned)nblk, 256>>>(ix->T, ix->dim, ix->nbits, ix->pd, ix->d_centroids, ix->d_wlut, ix->d_codes,
+    inv_norm_kernel<<<(unsigned)nblk, 256>>>(ix->T, ix->dim, ix->nbits, ix->pd, ix->d_centroids, ix->d_wlut, ix->codes(),
                                              ix->d_residuals, ix->d_inv_norm);
   }
   NP_HIP(hipGetLastError());
@@ -406,13 +430,14 @@ static int build_inv_norm(DeviceIndex* ix) {
 // one eighth (or pair / quad of eighths) of every candidate at a time so that the slice of the query's score
 // table it touches stays resident in one XCD's L2.
 __global__ void __launch_bounds__(256) useg_kernel(int64_t n_docs, const int64_t* __restrict__ doc_off,
-                                                   const uint32_t* __restrict__ ucodes, const int32_t* __restrict__ ulen,
-                                                   uint32_t slice_w, uint4* __restrict__ useg, int* __restrict__ bad) {
+                                                   const int64_t* __restrict__ uoff, CodeArr ucodes,
+                                                   const int32_t* __restrict__ ulen, uint32_t slice_w,
+                                                   uint4* __restrict__ useg, int* __restrict__ bad) {
   const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (d >= n_docs) return;
-  const int64_t off = doc_off[d];
+  const int64_t off = uoff[d];
   const int n = ulen[d];
-  if (doc_off[d + 1] - off > NP_UNIQ_MAX || n > 65535) {   // list not sorted / counts do not fit
+  if (doc_off[d + 1] - doc_off[d] > NP_UNIQ_MAX || n > 65535) {   // list not sorted / counts do not fit
     *bad = 1;
     useg[d] = make_uint4(0, 0, 0, 0);
     return;
@@ -428,42 +453,102 @@ __global__ void __launch_bounds__(256) useg_kernel(int64_t n_docs, const int64_t
   useg[d] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
 }
 
-__global__ void doc_meta_kernel(int64_t n_docs, const int64_t* __restrict__ doc_off, const int32_t* __restrict__ ulen,
-                                uint4* __restrict__ meta) {
+__global__ void doc_meta_kernel(int64_t n_docs, const int64_t* __restrict__ doc_off, const int64_t* __restrict__ uoff,
+                                const int32_t* __restrict__ ulen, uint4* __restrict__ meta) {
   const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n_docs) return;
-  const int64_t o = doc_off[d];
-  const uint32_t dl = (uint32_t)(doc_off[d + 1] - o);   // w = offset bits 32..39 | doc length << 8
+  const int64_t o = uoff[d];                                     // the document's list in d_ucodes
+  const uint32_t dl = (uint32_t)(doc_off[d + 1] - doc_off[d]);   // w = offset bits 32..39 | doc length << 8
   meta[d] = make_uint4((uint32_t)d, (uint32_t)ulen[d], (uint32_t)(o & 0xFFFFFFFFll), (uint32_t)((o >> 32) & 0xFF) | (dl << 8));
 }
 
-static int build_unique_codes(DeviceIndex* ix) {
-  NP_TRY(dev_alloc(&ix->d_ucodes, (size_t)ix->T + 4, &ix->device_bytes));   // +4: the S4 filter reads codes 4 at a time
-  NP_HIP(hipMemset(ix->d_ucodes + ix->T, 0, 16));
-  NP_TRY(dev_alloc(&ix->d_ulen, (size_t)ix->n_docs, &ix->device_bytes));
-  NP_TRY(dev_alloc(&ix->d_useg, (size_t)ix->n_docs, &ix->device_bytes));
-  NP_TRY(dev_alloc(&ix->d_doc_meta, (size_t)ix->n_docs, &ix->device_bytes));
-  for (int64_t d0 = 0; d0 < ix->n_docs; d0 += (int64_t)1 << 30) {
-    const int64_t n = std::min<int64_t>((int64_t)1 << 30, ix->n_docs - d0);
-    unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->d_codes, ix->d_ucodes, ix->d_ulen + d0);
+// d_uoff (list offsets, [n_docs + 1]) is returned to the caller: the IVF build of the synthetic path reads the lists
+// through it; whoever receives it frees it.
+static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
+  *d_uoff_out = nullptr;
+  const int64_t N = ix->n_docs;
+  NP_TRY(dev_alloc(&ix->d_ulen, (size_t)N, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_useg, (size_t)N, &ix->device_bytes));
+  NP_TRY(dev_alloc(&ix->d_doc_meta, (size_t)N, &ix->device_bytes));
+  int64_t* d_uoff = nullptr;
+  NP_TRY(dev_alloc(&d_uoff, (size_t)N + 1, nullptr));
+  struct FreeOnError {
+    int64_t** p;
+    bool armed = true;
+    ~FreeOnError() {
+      if (armed) {
+        (void)hipFree(*p);
+        *p = nullptr;
+      }
+    }
+  } guard{&d_uoff};
+  NP_HIP(hipMemset(d_uoff, 0, 8));
+  // pass 1: list lengths
+  for (int64_t d0 = 0; d0 < N; d0 += (int64_t)1 << 30) {
+    const int64_t n = std::min<int64_t>((int64_t)1 << 30, N - d0);
+    unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->codes(), nullptr, nullptr, ix->d_ulen + d0);
   }
-  if (ix->n_docs > 0)
-    doc_meta_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(ix->n_docs, ix->d_doc_offsets, ix->d_ulen, ix->d_doc_meta);
+  NP_HIP(hipGetLastError());
+  int64_t total = 0;
+  if (N > 0) {
+    int64_t* d_pad = nullptr;
+    void* d_temp = nullptr;
+    NP_TRY(dev_alloc(&d_pad, (size_t)N, nullptr));
+    ulen_padded_kernel<<<(unsigned)((N + 255) / 256), 256>>>(ix->d_ulen, N, d_pad);
+    size_t tb = 0;
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_pad, d_uoff + 1, (int)N);
+    if (e == hipSuccess) e = hipMalloc(&d_temp, std::max<size_t>(tb, 16));
+    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_pad, d_uoff + 1, (int)N);
+    if (e == hipSuccess) e = hipMemcpy(&total, d_uoff + N, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_pad);
+    (void)hipFree(d_temp);
+    if (e != hipSuccess) {
+      set_error("distinct-code list scan failed: %s", hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? NP_ERR_OUT_OF_MEMORY : NP_ERR_DEVICE_UNAVAILABLE;
+    }
+  }
+  if (total >= ((int64_t)1 << 40)) {   // candidate records carry a 40-bit list offset
+    set_error("Index load failed: %lld distinct (document, code) pairs exceed the 40-bit list offset; use more shards",
+              (long long)total);
+    return NP_ERR_INDEX_LOAD;
+  }
+  ix->n_ucodes = total;
+  // pass 2: the lists, dense (+8 entries: list readers fetch up to 8 bytes past a list's last code)
+  {
+    const size_t bytes = ((size_t)total + 8) * ix->code_bytes();
+    hipError_t e = hipMalloc(&ix->d_ucodes, bytes);
+    if (e != hipSuccess) {
+      ix->d_ucodes = nullptr;
+      set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+      return NP_ERR_OUT_OF_MEMORY;
+    }
+    ix->device_bytes += bytes;
+    NP_HIP(hipMemset(ix->d_ucodes, 0, bytes));
+  }
+  for (int64_t d0 = 0; d0 < N; d0 += (int64_t)1 << 30) {
+    const int64_t n = std::min<int64_t>((int64_t)1 << 30, N - d0);
+    unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->codes(), ix->d_ucodes, d_uoff + d0, ix->d_ulen + d0);
+  }
+  if (N > 0)
+    doc_meta_kernel<<<(unsigned)((N + 255) / 256), 256>>>(N, ix->d_doc_offsets, d_uoff, ix->d_ulen, ix->d_doc_meta);
   NP_HIP(hipGetLastError());
   ix->sliced_ok = false;
-  if (ix->n_docs > 0) {
+  if (N > 0) {
     int* d_bad = nullptr;
     NP_HIP(hipMalloc(&d_bad, sizeof(int)));
     NP_HIP(hipMemset(d_bad, 0, sizeof(int)));
     const uint32_t slice_w = (uint32_t)((ix->K + 7) / 8);
-    useg_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(ix->n_docs, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
-                                                              slice_w, ix->d_useg, d_bad);
+    useg_kernel<<<(unsigned)((N + 255) / 256), 256>>>(N, ix->d_doc_offsets, d_uoff, ix->ucodes(), ix->d_ulen, slice_w,
+                                                      ix->d_useg, d_bad);
     int bad = 1;
-    NP_HIP(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+    hipError_t e = hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost);
     (void)hipFree(d_bad);
+    NP_HIP(e);
     ix->sliced_ok = (bad == 0);
   }
   NP_HIP(hipDeviceSynchronize());
+  guard.armed = false;
+  *d_uoff_out = d_uoff;
   return NP_OK;
 }
 
@@ -513,6 +598,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
   }
   ix->K = h.K;
   ix->KP = (h.K + 63) / 64 * 64;
+  ix->code_wide = h.K > 65536 ? 1 : 0;   // u16 codes whenever every centroid id fits (2 B per token instead of 4)
   ix->dim = h.dim;
   ix->nbits = h.nbits;
   ix->pd = h.dim * h.nbits / 8;
@@ -540,11 +626,16 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
   NP_HIP(hipMemcpy(ix->d_doc_offsets, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
 
   // codes (i64 -> u32, range-checked) and residuals, chunk by chunk
-  NP_TRY(dev_alloc(&ix->d_codes, (size_t)ix->T, &ix->device_bytes));
+  {
+    uint8_t* cbuf = nullptr;
+    NP_TRY(dev_alloc(&cbuf, (size_t)std::max<int64_t>(ix->T, 1) * ix->code_bytes(), &ix->device_bytes));
+    ix->d_codes = cbuf;
+  }
   NP_TRY(dev_alloc(&ix->d_residuals, (size_t)ix->T * ix->pd, &ix->device_bytes));
   {
     const int64_t PIECE = (int64_t)8 << 20;
     std::vector<uint32_t> tmp((size_t)std::min<int64_t>(PIECE, std::max<int64_t>(ix->T, 1)));
+    std::vector<uint16_t> tmp16(ix->code_wide ? 0 : tmp.size());
     int64_t pos = 0;  // token position of the current chunk's first token in the host arrays
     for (const HostChunk& c : h.chunks) {
       int64_t a = std::max(pos, tb), b = std::min(pos + c.n_tokens, te);
@@ -560,7 +651,12 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
           }
           tmp[i] = (uint32_t)v;
         }
-        NP_HIP(hipMemcpy(ix->d_codes + (s - tb), tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        if (ix->code_wide) {
+          NP_HIP(hipMemcpy((uint32_t*)ix->d_codes + (s - tb), tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        } else {
+          for (int64_t i = 0; i < n; ++i) tmp16[i] = (uint16_t)tmp[i];
+          NP_HIP(hipMemcpy((uint16_t*)ix->d_codes + (s - tb), tmp16.data(), (size_t)n * 2, hipMemcpyHostToDevice));
+        }
       }
       if (b > a)
         NP_HIP(hipMemcpy(ix->d_residuals + (a - tb) * ix->pd, c.residuals + (a - pos) * ix->pd,
@@ -604,7 +700,12 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
   }
   NP_TRY(sort_tokens(ix));
-  NP_TRY(build_unique_codes(ix));
+  {
+    int64_t* d_uoff = nullptr;
+    const int rc = build_unique_codes(ix, &d_uoff);
+    (void)hipFree(d_uoff);
+    NP_TRY(rc);
+  }
   NP_TRY(build_inv_norm(ix));
   cleanup.p = nullptr;
   *out = ix;
@@ -628,15 +729,16 @@ struct SynthP {
   int32_t len_min, len_span, n_topics, rand256, pd, nw;
 };
 
-__global__ void synth_lens_kernel(SynthP p, int64_t* lens) {
+__global__ void synth_lens_kernel(SynthP p, const int32_t* __restrict__ len_table, int len_table_size, int64_t* lens) {
   int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= p.n_docs) return;
-  lens[d] = p.len_min + (int64_t)(mix64(p.b_len + (uint64_t)(p.doc_begin + d)) % (uint64_t)p.len_span);
+  const uint64_t r = mix64(p.b_len + (uint64_t)(p.doc_begin + d));
+  lens[d] = len_table ? (int64_t)len_table[r % (uint64_t)len_table_size] : p.len_min + (int64_t)(r % (uint64_t)p.len_span);
 }
 
 // one wave per document
 __global__ void __launch_bounds__(256) synth_tokens_kernel(SynthP p, const int64_t* __restrict__ doc_off,
-                                                           uint32_t* __restrict__ codes, uint8_t* __restrict__ res) {
+                                                           void* __restrict__ codes, int wide, uint8_t* __restrict__ res) {
   const int lane = threadIdx.x & 63;
   int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= p.n_docs) return;
@@ -653,7 +755,8 @@ __global__ void __launch_bounds__(256) synth_tokens_kernel(SynthP p, const int64
       uint64_t rt = mix64(p.b_topic + (gdoc * (uint64_t)p.n_topics + s));
       code = (uint32_t)(((rt & 0xFFFFFFFFull) % p.K) >> ((rt >> 32) & 3));
     }
-    codes[off + t] = code;
+    if (wide) static_cast<uint32_t*>(codes)[off + t] = code;
+    else static_cast<uint16_t*>(codes)[off + t] = (uint16_t)code;
   }
   const int nwords = len * p.nw;
   for (int w = lane; w < nwords; w += 64) {
@@ -676,8 +779,8 @@ __global__ void __launch_bounds__(256) synth_tokens_kernel(SynthP p, const int64
 #define NP_IVF_SEG ((int64_t)1 << 29)
 
 // one wave per document: pair position = (exclusive prefix of ulen) - seg_base
-__global__ void __launch_bounds__(256) ivf_emit_pairs_kernel(int64_t d0, int64_t d1, const int64_t* __restrict__ doc_off,
-                                                             const uint32_t* __restrict__ ucodes,
+__global__ void __launch_bounds__(256) ivf_emit_pairs_kernel(int64_t d0, int64_t d1, const int64_t* __restrict__ uoff,
+                                                             CodeArr ucodes,
                                                              const int32_t* __restrict__ ulen,
                                                              const int64_t* __restrict__ upfx /* inclusive */,
                                                              int64_t seg_base, uint64_t* __restrict__ keys) {
@@ -686,7 +789,7 @@ __global__ void __launch_bounds__(256) ivf_emit_pairs_kernel(int64_t d0, int64_t
   if (d >= d1) return;
   const int n = ulen[d];
   const int64_t pos = upfx[d] - n - seg_base;
-  const int64_t off = doc_off[d];
+  const int64_t off = uoff[d];
   for (int i = lane; i < n; i += 64) keys[pos + i] = ((uint64_t)ucodes[off + i] << 32) | (uint64_t)d;
 }
 
@@ -720,7 +823,7 @@ __global__ void ulen_to_i64_kernel(const int32_t* __restrict__ ulen, int64_t n, 
   if (i < n) out[i] = ulen[i];
 }
 
-static int build_ivf_from_ucodes(DeviceIndex* ix) {
+static int build_ivf_from_ucodes(DeviceIndex* ix, const int64_t* d_uoff) {
   const int64_t K = ix->K, N = ix->n_docs;
   std::vector<int64_t> ioff((size_t)K + 1, 0);
   ix->ivf_size = 0;
@@ -787,7 +890,7 @@ static int build_ivf_from_ucodes(DeviceIndex* ix) {
       const int64_t base = d0 > 0 ? upfx[(size_t)d0 - 1] : 0, n = upfx[(size_t)d1 - 1] - base;
       *n_out = n;
       if (n == 0) return NP_OK;
-      ivf_emit_pairs_kernel<<<(unsigned)((d1 - d0 + 3) / 4), 256>>>(d0, d1, ix->d_doc_offsets, ix->d_ucodes, ix->d_ulen,
+      ivf_emit_pairs_kernel<<<(unsigned)((d1 - d0 + 3) / 4), 256>>>(d0, d1, d_uoff, ix->ucodes(), ix->d_ulen,
                                                                    d_upfx, base, d_k1);
       size_t tbs = tb;
       NP_HIP(hipcub::DeviceRadixSort::SortKeys(d_temp, tbs, d_k1, d_k2, (int)n, 0, 32 + kbits));
@@ -839,9 +942,17 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
   }
   NP_TRY(check_geometry(s->num_centroids, s->dim, s->nbits, s->num_docs));
   if (s->doc_len_min < 0 || s->doc_len_max < s->doc_len_min || s->doc_len_max > NP_UNIQ_MAX || s->n_topics <= 0 ||
-      s->dim * s->nbits / 8 > 128) {
+      s->dim * s->nbits / 8 > 128 || s->len_table_size < 0 || (s->len_table_size > 0 && !s->len_table)) {
     set_error("Invalid configuration: synth doc_len/n_topics/packed width out of range");
     return NP_ERR_INVALID_ARGUMENT;
+  }
+  int32_t table_max = 0;
+  for (int i = 0; i < s->len_table_size; ++i) {
+    if (s->len_table[i] < 0 || s->len_table[i] > NP_UNIQ_MAX) {
+      set_error("Invalid configuration: synth len_table entry %d out of range", s->len_table[i]);
+      return NP_ERR_INVALID_ARGUMENT;
+    }
+    table_max = std::max(table_max, s->len_table[i]);
   }
   DeviceGuard g(o.device);
   if (!g.ok) {
@@ -877,10 +988,11 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
   }
   ix->K = s->num_centroids;
   ix->KP = (ix->K + 63) / 64 * 64;
+  ix->code_wide = ix->K > 65536 ? 1 : 0;
   ix->dim = s->dim;
   ix->nbits = s->nbits;
   ix->pd = s->dim * s->nbits / 8;
-  ix->max_doc_len = s->doc_len_max;
+  ix->max_doc_len = s->len_table_size > 0 ? table_max : s->doc_len_max;
   NP_TRY(upload_codec(ix, s->centroids, s->bucket_weights));
 
   SynthP p;
@@ -903,14 +1015,26 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
   NP_HIP(hipMemset(ix->d_doc_offsets, 0, sizeof(int64_t)));
   if (ix->n_docs > 0) {
     int64_t* d_lens = nullptr;
+    int32_t* d_tab = nullptr;
     NP_TRY(dev_alloc(&d_lens, (size_t)ix->n_docs, nullptr));
-    synth_lens_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(p, d_lens);
+    if (s->len_table_size > 0) {
+      hipError_t e0 = hipMalloc(&d_tab, (size_t)s->len_table_size * 4);
+      if (e0 == hipSuccess) e0 = hipMemcpy(d_tab, s->len_table, (size_t)s->len_table_size * 4, hipMemcpyHostToDevice);
+      if (e0 != hipSuccess) {
+        (void)hipFree(d_lens);
+        (void)hipFree(d_tab);
+        set_error("synth: length table upload failed: %s", hipGetErrorString(e0));
+        return NP_ERR_DEVICE_UNAVAILABLE;
+      }
+    }
+    synth_lens_kernel<<<(unsigned)((ix->n_docs + 255) / 256), 256>>>(p, d_tab, s->len_table_size, d_lens);
     size_t tb = 0;
     hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_lens, ix->d_doc_offsets + 1, (int)ix->n_docs);
     if (e == hipSuccess) e = hipMalloc(&d_temp, std::max<size_t>(tb, 16));
     if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_lens, ix->d_doc_offsets + 1, (int)ix->n_docs);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_lens);
+    (void)hipFree(d_tab);
     (void)hipFree(d_temp);
     d_temp = nullptr;
     if (e != hipSuccess) {
@@ -924,22 +1048,33 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     return NP_ERR_INVALID_ARGUMENT;
   }
   ix->n_emb_total = 0;  // filled below for unsharded corpora; sharded: avg-based estimate
-  NP_TRY(dev_alloc(&ix->d_codes, (size_t)ix->T, &ix->device_bytes));
+  {
+    uint8_t* cbuf = nullptr;
+    NP_TRY(dev_alloc(&cbuf, (size_t)std::max<int64_t>(ix->T, 1) * ix->code_bytes(), &ix->device_bytes));
+    ix->d_codes = cbuf;
+  }
   NP_TRY(dev_alloc(&ix->d_residuals, (size_t)ix->T * ix->pd, &ix->device_bytes));
   if (ix->n_docs > 0)
-    synth_tokens_kernel<<<(unsigned)((ix->n_docs + 3) / 4), 256>>>(p, ix->d_doc_offsets, ix->d_codes, ix->d_residuals);
+    synth_tokens_kernel<<<(unsigned)((ix->n_docs + 3) / 4), 256>>>(p, ix->d_doc_offsets, ix->d_codes, ix->code_wide,
+                                                                   ix->d_residuals);
   NP_HIP(hipGetLastError());
   NP_HIP(hipDeviceSynchronize());
 
   // whole-corpus token count: exact when unsharded or fixed-length, else extrapolated
-  if (o.shard_count == 1 || s->doc_len_min == s->doc_len_max)
-    ix->n_emb_total = (s->doc_len_min == s->doc_len_max) ? s->num_docs * (int64_t)s->doc_len_min : ix->T;
+  const bool fixed_len = s->len_table_size == 0 && s->doc_len_min == s->doc_len_max;
+  if (o.shard_count == 1 || fixed_len)
+    ix->n_emb_total = fixed_len ? s->num_docs * (int64_t)s->doc_len_min : ix->T;
   else
     ix->n_emb_total = ix->n_docs > 0 ? (int64_t)((double)ix->T / (double)ix->n_docs * (double)s->num_docs) : 0;
   ix->avg_doclen = s->num_docs > 0 ? (double)ix->n_emb_total / (double)s->num_docs : 0.0;
   NP_TRY(sort_tokens(ix));
-  NP_TRY(build_unique_codes(ix));
-  NP_TRY(build_ivf_from_ucodes(ix));   // index.rs:479-499
+  {
+    int64_t* d_uoff = nullptr;
+    int rc = build_unique_codes(ix, &d_uoff);
+    if (rc == NP_OK) rc = build_ivf_from_ucodes(ix, d_uoff);   // index.rs:479-499
+    (void)hipFree(d_uoff);
+    NP_TRY(rc);
+  }
   NP_TRY(build_inv_norm(ix));
   cleanup.p = nullptr;
   *out = ix;
@@ -1088,8 +1223,14 @@ int np_hip_index_export(const np_index* ix, int64_t* doc_lengths, int64_t* codes
     std::vector<uint32_t> tmp((size_t)std::min(PIECE, ix->T));
     for (int64_t s = 0; s < ix->T; s += PIECE) {
       int64_t n = std::min(PIECE, ix->T - s);
-      NP_HIP(hipMemcpy(tmp.data(), ix->d_codes + s, (size_t)n * 4, hipMemcpyDeviceToHost));
-      for (int64_t i = 0; i < n; ++i) codes[s + i] = (int64_t)tmp[i];
+      if (ix->code_wide) {
+        NP_HIP(hipMemcpy(tmp.data(), (const uint32_t*)ix->d_codes + s, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) codes[s + i] = (int64_t)tmp[i];
+      } else {
+        uint16_t* t16 = reinterpret_cast<uint16_t*>(tmp.data());
+        NP_HIP(hipMemcpy(t16, (const uint16_t*)ix->d_codes + s, (size_t)n * 2, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) codes[s + i] = (int64_t)t16[i];
+      }
     }
   }
   if (residuals && ix->T > 0)

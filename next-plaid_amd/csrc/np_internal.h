@@ -4,9 +4,11 @@
 //   centroids   f32 [K][dim]            replicated on every shard   (centroids.npy)
 //   wlut        f32 [2^nbits]           permuted bucket weights: wlut[s] = bucket_weights[bitrev_nbits(s)]
 //                                       (folds codec.rs:168-214's two LUTs into one)
-//   codes       u32 [T]                 centroid id per token       (N.codes.npy, i64 on disk)
+//   codes       u16 [T] (K <= 65536) or u32 [T]   centroid id per token   (N.codes.npy, i64 on disk, range-checked at load)
 //   residuals   u8  [T][pd]             packed buckets, unchanged   (N.residuals.npy)
-//   ucodes/ulen u32 [T] / i32 [n_docs]  derived at open: each document's DISTINCT codes (S4 gathers these)
+//   ucodes      u16 / u32 [U]           derived at open: the documents' sorted DISTINCT-code lists, DENSE (document d's list
+//                                       starts at the offset its doc_meta record carries, 8-byte aligned; U = their total
+//                                       + padding); S4 gathers these.  ulen i32 [n_docs] = list lengths
 //   inv_norm    f32 [T]                 derived at open: 1/||centroid + residual|| per token (S6 QC-reuse form)
 //   tok_pos     u16 [T]                 derived at open: codes / residuals / inv_norm keep each document's tokens ORDERED BY
 //                                       CODE (MaxSim is a max over tokens: order-free), tok_pos = the original position
@@ -24,6 +26,16 @@
 #include "../../include/nextplaid_hip.h"
 
 namespace np {
+
+// A code array of the index (token codes, or the documents' distinct-code lists): u16 entries when every centroid id
+// fits 16 bits (K <= 65536), u32 otherwise.  `wide` is a kernel argument, so the branch is wave-uniform.
+struct CodeArr {
+  const void* p;
+  int wide;
+  __device__ __forceinline__ uint32_t operator[](int64_t i) const {
+    return wide ? static_cast<const uint32_t*>(p)[i] : (uint32_t)static_cast<const uint16_t*>(p)[i];
+  }
+};
 
 // ---- errors --------------------------------------------------------------------------------
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
@@ -131,12 +143,14 @@ struct DeviceIndex {
   int64_t max_doc_len = 0;
   float* d_centroids = nullptr;
   float* d_wlut = nullptr;
-  uint32_t* d_codes = nullptr;
-  uint32_t* d_ucodes = nullptr;   // [T] per-document sorted distinct codes at the document's offset (derived)
+  void* d_codes = nullptr;        // [T] u16 when code_wide == 0 (K <= 65536), else u32
+  int code_wide = 0;
+  void* d_ucodes = nullptr;       // [n_ucodes] dense per-document sorted distinct-code lists, same element type (derived)
+  int64_t n_ucodes = 0;           // entries of d_ucodes without the tail padding
   int32_t* d_ulen = nullptr;      // [n_docs] number of distinct codes per document (derived)
   uint4* d_useg = nullptr;        // [n_docs] 8 x u16: distinct codes below each eighth of the centroid range (derived)
-  uint4* d_doc_meta = nullptr;    // [n_docs] the 16-B candidate record of every document {doc, n distinct codes, token offset lo,
-                                  // offset bits 32..39 | doc length << 8} (derived): S3 copies it instead of three gathers
+  uint4* d_doc_meta = nullptr;    // [n_docs] the 16-B candidate record of every document {doc, n distinct codes, offset of its
+                                  // distinct-code list in d_ucodes: low 32 bits, bits 32..39 | doc length << 8} (derived)
   bool sliced_ok = false;         // every document's distinct-code list is sorted and < 65536 long
   float cmax = 0.f;               // upper bound of the centroid row norms (derived; scales the S4 u8 score table)
   bool filter_ok = false;         // every centroid value is finite: the S4 upper-bound filter may run
@@ -153,6 +167,9 @@ struct DeviceIndex {
   size_t device_bytes = 0;
   np_open_opts opts{};
   Tuning tune;
+  CodeArr codes() const { return CodeArr{d_codes, code_wide}; }
+  CodeArr ucodes() const { return CodeArr{d_ucodes, code_wide}; }
+  size_t code_bytes() const { return code_wide ? 4 : 2; }
   // context pool
   mutable std::mutex mu;
   mutable std::condition_variable cv;

@@ -47,11 +47,13 @@ struct Counters {  // per-call work counters (np_stats)
   unsigned long long n_cells, n_ivf_ids, n_candidates, n_cand_tokens, n_exact_docs, n_exact_tokens, n_cand_codes;
   unsigned long long n_rounds;     // candidate-pool rounds the slice needed (max over slices)
   unsigned long long n_survivors;  // candidates that passed the S4 upper-bound filter (= n_candidates when it is off)
+  unsigned long long n_cand_dcodes;  // distinct (document, code) pairs of the candidates (the hot level scans these)
+  unsigned long long n_level2;       // two-level filter: documents that took the exact u8 bound (S1 + S2)
 };
 
 // One launch instead of a dozen hipMemsetAsync calls per batch (each ~3.6 us on the stream: 50 us per batch at 1 M
 // documents): fills up to NP_CLEAR_MAX small word regions (counters, per-query bitmaps, histogram, hand-out slots).
-#define NP_CLEAR_MAX 12
+#define NP_CLEAR_MAX 24
 struct ClearList {
   uint32_t* p[NP_CLEAR_MAX];
   uint32_t words[NP_CLEAR_MAX];
@@ -750,7 +752,7 @@ __global__ void __launch_bounds__(256) masked_gmax_kernel(const float* __restric
 // one wave per subset doc: doc bitmap (shard-local) + eligible-centroid bitmap
 __global__ void __launch_bounds__(256) subset_kernel(const int64_t* __restrict__ subset, int64_t n, int64_t doc_begin,
                                                      int64_t n_docs, const int64_t* __restrict__ doc_off,
-                                                     const uint32_t* __restrict__ codes, uint32_t* __restrict__ docbits,
+                                                     CodeArr codes, uint32_t* __restrict__ docbits,
                                                      uint32_t* __restrict__ elig) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1193,7 +1195,7 @@ __global__ void __launch_bounds__(256) approx_kernel(const float* __restrict__ Q
                                                      const int32_t* __restrict__ qoff,
                                                      const uint4* __restrict__ cand_meta, const int32_t* __restrict__ n_cand,
                                                      RoundPlan rp, int round, int max_rounds,
-                                                     const uint32_t* __restrict__ codes, float* __restrict__ approx,
+                                                     CodeArr codes, float* __restrict__ approx,
                                                      Counters* ctr) {
   constexpr int RPI = 64 / LPR;            // rows (codes) per gather instruction
   constexpr int RW = 4 * LPR + 1;          // LDS row stride in floats (+1: conflict-free column walks)
@@ -1357,7 +1359,7 @@ __global__ void __launch_bounds__(256) approx_xcd_kernel(const float* __restrict
                                                          const uint4* __restrict__ cand_meta,
                                                          const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
                                                          int max_rounds,
-                                                         const uint32_t* __restrict__ codes, int64_t T,
+                                                         CodeArr codes, int64_t T /* entries of `codes` */,
                                                          const uint4* __restrict__ useg, float* __restrict__ approx,
                                                          int pshift, Counters* ctr) {
   static_assert(!SWZ || LPR == 8, "the swizzle pattern broadcasts inside 8-lane groups");
@@ -1537,7 +1539,7 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
                                                             const uint4* __restrict__ cand_meta,
                                                             const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
                                                             int max_rounds,
-                                                            const uint32_t* __restrict__ codes, int64_t T,
+                                                            CodeArr codes, int64_t T /* entries of `codes` */,
                                                             const uint4* __restrict__ useg, float* __restrict__ approx,
                                                             int pshift, uint32_t slice_w, Counters* ctr) {
   constexpr int RPI = 64 / LPR;   // groups per wave
@@ -1744,7 +1746,8 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 // v_max_u32 on byte lanes.  Queries with a non-finite value (qflag) and queries with <= n_sel candidates skip
 // the filter: all their candidates survive.
 // ---------------------------------------------------------------------------------------------
-#define NP_UB_BINS 8192
+#define NP_UB_BINS 2048    // histogram bins of the integer bounds: bin = U >> hshift, hshift = log2(ROWB / 32) + 2 (U <= 255 * ROWB);
+                           // u32 counters in LDS (8 KB): a workgroup's share of a query's documents is unbounded
 #define NP_UB_NBX 96       // workgroups per XCD: 3 per CU (48 KB of LDS each)
 
 // CT = uint16_t when every code fits 16 bits (K <= 65536), else uint32_t.
@@ -1755,16 +1758,20 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 //         the padding of the lockstep walk costs no L2 request slot.
 template <int ROWB, typename CT, int MODE>
 __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
-                                                        const uint4* __restrict__ cand_meta,
-                                                        const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
-                                                        int max_rounds, const uint32_t* __restrict__ codes,
+                                                        const uint4* __restrict__ cand_meta /* records of the list to score */,
+                                                        const int32_t* __restrict__ n_begin /* [B] first record (NULL = 0) */,
+                                                        const int32_t* __restrict__ n_count /* [B] records to score */,
+                                                        const int32_t* __restrict__ n_cand /* [B] ALL candidates of the query: skip rule */,
+                                                        RoundPlan rp, int round,
+                                                        int max_rounds, const CT* __restrict__ codes /* lists start 8-B aligned, array padded */,
                                                         const uint32_t* __restrict__ qflag, int n_sel,
-                                                        uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift,
+                                                        uint16_t* __restrict__ U /* [pool] by record position */,
+                                                        uint32_t* __restrict__ hist /* [B][NP_UB_BINS] or NULL */, int hshift,
                                                         uint32_t* __restrict__ cursor /* [B] zeroed: next unclaimed candidate */,
                                                         int32_t* __restrict__ slots /* [8][B+1] = -1 */,
                                                         int32_t* __restrict__ ticket /* [1] = -1 */, int B,
                                                         int steal_min /* unclaimed documents worth joining a query for */,
-                                                        Counters* ctr) {
+                                                        Counters* ctr, int count_tokens /* add the lists' token counts to ctr */) {
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
   constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // distinct codes of one document staged per pass (32 KB of LDS per
@@ -1776,16 +1783,16 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   // per lane), and the gathers take their codes from there.  (Reading it 16 B at a time per lane as the walk
   // proceeds keeps ~3 lines per document live for the whole walk -- 6 MB per XCD next to the 2 MB table: measured
   // 30 M L2 misses and 8x over-fetch per launch.)
-  __shared__ uint32_t s_hist[NP_UB_BINS / 2];          // two u16 counters per word (a block sees < 65536 docs per query)
+  __shared__ uint32_t s_hist[NP_UB_BINS];
   __shared__ CT s_codes[4][DPW][CAP];
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
-  const int x = blockIdx.x & 7, NBX = gridDim.x >> 3;
+  const int x = blockIdx.x & 7;
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
-  unsigned long long toks = 0, ucnt = 0;
+  unsigned long long toks = 0, ucnt = 0, ndoc = 0;
   const int half = lane >> 5, hl = lane & 31;   // staging: half-wave `half` loads 4 codes per lane of one document
   // The waves of an XCD claim the query's documents DPW at a time from a per-query cursor, so every workgroup of
   // the XCD finishes a query within one claim of the others and moves on together: with a fixed share per
@@ -1801,8 +1808,8 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         int64_t most = steal_min;
         for (int j = rb; j < re; ++j) {
           const int b2 = rp.order[j];
-          const int64_t n2 = n_cand[b2];
-          if (qflag[b2] || n2 <= (int64_t)n_sel) continue;
+          if (qflag[b2] || n_cand[b2] <= n_sel) continue;
+          const int64_t n2 = n_count[b2];
           const int64_t left = n2 - (int64_t)__hip_atomic_load(&cursor[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (left >= most) {
             most = left;
@@ -1814,9 +1821,11 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     __syncthreads();
     const int b = __builtin_amdgcn_readfirstlane(s_q);
     if (b < 0) break;
-    const int64_t n = n_cand[b];
-    if (qflag[b] || n <= (int64_t)n_sel) continue;   // ub_cut_kernel keeps every candidate of this query
-    const int64_t pbase = rp.cand_base[b];
+    if (qflag[b] || n_cand[b] <= n_sel) continue;   // the final cut keeps every candidate of this query
+    const int64_t first = n_begin ? n_begin[b] : 0;
+    const int64_t n = n_count[b];                    // records [first, first + n) of the query's list
+    if (n <= 0) continue;
+    const int64_t pbase = rp.cand_base[b] + first;
     const uint4* metab = cand_meta + pbase;
     const char* Tb = reinterpret_cast<const char*>(QCU + (int64_t)b * KP * ROWB) + jl * 16;
     // MODE 2: this query's table as a bounds-checked buffer (descriptor built from wave-uniform values only)
@@ -1825,10 +1834,10 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tb64 >> 32));
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((uint64_t)thi << 32) | tlo), 0, (int)(KP * ROWB), 0x00020000);
-    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
-    const bool big = n / NBX >= 60000;   // a block could see >= 2^16 documents of one bin: count in memory instead
+    uint32_t* hb = hist ? hist + (int64_t)b * NP_UB_BINS : nullptr;
     __syncthreads();
-    for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
+    if (hb)
+      for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
     __syncthreads();
     uint32_t inext = 0;
     if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
@@ -1854,6 +1863,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         if (valid) {
           toks += (unsigned long long)(m.w >> 8);
           ucnt += (unsigned long long)nd;
+          ++ndoc;
         }
       }
       int nmax = nd;
@@ -1879,21 +1889,28 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
           for (int j = 0; j < SB; ++j) {
             const int sl = 2 * (sb + j) + half;
             nds[j] = s_nd[wave][sl];
-            const uint32_t* cp = codes + s_cl[wave][sl];
-            const int pos = min(p0 + CPS * hl, max(nds[j] - 1, 0));   // clamped: always inside (or 3 past) the list
+            const CT* cp = codes + s_cl[wave][sl];
+            // clamped to the list's last CPS-aligned group: one aligned 8-byte load (lists start 8-B aligned, the array is
+            // padded), at most CPS - 1 entries past the list's end
+            const int pos = min(p0 + CPS * hl, max(nds[j] - 1, 0) & ~(CPS - 1));
             if constexpr (NT) {
-              c0[j] = __builtin_nontemporal_load(cp);
+              c0[j] = (uint32_t)__builtin_nontemporal_load(cp);
 #pragma unroll
-              for (int k = 0; k < CPS; ++k) cv[j][k] = __builtin_nontemporal_load(cp + pos + k);
+              for (int k = 0; k < CPS; ++k) cv[j][k] = (uint32_t)__builtin_nontemporal_load(cp + pos + k);
             } else {
-              c0[j] = cp[0];
-              __builtin_memcpy(cv[j], cp + pos, 4 * CPS);   // 4-byte aligned load; the array is padded by 4 entries
+              c0[j] = (uint32_t)cp[0];
+              const uint2 raw = *reinterpret_cast<const uint2*>(cp + pos);
+              if constexpr (sizeof(CT) == 2) {
+                cv[j][0] = raw.x & 0xFFFFu; cv[j][1] = raw.x >> 16; cv[j][2] = raw.y & 0xFFFFu; cv[j][3] = raw.y >> 16;
+              } else {
+                cv[j][0] = raw.x; cv[j][1] = raw.y;
+              }
             }
           }
 #pragma unroll
           for (int j = 0; j < SB; ++j) {
             const int sl = 2 * (sb + j) + half;
-            const int pos = p0 + CPS * hl;
+            const int pos = p0 + CPS * hl;   // the position this LDS slot stands for (the load above may have been clamped)
 #pragma unroll
             for (int k = 0; k < CPS; ++k)
               if (pos + k >= nds[j]) cv[j][k] = c0[j];
@@ -1972,58 +1989,64 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
       for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
       if (valid && jl == 0) {
         U[pbase + i] = (uint16_t)sum;
-        const uint32_t bin = min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1));
-        if (big) atomicAdd(&hb[bin], 1u);
-        else atomicAdd(&s_hist[bin >> 1], 1u << (16 * (bin & 1)));
+        if (hb) atomicAdd(&s_hist[min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
       }
       __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next one
     }
     __syncthreads();
-    for (int i = tid; i < NP_UB_BINS / 2; i += 256) {
-      const uint32_t v = s_hist[i];
-      if (v & 0xFFFFu) atomicAdd(&hb[2 * i], v & 0xFFFFu);
-      if (v >> 16) atomicAdd(&hb[2 * i + 1], v >> 16);
-    }
+    if (hb)
+      for (int i = tid; i < NP_UB_BINS; i += 256) {
+        const uint32_t v = s_hist[i];
+        if (v) atomicAdd(&hb[i], v);
+      }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     toks += __shfl_xor(toks, o);
     ucnt += __shfl_xor(ucnt, o);
+    ndoc += __shfl_xor(ndoc, o);
   }
-  // one pair of (same-address) memory atomics per workgroup, not per wave
-  __shared__ unsigned long long s_cnt[2];
+  // one set of (same-address) memory atomics per workgroup, not per wave
+  __shared__ unsigned long long s_cnt[3];
   __syncthreads();
-  if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
+  if (tid == 0) s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
   __syncthreads();
   if (lane == 0 && toks) {
     atomicAdd(&s_cnt[0], toks);
     atomicAdd(&s_cnt[1], ucnt);
+    atomicAdd(&s_cnt[2], ndoc);
   }
   __syncthreads();
-  if (tid == 0 && s_cnt[0]) {
-    atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
-    atomicAdd(&ctr->n_cand_codes, s_cnt[1]);
+  if (tid == 0 && s_cnt[0] && ctr) {
+    if (count_tokens) {   // the single-level filter: every candidate passes through here once
+      atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
+      atomicAdd(&ctr->n_cand_dcodes, s_cnt[1]);
+    } else {              // a list of the two-level filter
+      atomicAdd(&ctr->n_level2, s_cnt[2]);
+    }
+    atomicAdd(&ctr->n_cand_codes, s_cnt[1]);      // table rows gathered
   }
 }
 
-// Per query: the histogram bin of the n_sel-th largest U minus the slack (see above) -> thr[b]; 0 keeps everyone
-// (flagged queries, queries with <= n_sel candidates).  One block per query.
+// Per query: the histogram bin of the n_sel-th largest bound minus the slack (see above) -> thr[b]; 0 = "the filter does
+// not apply" (flagged queries, queries with <= n_sel candidates, or a cut that reaches bin 0).  One block per query.
 __global__ void __launch_bounds__(256) ub_thr_kernel(const uint32_t* __restrict__ hist, int hshift, int slack, int n_sel,
                                                      const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
                                                      const uint32_t* __restrict__ qflag, uint32_t* __restrict__ thr) {
   __shared__ uint32_t s_part[256];
+  constexpr int BPT = NP_UB_BINS / 256;   // bins per thread
   const int b = blockIdx.x, tid = threadIdx.x;
   if (rp.round_of[b] != round) return;
   if (qflag[b] != 0 || n_cand[b] <= n_sel) {
     if (tid == 0) thr[b] = 0;
     return;
   }
-  // bins from the top: thread t owns bins [(255 - t) * 32, +32)
+  // bins from the top: thread t owns bins [(255 - t) * BPT, +BPT)
   const uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
-  const int top = (255 - tid) * 32;
+  const int top = (255 - tid) * BPT;
   uint32_t mine = 0;
 #pragma unroll
-  for (int k4 = 0; k4 < 8; ++k4) {
+  for (int k4 = 0; k4 < BPT / 4; ++k4) {
     const uint4 v = *reinterpret_cast<const uint4*>(hb + top + 4 * k4);
     mine += v.x + v.y + v.z + v.w;
   }
@@ -2036,8 +2059,8 @@ __global__ void __launch_bounds__(256) ub_thr_kernel(const uint32_t* __restrict_
       if (cum + s_part[t] >= (uint32_t)n_sel) break;
       cum += s_part[t];
     }
-    int bin = (255 - t) * 32 + 31;
-    for (; bin > (255 - t) * 32; --bin) {
+    int bin = (255 - t) * BPT + BPT - 1;
+    for (; bin > (255 - t) * BPT; --bin) {
       if (cum + hb[bin] >= (uint32_t)n_sel) break;
       cum += hb[bin];
     }
@@ -2046,24 +2069,45 @@ __global__ void __launch_bounds__(256) ub_thr_kernel(const uint32_t* __restrict_
   }
 }
 
-// Survivors of the filter: documents whose U bin is >= thr[b].  grid (blocks per query, B).  Survivor records are
-// appended in arbitrary order at the query's pool base (S5 orders by (score, doc id) itself).
-__global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict__ U, const uint32_t* __restrict__ thr_b,
-                                                     int hshift, const uint4* __restrict__ cand_meta,
-                                                     const int32_t* __restrict__ n_cand, RoundPlan rp, int round,
-                                                     uint4* __restrict__ surv_meta, int32_t* __restrict__ n_surv,
-                                                     Counters* ctr) {
+// Cut by bound: appends the records of `src` whose bin is in [lo[b], hi[b]) to dst.  grid (blocks per query, B).  Records
+// are appended in arbitrary order (S5 orders by (score, doc id) itself).  Uses:
+//   single-level filter   src = all candidates, U = exact bound, zero_mode 0                      -> survivors
+//   two-level, list 1     src = all candidates, U = hot bound U', lo = thr1, zero_mode 1          -> S1 (the n_sel best by U')
+//   two-level, list 2     the same with lo = thr2, hi = thr1, appended behind list 1             -> S2 (U' >= tau, not in S1)
+//   two-level, final      src = list 1 + list 2, U = exact bound by list position, lo = thr2,
+//                         zero_mode 0 with all_src = all candidates                              -> survivors
+struct CutP {
+  const uint4* src;          // records to test, at src[cand_base[b] + i]
+  const int32_t* n_src_a;    // [B] number of them ...
+  const int32_t* n_src_b;    // [B] ... plus this (NULL = 0)
+  const uint16_t* U;         // bound of record i at U[cand_base[b] + i]
+  const uint32_t* lo;        // [B] keep bin >= lo
+  const uint32_t* hi;        // [B] and bin < hi (NULL: no upper limit)
+  int zero_mode;             // lo[b] == 0 ("filter does not apply"): 0 = keep every record of all_src, 1 = keep none
+  const uint4* all_src;      // zero_mode 0 source: every candidate of the query
+  const int32_t* n_all;
+  uint4* dst;                // appended at dst[cand_base[b] + dst_begin[b] + ...]
+  const int32_t* dst_begin;  // NULL = 0
+  int32_t* n_dst;            // [B] zeroed
+  int hshift;
+  Counters* ctr;             // work counters of the queries the filter skipped (zero_mode 0 only)
+};
+
+__global__ void __launch_bounds__(256) ub_cut_kernel(CutP p, RoundPlan rp, int round) {
   __shared__ int s_wcnt[4], s_base;
   __shared__ unsigned long long s_cnt[2];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (rp.round_of[b] != round) return;
-  const int64_t n = n_cand[b];
+  const uint32_t lo = p.lo[b], hi = p.hi ? p.hi[b] : 0xFFFFFFFFu;
+  const bool all = lo == 0;
+  if (all && p.zero_mode == 1) return;
+  const uint4* src = all ? p.all_src : p.src;
+  const int64_t n = all ? (int64_t)p.n_all[b] : (int64_t)p.n_src_a[b] + (p.n_src_b ? p.n_src_b[b] : 0);
   const int64_t pbase = rp.cand_base[b];
-  const uint32_t thr = thr_b[b];
-  const bool all = thr == 0;
+  const int64_t dbase = pbase + (p.dst_begin ? p.dst_begin[b] : 0);
   if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
-  unsigned long long toks = 0, ucnt = 0;   // work counters of the queries the filter kernel skipped
-  // 8 candidates per thread and step: one append (same-address atomic) and two barriers per 2048 candidates
+  unsigned long long toks = 0, ucnt = 0;
+  // 8 records per thread and step: one append (same-address atomic) and two barriers per 2048 records
   constexpr int PT = 8;
   for (int64_t i0 = (int64_t)blockIdx.x * (256 * PT); i0 < n; i0 += (int64_t)gridDim.x * (256 * PT)) {   // block-uniform trip count
     bool keep[PT];
@@ -2072,15 +2116,20 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
       const int64_t i = i0 + k * 256 + tid;
-      keep[k] = i < n && (all || ((uint32_t)U[pbase + i] >> hshift) >= thr);
-      bal[k] = __ballot(keep[k]);
+      bool kp = i < n;
+      if (kp && !all) {
+        const uint32_t bin = min((uint32_t)p.U[pbase + i] >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
+        kp = bin >= lo && bin < hi;
+      }
+      keep[k] = kp;
+      bal[k] = __ballot(kp);
       wtot += (int)__popcll(bal[k]);
     }
     if (lane == 0) s_wcnt[wave] = wtot;
     __syncthreads();
     if (tid == 0) {
       const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-      s_base = tot ? atomicAdd(&n_surv[b], tot) : 0;
+      s_base = tot ? atomicAdd(&p.n_dst[b], tot) : 0;
     }
     __syncthreads();
     int pos = s_base;
@@ -2088,8 +2137,8 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
       if (keep[k]) {
-        const uint4 m = cand_meta[pbase + i0 + k * 256 + tid];
-        surv_meta[pbase + pos + (int)__popcll(bal[k] & ((1ull << lane) - 1ull))] = m;
+        const uint4 m = src[pbase + i0 + k * 256 + tid];
+        p.dst[dbase + pos + (int)__popcll(bal[k] & ((1ull << lane) - 1ull))] = m;
         if (all) {
           toks += (unsigned long long)(m.w >> 8);
           ucnt += (unsigned long long)m.y;
@@ -2099,7 +2148,7 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
     }
     __syncthreads();
   }
-  if (all) {
+  if (all && p.ctr) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       toks += __shfl_xor(toks, o);
@@ -2111,9 +2160,327 @@ __global__ void __launch_bounds__(256) ub_cut_kernel(const uint16_t* __restrict_
     }
     __syncthreads();
     if (tid == 0 && s_cnt[0]) {
-      atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
-      atomicAdd(&ctr->n_cand_codes, s_cnt[1]);
+      atomicAdd(&p.ctr->n_cand_tokens, s_cnt[0]);
+      atomicAdd(&p.ctr->n_cand_dcodes, s_cnt[1]);
+      atomicAdd(&p.ctr->n_cand_codes, s_cnt[1]);   // these candidates all reach the f32 pass
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S4, first filter level: the HOT bound (round 3).
+// The exact bound U(d) costs one L2 row request per (document, distinct code): 813 M per batch at 10 M documents, and the L2
+// serves ~200-266 G requests/s whatever the row size -- the stage's ceiling.  Most of those rows are noise: a random
+// centroid scores N(0, 1/sqrt(dim)) against every query token.  Per query let M[c] = max_q u[q, c] (hot_prep_kernel) and
+// call the `hot_permille` centroids with the largest M HOT (M[c] > Lambda).  For a cold centroid u[q, c] <= Lambda for
+// every token, so
+//     U'(d) = sum_q max( Lambda, max_{c in codes(d), c hot} u[q, c] )  >=  U(d)
+// and it needs table rows for the document's hot codes only (~5-10 of ~68 at 8-12 % hot).  Whether a code is hot is one
+// bit of a K-bit map held in LDS (8 KB at K = 65536), so the scan of a document's code list issues no L2 row request at
+// all.  U' feeds the three-step cut of np_search.hip: S1 = the n_sel documents with the largest U' get the exact bound,
+// tau = (their n_sel-th largest exact U) - slack is a valid cut (any n_sel documents give a lower bound of the n_sel-th
+// best score), S2 = the other documents with U' >= tau get the exact bound too, and the survivors are the documents of
+// S1 + S2 with exact U >= tau -- a superset of the true top n_sel, like the single-level filter's.  CPU simulation on the
+// metric corpus (tools/sim/s4_hot_sim.py): 80-90 % of the candidates drop out at the first level, none of the exact
+// filter's survivors is lost.
+// Work split as in approx_ub_kernel (one XCD per query, documents claimed DPW at a time).  Per claim a wave (1) stages
+// the claim's code lists into LDS exactly like the exact kernel (one coalesced read per list, a batch of lists in
+// flight), (2) tests every staged code against the bitmap -- the whole wave on one document, ballot / prefix-count
+// compaction of the hot codes to the front of the same LDS row -- and (3) walks the hot codes in lockstep like the
+// exact kernel walks full lists: LPD lanes per 16-B piece of a row, 8 gathers in flight per lane through the
+// bounds-checked buffer descriptor (positions past a hot list issue no request).  Lists longer than the staged window
+// take further passes; the per-byte running maxima carry over.  (First version, measured at 10 M documents: scanning
+// straight from memory four documents at a time was latency-bound, 5.5 ms per batch for 2.9x fewer table rows.)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hot_prep_kernel(const uint8_t* __restrict__ QCU, int64_t K, int64_t KP, int RB,
+                                                       uint8_t* __restrict__ cmaxu /* [B][KP] */,
+                                                       uint32_t* __restrict__ chist /* [B][256] zeroed */) {
+  __shared__ uint32_t s_h[256];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  s_h[tid] = 0;
+  __syncthreads();
+  for (int64_t c = (int64_t)blockIdx.x * 256 + tid; c < KP; c += (int64_t)gridDim.x * 256) {
+    const uint4* row = reinterpret_cast<const uint4*>(QCU + ((int64_t)b * KP + c) * RB);
+    uint32_t m = 0;
+    for (int j = 0; j < RB / 16; ++j) {
+      const uint4 v = row[j];
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = max(m, (w4[e] >> (8 * k)) & 0xFFu);
+    }
+    cmaxu[(int64_t)b * KP + c] = (uint8_t)m;
+    if (c < K) atomicAdd(&s_h[m], 1u);
+  }
+  __syncthreads();
+  if (s_h[tid]) atomicAdd(&chist[(int64_t)b * 256 + tid], s_h[tid]);
+}
+
+// Lambda of every query: the smallest level with at most hot_permille of the centroids above it.  {v in [1, 255] :
+// #(M >= v) <= limit} is an upper interval [v0, 255], Lambda = v0 - 1 = 255 - its size.  One block per query.
+__global__ void __launch_bounds__(256) hot_lam_kernel(const uint32_t* __restrict__ chist, int64_t K, int hot_permille,
+                                                      uint32_t* __restrict__ lam) {
+  __shared__ uint32_t s_h[256];
+  __shared__ uint32_t s_wsum[4];
+  __shared__ int s_ok;
+  const int b = blockIdx.x, v = threadIdx.x, lane = v & 63, wave = v >> 6;
+  if (v == 0) s_ok = 0;
+  uint32_t suf = chist[(int64_t)b * 256 + v];   // -> #(M >= v): suffix sum over the block
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_down((int)suf, o);
+    if (lane + o < 64) suf += t;
+  }
+  if (lane == 0) s_wsum[wave] = suf;
+  __syncthreads();
+  for (int k = wave + 1; k < 4; ++k) suf += s_wsum[k];
+  (void)s_h;
+  const uint64_t limit = (uint64_t)K * (uint64_t)hot_permille / 1000u;
+  const bool ok = v >= 1 && (uint64_t)suf <= limit;
+  const int cnt = (int)__popcll(__ballot(ok));
+  if (lane == 0 && cnt) atomicAdd(&s_ok, cnt);
+  __syncthreads();
+  if (v == 0) lam[b] = (uint32_t)(255 - s_ok);
+}
+
+template <int ROWB, typename CT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) approx_hot_kernel(
+    const uint8_t* __restrict__ QCU, int64_t K, int64_t KP, const uint8_t* __restrict__ cmaxu, const uint32_t* __restrict__ lam_b,
+    const uint4* __restrict__ cand_meta, const int32_t* __restrict__ n_cand, RoundPlan rp, int round, int max_rounds,
+    const CT* __restrict__ codes, const uint32_t* __restrict__ qflag, const int32_t* __restrict__ qoff, int n_sel,
+    uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift, uint32_t* __restrict__ cursor, int32_t* __restrict__ slots,
+    int32_t* __restrict__ ticket, int B, int steal_min, Counters* ctr) {
+  constexpr int LPD = ROWB / 16;   // lanes per document in the walk (one 16-B piece of the row each)
+  constexpr int DPW = 64 / LPD;    // documents per claim
+  constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // codes of one document staged per pass
+  constexpr int CPS = CAP / 32;                     // codes a staging lane loads (half a wave per document)
+  constexpr int CPL = CAP / 64;                     // codes a scanning lane tests (the whole wave on one document)
+  constexpr int RS = CAP + 16 / (int)sizeof(CT);    // row stride: 16 B of padding keeps rows 16-B aligned and off each other's banks
+  extern __shared__ uint32_t s_bits[];   // KP / 32 words: hot centroids of the current query
+  __shared__ uint32_t s_hist[NP_UB_BINS];
+  __shared__ __attribute__((aligned(16))) CT s_codes[4][DPW][RS];
+  __shared__ int64_t s_cl[4][DPW];
+  __shared__ int s_nd[4][DPW];
+  __shared__ int s_hcnt[4][DPW];
+  __shared__ int s_q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & (LPD - 1), grp = lane / LPD;
+  const int half = lane >> 5, hl = lane & 31;
+  const int x = blockIdx.x & 7;
+  if (round >= rp.round_tab[2 * max_rounds]) return;
+  const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
+  unsigned long long toks = 0, ucnt = 0, rows = 0;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (int step = 0;; ++step) {
+    __syncthreads();
+    if (tid == 0)
+      s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
+        int best = -3;
+        int64_t most = steal_min;
+        for (int j = rb; j < re; ++j) {
+          const int b2 = rp.order[j];
+          const int64_t n2 = n_cand[b2];
+          if (qflag[b2] || n2 <= (int64_t)n_sel) continue;
+          const int64_t left = n2 - (int64_t)__hip_atomic_load(&cursor[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (left >= most) {
+            most = left;
+            best = b2;
+          }
+        }
+        return best;
+      });
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(s_q);
+    if (b < 0) break;
+    const int64_t n = n_cand[b];
+    if (qflag[b] || n <= (int64_t)n_sel) continue;   // the cuts keep every candidate of this query
+    const int64_t pbase = rp.cand_base[b];
+    const uint4* metab = cand_meta + pbase;
+    const int Lq = qoff[b + 1] - qoff[b];
+    const uint32_t lam = lam_b[b];   // hot_lam_kernel
+    // ---- hot bitmap: bit c = M[c] > Lambda
+    {
+      const uint8_t* cm = cmaxu + (int64_t)b * KP;
+      for (int64_t w = tid; w < (KP >> 5); w += 256) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(cm + w * 32), v1 = *reinterpret_cast<const uint4*>(cm + w * 32 + 16);
+        const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) bits |= (((w8[e] >> (8 * k)) & 0xFFu) > lam ? 1u : 0u) << (4 * e + k);
+        s_bits[w] = bits;
+      }
+      for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t tb64 = reinterpret_cast<uint64_t>(QCU + (int64_t)b * KP * ROWB);
+    const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb64);
+    const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tb64 >> 32));
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uint64_t)thi << 32) | tlo), 0, (int)(KP * ROWB), 0x00020000);
+    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+    uint32_t inext = 0;
+    if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
+    for (;;) {
+      const int64_t i0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
+      if (i0 >= n) break;
+      if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);   // the next claim travels while this one is processed
+      const int64_t i = i0 + grp;
+      const bool valid = i < n;
+      const uint4 m = metab[valid ? i : n - 1];
+      const int nd = valid ? (int)m.y : 0;
+      if (jl == 0) {
+        s_cl[wave][grp] = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
+        s_nd[wave][grp] = nd;
+        if (valid) {
+          toks += (unsigned long long)(m.w >> 8);
+          ucnt += (unsigned long long)nd;
+        }
+      }
+      int nmax = nd;
+#pragma unroll
+      for (int o = LPD; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+      nmax = __builtin_amdgcn_readfirstlane(nmax);
+      uint32_t st[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) st[k] = 0;
+      for (int p0 = 0; p0 < nmax; p0 += CAP) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();     // s_cl / s_nd written, the previous pass's lists consumed
+        // ---- (1) stage codes [p0, p0 + CAP) of every document of the claim: one coalesced read per list, half a wave per
+        // document, all loads of a batch of documents in flight before the first LDS write (one memory round trip per
+        // batch).  Positions past a list's end hold whatever follows it in memory: the scan below knows the lengths.
+        constexpr int SB = DPW / 2 < 8 ? DPW / 2 : 8;   // staging steps per batch (two documents per step)
+#pragma unroll 1
+        for (int sb = 0; sb < DPW / 2; sb += SB) {
+          uint2 raw[SB];
+#pragma unroll
+          for (int j = 0; j < SB; ++j) {
+            const int sl = 2 * (sb + j) + half;
+            const int nds = s_nd[wave][sl];
+            const CT* cp = codes + s_cl[wave][sl];
+            // clamped to the list's last CPS-aligned group: an aligned 8-byte load, at most CPS - 1 entries past the end
+            const int pos = min(p0 + CPS * hl, max(nds - 1, 0) & ~(CPS - 1));
+            raw[j] = *reinterpret_cast<const uint2*>(cp + pos);
+          }
+#pragma unroll
+          for (int j = 0; j < SB; ++j) {
+            const int sl = 2 * (sb + j) + half;
+            *reinterpret_cast<uint2*>(&s_codes[wave][sl][CPS * hl]) = raw[j];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- (2) scan: the whole wave tests one document's staged codes against the bitmap and compacts the hot ones to
+        // the front of the same row (every code is in a register before the first write)
+#pragma unroll 2
+        for (int sl = 0; sl < DPW; ++sl) {
+          const int cnt = min(max(__builtin_amdgcn_readfirstlane(s_nd[wave][sl]) - p0, 0), CAP);
+          int tot = 0;
+          if (cnt > 0) {
+            uint32_t c[CPL];
+            if constexpr (sizeof(CT) == 2) {
+              const uint32_t w2 = *reinterpret_cast<const uint32_t*>(&s_codes[wave][sl][CPL * lane]);
+              c[0] = w2 & 0xFFFFu;
+              c[1] = w2 >> 16;
+            } else {
+              c[0] = s_codes[wave][sl][lane];
+            }
+            bool h[CPL];
+            unsigned long long bal[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+              h[k] = CPL * lane + k < cnt && ((s_bits[c[k] >> 5] >> (c[k] & 31)) & 1u);
+              bal[k] = __ballot(h[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+              if (h[k]) s_codes[wave][sl][tot + (int)__popcll(bal[k] & lt_mask)] = (CT)c[k];
+              tot += (int)__popcll(bal[k]);
+            }
+          }
+          if (lane == 0) s_hcnt[wave][sl] = tot;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- (3) walk the hot codes in lockstep (LPD lanes per row, 8 gathers in flight per lane; positions past a
+        // document's hot list carry an out-of-range offset: the bounds check answers without a memory request)
+        const int hn = s_hcnt[wave][grp];
+        int hmax = hn;
+#pragma unroll
+        for (int o = LPD; o < 64; o <<= 1) hmax = max(hmax, __shfl_xor(hmax, o));
+        hmax = __builtin_amdgcn_readfirstlane(hmax);
+        if (jl == 0) rows += (unsigned long long)hn;
+        const CT* mine = &s_codes[wave][grp][0];
+        for (int t = 0; t < hmax; t += 8) {
+          uint32_t c[8];
+          if constexpr (sizeof(CT) == 2) {
+            const uint4 cw = *reinterpret_cast<const uint4*>(mine + t);
+            c[0] = cw.x & 0xFFFFu; c[1] = cw.x >> 16; c[2] = cw.y & 0xFFFFu; c[3] = cw.y >> 16;
+            c[4] = cw.z & 0xFFFFu; c[5] = cw.z >> 16; c[6] = cw.w & 0xFFFFu; c[7] = cw.w >> 16;
+          } else {
+            const uint4 ca = *reinterpret_cast<const uint4*>(mine + t), cb = *reinterpret_cast<const uint4*>(mine + t + 4);
+            c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w;
+            c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
+          }
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          uint4 v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t off = (t + k < hn) ? c[k] * (uint32_t)ROWB + (uint32_t)(jl * 16) : 0x7FFFFFF0u;
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)off, 0, 0);
+            v[k] = make_uint4(r.x, r.y, r.z, r.w);
+          }
+          asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) st[4 * j + e] = max(st[4 * j + e], (w4[j] >> (8 * e)) & 0xFFu);
+          }
+        }
+      }
+      uint32_t sum = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += (16 * jl + k < Lq) ? max(st[k], lam) : 0u;   // padding tokens carry no bound
+#pragma unroll
+      for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
+      if (valid && jl == 0) {
+        U[pbase + i] = (uint16_t)sum;
+        atomicAdd(&s_hist[min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
+      }
+      __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next claim
+    }
+    __syncthreads();
+    for (int i = tid; i < NP_UB_BINS; i += 256) {
+      const uint32_t v = s_hist[i];
+      if (v) atomicAdd(&hb[i], v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    toks += __shfl_xor(toks, o);
+    ucnt += __shfl_xor(ucnt, o);
+    rows += __shfl_xor(rows, o);
+  }
+  __shared__ unsigned long long s_cnt[3];
+  __syncthreads();
+  if (tid == 0) s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+  __syncthreads();
+  if (lane == 0 && toks) {
+    atomicAdd(&s_cnt[0], toks);
+    atomicAdd(&s_cnt[1], ucnt);
+    atomicAdd(&s_cnt[2], rows);
+  }
+  __syncthreads();
+  if (tid == 0 && s_cnt[0]) {
+    atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
+    atomicAdd(&ctr->n_cand_dcodes, s_cnt[1]);
+    atomicAdd(&ctr->n_cand_codes, s_cnt[2]);     // table rows gathered
   }
 }
 
@@ -2139,7 +2506,7 @@ template <int DIM>
 __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restrict__ qrows, const int32_t* __restrict__ qoff,
                                                             const float* __restrict__ centroids,
                                                             const uint4* __restrict__ meta, const int32_t* __restrict__ n_list,
-                                                            RoundPlan rp, int round, const uint32_t* __restrict__ codes,
+                                                            RoundPlan rp, int round, CodeArr codes,
                                                             float* __restrict__ approx) {
 #pragma clang fp contract(off)
   constexpr int QS = DIM + 4;   // LDS row stride (floats): conflict-free b128 reads across 32 rows
@@ -2158,7 +2525,7 @@ __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restr
     const bool live = i < n;
     const uint4 m = meta[pbase + (live ? i : 0)];
     const int nd = live ? (int)m.y : 0;
-    const uint32_t* cl = codes + ((int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32));
+    const int64_t cl = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
     float score = 0.f;
     for (int qt = 0; qt < Lq; qt += 32) {
       __syncthreads();
@@ -2174,7 +2541,7 @@ __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restr
         const int j = j0 + half;
         // the two centroid rows of this step, one per half-wave, through LDS
         {
-          const uint32_t c = cl[min(j, nd - 1)];
+          const uint32_t c = codes[cl + max(min(j, nd - 1), 0)];
           const float4* src = reinterpret_cast<const float4*>(centroids + (int64_t)c * DIM);
           if (ql < DIM / 4) *reinterpret_cast<float4*>(&sC[wave][half][4 * ql]) = src[ql];
         }
@@ -2456,7 +2823,7 @@ struct ExactP {
   int LQP;
   const float* centroids;
   const float* wlut;
-  const uint32_t* codes;
+  CodeArr codes;
   const uint8_t* residuals;
   const int64_t* doc_off;
   const uint64_t* sel_keys; // [B][n_sel]
@@ -3297,7 +3664,7 @@ __global__ void __launch_bounds__(256) decompress_kernel(const int64_t* __restri
                                                          int64_t n, int dim, int nbits, int pd,
                                                          const float* __restrict__ centroids,
                                                          const float* __restrict__ wlut,
-                                                         const uint32_t* __restrict__ codes,
+                                                         CodeArr codes,
                                                          const uint8_t* __restrict__ residuals,
                                                          float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

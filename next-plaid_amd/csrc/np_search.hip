@@ -16,7 +16,7 @@ namespace np {
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, n_list2, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
-      subset_bits, elig, misc, cut;
+      subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
@@ -25,7 +25,7 @@ struct Workspace {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
                      &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
-                     &cut};
+                     &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2};
     for (DevBuf* b : all) b->release();
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
@@ -170,11 +170,11 @@ static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_sear
 
 // ---- workspace plan: one expression set for slicing AND for the reserve() calls ---------------------------------
 // Per-query scratch that scales with the batch (score table, probe bitmaps, doc bitmap, selection) and the
-// candidate pool (NP_POOL_ENTRY bytes per entry: doc id + 16-B record + approximate score + u16 upper bound + 16-B
-// survivor record), which is sized by the
+// candidate pool (NP_POOL_ENTRY bytes per entry: doc id + 16-B record + approximate score + two u16 bounds + 16-B list
+// record of the two-level filter + 16-B survivor record), which is sized by the
 // budget, not by n_docs: B x n_docs entries only when that fits workspace_bytes, otherwise what is left of the
 // budget after the per-query scratch (never less than 2 x n_docs entries, one query's worst case twice).
-#define NP_POOL_ENTRY 42
+#define NP_POOL_ENTRY 60
 struct WsPlan {
   int S = 1;            // queries per slice
   int64_t pool = 1;     // candidate-pool entries
@@ -185,7 +185,8 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int to
   const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
   const int64_t nchunks = (NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS;
   return KP * LQP * 6                      // QCT (f32) + QCU (u8, rows padded to a power of two)
-         + NP_UB_BINS * 4
+         + KP + 1024                       // per-centroid maxima of the u8 table + their histogram (hot level)
+         + NP_UB_BINS * 8
          + G * LQP * 4 + G * 4             // gmax, cellbits
          + KP * 8                          // cells_tmp, cells
          + (int64_t)LQP * 4                // tauq
@@ -292,7 +293,7 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
     // streamed form (approx_stream_kernel): u16 code-in-slice needs a phase's centroid range <= 65536
 #define NP_LAUNCH_APPROX_S(LPR)                                                                                       \
   approx_stream_kernel<LPR><<<8 * nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round,          \
-                                                     max_rounds, ix->d_ucodes, ix->T, ix->d_useg, w.approx.as<float>(), \
+                                                     max_rounds, ix->ucodes(), ix->n_ucodes, ix->d_useg, w.approx.as<float>(), \
                                                      t.s4_mode - 5, slice_w, ctr)
     if (LQP <= 32) NP_LAUNCH_APPROX_S(8);
     else if (LQP <= 64) NP_LAUNCH_APPROX_S(16);
@@ -302,7 +303,7 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
   } else if (t.s4_mode > 0 && ix->sliced_ok && B >= t.s4_minb) {
 #define NP_LAUNCH_APPROX_X(LPR, SWZ)                                                                                  \
   approx_xcd_kernel<LPR, SWZ><<<8 * nbx, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round,        \
-                                                       max_rounds, ix->d_ucodes, ix->T, ix->d_useg,                   \
+                                                       max_rounds, ix->ucodes(), ix->n_ucodes, ix->d_useg,         \
                                                        w.approx.as<float>(), s4_p - 1, ctr)
     if (LQP <= 32) {
       if (t.s4_swz) NP_LAUNCH_APPROX_X(8, true);
@@ -315,7 +316,7 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
     const unsigned grid = 768;
 #define NP_LAUNCH_APPROX(LPR)                                                                                          \
   approx_kernel<LPR><<<grid, 256, 0, st>>>(w.QCT.as<float>(), KP, LQP, d_qoff, meta, n, rp, round, max_rounds,         \
-                                           ix->d_ucodes, w.approx.as<float>(), ctr)
+                                           ix->ucodes(), w.approx.as<float>(), ctr)
     if (LQP <= 32) NP_LAUNCH_APPROX(8);
     else if (LQP <= 64) NP_LAUNCH_APPROX(16);
     else if (LQP <= 128) NP_LAUNCH_APPROX(32);
@@ -329,10 +330,10 @@ static void launch_matvec(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
                           const uint4* meta, const int32_t* n, const RoundPlan& rp, int round) {
   const dim3 grid(64, (unsigned)B);
   switch (ix->dim) {
-    case 32: approx_matvec_kernel<32><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
-    case 64: approx_matvec_kernel<64><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
-    case 96: approx_matvec_kernel<96><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
-    default: approx_matvec_kernel<128><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->d_ucodes, w.approx.as<float>()); break;
+    case 32: approx_matvec_kernel<32><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
+    case 64: approx_matvec_kernel<64><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
+    case 96: approx_matvec_kernel<96><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
+    default: approx_matvec_kernel<128><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
   }
 }
 
@@ -393,13 +394,15 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.round_tab.reserve((size_t)(2 * max_rounds + 1) * 4));
   NP_TRY(w.q_order.reserve((size_t)B * 4));
   NP_TRY(w.n_list2.reserve((size_t)B * 4));
-  NP_TRY(w.xcd_slots.reserve((size_t)max_rounds * (8 * (B + 1) + 1) * 4));   // hand-out slots + ticket per round
   // S4 upper-bound filter (np_kernels.h): off for debug traces (every candidate keeps its exact score) and for
   // indices with a non-finite centroid value
   const bool use_filter = ix->tune.s4_filter && ix->filter_ok && !cs->trace && cs->n_sel > 0 && ix->T > 0;
   const int RB = LQP <= 32 ? 32 : (LQP <= 64 ? 64 : (LQP <= 128 ? 128 : 256));   // u8 table row bytes
   NP_TRY(w.qinv.reserve((size_t)B * 4));
   NP_TRY(w.qflag.reserve((size_t)B * 4));
+  // two-level filter (np_kernels.h, "S4, first filter level"): the hot bitmap of a query lives in LDS (K / 8 bytes)
+  const bool two_level = use_filter && ix->tune.s4_hot > 0 && KP / 8 <= 64 * 1024 && KP * RB < ((int64_t)1 << 31);
+  const size_t slot_words = (size_t)(8 * (B + 1) + 1);   // hand-out slots + ticket of one filter launch
   if (use_filter) {
     NP_TRY(w.QCU.reserve((size_t)B * KP * RB));
     NP_TRY(w.ub.reserve((size_t)pool * 2));
@@ -407,7 +410,18 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     NP_TRY(w.surv_meta.reserve((size_t)pool * 16));
     NP_TRY(w.n_surv.reserve((size_t)B * 4));
     NP_TRY(w.ub_thr.reserve((size_t)B * 4));
-    NP_TRY(w.ub_cursor.reserve((size_t)B * 4));
+    NP_TRY(w.ub_cursor.reserve((size_t)3 * B * 4));
+    NP_TRY(w.xcd_slots.reserve((size_t)max_rounds * 3 * slot_words * 4));
+  }
+  if (two_level) {
+    NP_TRY(w.cmaxu.reserve((size_t)B * KP));
+    NP_TRY(w.chist.reserve((size_t)B * 256 * 4));
+    NP_TRY(w.ub2.reserve((size_t)pool * 2));
+    NP_TRY(w.ub_hist2.reserve((size_t)B * NP_UB_BINS * 4));
+    NP_TRY(w.ub_thr2.reserve((size_t)2 * B * 4));   // [B] tau bins, [B] Lambda
+    NP_TRY(w.list_meta.reserve((size_t)pool * 16));
+    NP_TRY(w.n_l1.reserve((size_t)B * 4));
+    NP_TRY(w.n_l2.reserve((size_t)B * 4));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -443,8 +457,14 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     if (use_filter && B > 0) {
       add(w.ub_hist.p, (size_t)B * NP_UB_BINS * 4, 0);
       add(w.n_surv.p, (size_t)B * 4, 0);
-      add(w.ub_cursor.p, (size_t)B * 4, 0);
-      add(w.xcd_slots.p, (size_t)max_rounds * (8 * (B + 1) + 1) * 4, 0xFFFFFFFFu);   // slots and tickets of every round: -1
+      add(w.ub_cursor.p, (size_t)3 * B * 4, 0);
+      add(w.xcd_slots.p, (size_t)max_rounds * 3 * slot_words * 4, 0xFFFFFFFFu);   // slots and tickets of every launch: -1
+    }
+    if (two_level && B > 0) {
+      add(w.chist.p, (size_t)B * 256 * 4, 0);
+      add(w.ub_hist2.p, (size_t)B * NP_UB_BINS * 4, 0);
+      add(w.n_l1.p, (size_t)B * 4, 0);
+      add(w.n_l2.p, (size_t)B * 4, 0);
     }
     if (cl.n > 0) clear_regions_kernel<<<128, 256, 0, st>>>(cl);
   }
@@ -465,6 +485,11 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       default: launch_gemm<128>(st, ix, w.Qt.as<float>(), B, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, RB, qinv, d_qoff); break;
     }
   }
+  if (two_level) {   // per-centroid maxima of the u8 table, their histogram, the hot level's Lambda
+    hot_prep_kernel<<<dim3((unsigned)std::min<int64_t>((KP + 255) / 256, 64), B), 256, 0, st>>>(
+        w.QCU.as<uint8_t>(), ix->K, KP, RB, w.cmaxu.as<uint8_t>(), w.chist.as<uint32_t>());
+    hot_lam_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.ub_thr2.as<uint32_t>() + B);
+  }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[1], st));
 
   // ---- subset pre-filter (search.rs:350-382); the batched path only filters candidates (:542-545)
@@ -481,7 +506,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     // (np_hip_subset_eligible + one small all-gather) and hands the global one in
     const bool local_elig = use_elig && !cs->elig_global;
     subset_kernel<<<(unsigned)((subset_len + 3) / 4), 256, 0, st>>>(
-        d_subset, subset_len, ix->doc_begin, ix->n_docs, ix->d_doc_offsets, ix->d_codes, w.subset_bits.as<uint32_t>(),
+        d_subset, subset_len, ix->doc_begin, ix->n_docs, ix->d_doc_offsets, ix->codes(), w.subset_bits.as<uint32_t>(),
         local_elig ? w.elig.as<uint32_t>() : nullptr);
     if (use_elig) {
       elig_bits = cs->elig_global ? cs->elig_global : w.elig.as<uint32_t>();
@@ -585,17 +610,22 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
                                                      ix->d_doc_meta, w.cand_meta.as<uint4>());
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
     if (use_filter) {
-      const int hshift = RB == 32 ? 0 : (RB == 64 ? 1 : (RB == 128 ? 2 : 3));   // U <= 255 * LQP fits NP_UB_BINS << hshift
+      const int hshift = RB == 32 ? 2 : (RB == 64 ? 3 : (RB == 128 ? 4 : 5));   // U <= 255 * RB fits NP_UB_BINS << hshift
       const unsigned nbx = (unsigned)ix->tune.ub_nbx;
-      // query hand-out state of this launch: slots = -1 (empty), ticket = 0
-      int32_t* xslots = w.xcd_slots.as<int32_t>() + (size_t)r * (8 * (B + 1) + 1);   // cleared to -1 with the call's regions
-      int32_t* xticket = xslots + 8 * (B + 1);
-#define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                    \
-  approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cand_meta.as<uint4>(),            \
-                                                          w.n_cand.as<int32_t>(), rp, r, max_rounds, ix->d_ucodes,     \
-                                                          w.qflag.as<uint32_t>(), cs->n_sel, w.ub.as<uint16_t>(),       \
-                                                          w.ub_hist.as<uint32_t>(), hshift, w.ub_cursor.as<uint32_t>(), \
-                                                          xslots, xticket, B, ix->tune.ub_steal, w.ctr.as<Counters>())
+      // hand-out state of the (up to three) filter launches of this round: slots = -1 (empty), ticket = -1; cursors 0
+      auto xslots = [&](int lvl) { return w.xcd_slots.as<int32_t>() + ((size_t)r * 3 + lvl) * slot_words; };
+      auto xcursor = [&](int lvl) { return w.ub_cursor.as<uint32_t>() + (size_t)lvl * B; };
+      const bool oob = ix->tune.ub_nt == 2 && KP * RB < ((int64_t)1 << 30);   // the table behind a 32-bit buffer offset
+      // exact u8 bound of the records meta[begin[b] .. begin[b] + count[b]) -> U, histogram (optional)
+      auto launch_ub = [&](int lvl, const uint4* meta, const int32_t* begin, const int32_t* count, uint16_t* U, uint32_t* hist,
+                           int count_tokens) {
+        int32_t* sl = xslots(lvl);
+        int32_t* tk = sl + 8 * (B + 1);
+#define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                        \
+  approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(), \
+                                                          rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), \
+                                                          cs->n_sel, U, hist, hshift, xcursor(lvl), sl, tk, B,              \
+                                                          ix->tune.ub_steal, w.ctr.as<Counters>(), count_tokens)
 #define NP_LAUNCH_UB_RB(CT, NT)                 \
   do {                                          \
     if (RB == 32) NP_LAUNCH_UB(32, CT, NT);     \
@@ -603,25 +633,106 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     else if (RB == 128) NP_LAUNCH_UB(128, CT, NT); \
     else NP_LAUNCH_UB(256, CT, NT);             \
   } while (0)
-      const bool oob = ix->tune.ub_nt == 2 && KP * RB < ((int64_t)1 << 30);   // the table behind a 32-bit buffer offset
-      if (ix->K <= 65536) {
-        if (oob) NP_LAUNCH_UB_RB(uint16_t, 2);
-        else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint16_t, 1);
-        else NP_LAUNCH_UB_RB(uint16_t, 0);
-      } else {
-        if (oob) NP_LAUNCH_UB_RB(uint32_t, 2);
-        else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint32_t, 1);
-        else NP_LAUNCH_UB_RB(uint32_t, 0);
-      }
+        if (!ix->code_wide) {
+          if (oob) NP_LAUNCH_UB_RB(uint16_t, 2);
+          else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint16_t, 1);
+          else NP_LAUNCH_UB_RB(uint16_t, 0);
+        } else {
+          if (oob) NP_LAUNCH_UB_RB(uint32_t, 2);
+          else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint32_t, 1);
+          else NP_LAUNCH_UB_RB(uint32_t, 0);
+        }
 #undef NP_LAUNCH_UB_RB
 #undef NP_LAUNCH_UB
+      };
       const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
       // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
-      ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, LQP + 2 + (batched ? 1 : 0), cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
-                                       w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
-      ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(w.ub.as<uint16_t>(), w.ub_thr.as<uint32_t>(), hshift,
-                                                   w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r,
-                                                   w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), w.ctr.as<Counters>());
+      const int slack = LQP + 2 + (batched ? 1 : 0);
+      CutP cp{};
+      cp.hshift = hshift;
+      cp.all_src = w.cand_meta.as<uint4>();
+      cp.n_all = w.n_cand.as<int32_t>();
+      if (!two_level) {
+        launch_ub(0, w.cand_meta.as<uint4>(), nullptr, w.n_cand.as<int32_t>(), w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), 1);
+        ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, slack, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
+                                         w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
+        cp.src = w.cand_meta.as<uint4>();
+        cp.n_src_a = w.n_cand.as<int32_t>();
+        cp.U = w.ub.as<uint16_t>();
+        cp.lo = w.ub_thr.as<uint32_t>();
+        cp.zero_mode = 0;
+        cp.dst = w.surv_meta.as<uint4>();
+        cp.n_dst = w.n_surv.as<int32_t>();
+        cp.ctr = w.ctr.as<Counters>();
+        ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(cp, rp, r);
+      } else {
+        // level 1: the hot bound U' of every candidate
+        {
+          int32_t* sl = xslots(0);
+          const size_t dyn = (size_t)(KP / 8);
+#define NP_LAUNCH_HOT(ROWB, CT)                                                                                          \
+  do {                                                                                                                   \
+    if (dyn > 16 * 1024)                                                                                                 \
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hot_kernel<ROWB, CT>),                             \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                                 \
+    approx_hot_kernel<ROWB, CT><<<8 * nbx, 256, dyn, st>>>(w.QCU.as<uint8_t>(), ix->K, KP, w.cmaxu.as<uint8_t>(),         \
+                                                           w.ub_thr2.as<uint32_t>() + B, w.cand_meta.as<uint4>(),              \
+                                                           w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, \
+                                                           w.qflag.as<uint32_t>(), d_qoff, cs->n_sel, w.ub.as<uint16_t>(),  \
+                                                           w.ub_hist.as<uint32_t>(), hshift, xcursor(0), sl, sl + 8 * (B + 1), \
+                                                           B, ix->tune.ub_steal, w.ctr.as<Counters>());                    \
+  } while (0)
+#define NP_LAUNCH_HOT_RB(CT)                    \
+  do {                                          \
+    if (RB == 32) NP_LAUNCH_HOT(32, CT);        \
+    else if (RB == 64) NP_LAUNCH_HOT(64, CT);   \
+    else if (RB == 128) NP_LAUNCH_HOT(128, CT); \
+    else NP_LAUNCH_HOT(256, CT);                \
+  } while (0)
+          if (!ix->code_wide) NP_LAUNCH_HOT_RB(uint16_t);
+          else NP_LAUNCH_HOT_RB(uint32_t);
+#undef NP_LAUNCH_HOT_RB
+#undef NP_LAUNCH_HOT
+        }
+        // S1 = the n_sel documents with the largest U' (whole bins): exact bound -> tau
+        ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, 0, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
+                                         w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
+        cp.src = w.cand_meta.as<uint4>();
+        cp.n_src_a = w.n_cand.as<int32_t>();
+        cp.U = w.ub.as<uint16_t>();
+        cp.lo = w.ub_thr.as<uint32_t>();
+        cp.zero_mode = 1;
+        cp.dst = w.list_meta.as<uint4>();
+        cp.n_dst = w.n_l1.as<int32_t>();
+        ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(cp, rp, r);
+        launch_ub(1, w.list_meta.as<uint4>(), nullptr, w.n_l1.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0);
+        ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist2.as<uint32_t>(), hshift, slack, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
+                                         w.qflag.as<uint32_t>(), w.ub_thr2.as<uint32_t>());
+        // S2 = the other documents with U' >= tau: exact bound too (appended behind S1)
+        cp.lo = w.ub_thr2.as<uint32_t>();
+        cp.hi = w.ub_thr.as<uint32_t>();
+        cp.dst_begin = w.n_l1.as<int32_t>();
+        cp.n_dst = w.n_l2.as<int32_t>();
+        ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(cp, rp, r);
+        launch_ub(2, w.list_meta.as<uint4>(), w.n_l1.as<int32_t>(), w.n_l2.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0);
+        // every document with U' >= tau now has its exact bound in the histogram: the cut over S1 + S2 is the single-level
+        // filter's cut (the n_sel-th largest exact U of ALL candidates lies in S1 + S2), tau can only rise
+        ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist2.as<uint32_t>(), hshift, slack, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
+                                         w.qflag.as<uint32_t>(), w.ub_thr2.as<uint32_t>());
+        // survivors: the documents of S1 + S2 whose exact bound reaches tau (every candidate where the filter does not apply)
+        cp.src = w.list_meta.as<uint4>();
+        cp.n_src_a = w.n_l1.as<int32_t>();
+        cp.n_src_b = w.n_l2.as<int32_t>();
+        cp.U = w.ub2.as<uint16_t>();
+        cp.lo = w.ub_thr2.as<uint32_t>();
+        cp.hi = nullptr;
+        cp.zero_mode = 0;
+        cp.dst = w.surv_meta.as<uint4>();
+        cp.dst_begin = nullptr;
+        cp.n_dst = w.n_surv.as<int32_t>();
+        cp.ctr = w.ctr.as<Counters>();
+        ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(cp, rp, r);
+      }
       // exact f32 approximate scores of the survivors only
       launch_approx(st, ix, w, d_qoff, B, LQP, w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), rp, r, max_rounds, nullptr);
       sp.cand = reinterpret_cast<const uint32_t*>(w.surv_meta.p);
@@ -682,7 +793,7 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.LQP = cs->LQP;
     ep.centroids = ix->d_centroids;
     ep.wlut = ix->d_wlut;
-    ep.codes = ix->d_codes;
+    ep.codes = ix->codes();
     ep.residuals = ix->d_residuals;
     ep.doc_off = ix->d_doc_offsets;
     ep.sel_keys = w.sel_keys.as<uint64_t>();
@@ -908,6 +1019,8 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
       acc.n_exact_tokens += (int64_t)h_ctr->n_exact_tokens;
       acc.n_cand_codes += (int64_t)h_ctr->n_cand_codes;
       acc.n_survivors += (int64_t)h_ctr->n_survivors;
+      acc.n_cand_dcodes += (int64_t)(h_ctr->n_cand_dcodes ? h_ctr->n_cand_dcodes : h_ctr->n_cand_codes);
+      acc.n_level2 += (int64_t)h_ctr->n_level2;
       acc.n_rounds = std::max(acc.n_rounds, (int32_t)h_ctr->n_rounds);
     }
   }
@@ -1036,7 +1149,7 @@ int np_hip_subset_eligible(const np_index* ix, const int64_t* d_subset, int64_t 
   NP_HIP(hipMemsetAsync(d_elig_bits, 0, (size_t)(ix->KP / 32) * 4, st));
   if (subset_len > 0)
     subset_kernel<<<(unsigned)((subset_len + 3) / 4), 256, 0, st>>>(d_subset, subset_len, ix->doc_begin, ix->n_docs,
-                                                                     ix->d_doc_offsets, ix->d_codes, nullptr, d_elig_bits);
+                                                                     ix->d_doc_offsets, ix->codes(), nullptr, d_elig_bits);
   NP_HIP(hipGetLastError());
   return NP_OK;
 }
@@ -1164,7 +1277,7 @@ int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int6
     decompress_kernel<<<(unsigned)((toks.size() + 3) / 4), 256>>>(d_tok, d_tok + toks.size(),
                                                                   ix->tok_sorted ? ix->d_tok_pos : nullptr,
                                                                   (int64_t)toks.size(), ix->dim, ix->nbits, ix->pd,
-                                                                  ix->d_centroids, ix->d_wlut, ix->d_codes, ix->d_residuals,
+                                                                  ix->d_centroids, ix->d_wlut, ix->codes(), ix->d_residuals,
                                                                   d_out);
     e = hipMemcpy(out_embeddings, d_out, toks.size() * (size_t)ix->dim * 4, hipMemcpyDeviceToHost);
   }

@@ -107,3 +107,32 @@ def test_production_path_selects_the_oracles_set(big):
     for i, (g, o) in enumerate(zip(got, ref)):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} default q{i}")
         assert g.passage_ids[0] == src[i]
+
+
+def test_colgrep_window_and_encoder_query_length(big):
+    """The two caller defaults the 32-token / 4096 headline does not exercise: ColGREP re-ranks n_full_scores = 8192
+    candidates (colgrep/src/index/mod.rs:771-777: n_sel = 2048) and the ONNX encoder pads queries to 48 tokens
+    (next-plaid-onnx/src/lib.rs:628-630: two 32-token tiles, 64-byte rows of the u8 table).  Stage traces bit-equal, the
+    selected 2048-document set equal to the oracle's through the production (filtered) path."""
+    name, spec, hx, ox, qs, src, cbs = big
+    cen = ox.centroids if hasattr(ox, "centroids") else None
+    q48, src48 = synth.make_queries(spec, 12, n_tokens=48, cen=synth.centroids(spec) if cen is None else cen, first_query=100)
+    p = P(n_full_scores=8192, top_k=10, n_ivf_probe=8, centroid_score_threshold=0.4, centroid_batch_size=cbs)
+    for qi in range(2):
+        trace_equal(hx, ox, q48[qi], p, f"{name} Lq=48 nfs=8192 q{qi}")
+    for nprobe, thr in ((32, None), (8, 0.4)):
+        p = P(n_full_scores=8192, top_k=2048, n_ivf_probe=nprobe, centroid_score_threshold=thr, centroid_batch_size=cbs)
+        got = hx.search_batch(q48, p)
+        st = dict(hx.last_stats)
+        ref = ox.search_batch(q48, to_oracle_params(p))
+        for i, (g, o) in enumerate(zip(got, ref)):
+            assert set(g.passage_ids.tolist()) == set(o.passage_ids.tolist()), f"{name} Lq=48 nprobe={nprobe} q{i}: selected set"
+            assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} Lq=48 nprobe={nprobe} q{i}")
+            assert g.passage_ids[0] == src48[i]
+        if thr is None:
+            assert st["n_candidates"] > 12 * 2048 and st["n_survivors"] < st["n_candidates"], st   # the filter ran at n_sel = 2048
+    # mixed batch: 32- and 48-token queries share the 64-token tile layout of the longest
+    mixed = [qs[0], q48[0], qs[1][:5], q48[1]]
+    p = P(n_full_scores=8192, top_k=10, n_ivf_probe=32, centroid_score_threshold=0.4, centroid_batch_size=cbs)
+    for g, o in zip(hx.search_batch(mixed, p), ox.search_batch(mixed, to_oracle_params(p))):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} mixed lengths")

@@ -90,7 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 100)):
         hx.tune(k, v)
 
 
@@ -284,6 +284,44 @@ def test_s4_filter_preserves_selection(mid, tuned):
                 assert st1["n_survivors"] < st1["n_candidates"] // 2, st1
             surv.add(st1["n_survivors"])
         assert len(surv) == 1, surv       # the integer bounds U(d) do not depend on the load flavour
+    orc = ox.search_batch(batch[:8], to_oracle_params(p))
+    for g, o in zip(got[:8], orc):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
+
+
+def test_s4_two_level_filter_preserves_selection(mid, tuned):
+    """Round 3: a HOT bound (LDS bitmap of the query's hot centroids, table rows only for a document's hot codes) runs in
+    front of the exact u8 bound.  Whatever share of the centroids is hot (s4_hot per-mille; 0 = the single-level filter),
+    the selected documents, their order and their exact scores are those of the unfiltered path, bit for bit -- plain,
+    ragged-length and non-finite queries -- and the first level must actually spare work: fewer table rows gathered than
+    the single-level filter needs, and only part of the candidates reach the exact bound."""
+    spec, a, ox, hx, qs, src = mid
+    batch = list(qs[:24]) + [qs[30][:7], qs[31][:1]]
+    bad = qs[32].copy()
+    bad[3, 5] = np.nan
+    batch.append(bad)
+    for nfs, nprobe, thr in ((512, 32, None), (2048, 16, 0.4), (64, 64, None)):
+        p = P(n_full_scores=nfs, top_k=max(nfs // 4, 1), n_ivf_probe=nprobe, centroid_score_threshold=thr)
+        hx.tune("s4_filter", 0)
+        ref = hx.search_batch(batch, p)
+        hx.tune("s4_filter", 1)
+        rows = {}
+        for hot in (0, 10, 100, 300, 500):
+            hx.tune("s4_hot", hot)
+            got = hx.search_batch(batch, p)
+            st = dict(hx.last_stats)
+            for i, (g, r) in enumerate(zip(got, ref)):
+                assert np.array_equal(g.passage_ids, r.passage_ids), f"nfs={nfs} hot={hot} q{i}: selected set / order changed"
+                assert np.array_equal(g.scores, r.scores), f"nfs={nfs} hot={hot} q{i}"
+            assert 0 < st["n_survivors"] <= st["n_candidates"]
+            assert st["n_cand_dcodes"] > 0 and st["n_cand_tokens"] >= st["n_cand_dcodes"]
+            rows[hot] = st["n_cand_codes"]
+            if hot == 0:
+                assert st["n_level2"] == 0 and st["n_cand_codes"] <= st["n_cand_dcodes"]
+            elif nfs == 512:
+                assert 0 < st["n_level2"] < st["n_candidates"], st
+        if nfs == 512:
+            assert rows[100] < rows[0], rows        # the hot level gathers fewer table rows than the exact bound alone
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got[:8], orc):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)

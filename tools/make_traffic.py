@@ -22,6 +22,7 @@ STAGE = {
     "mark_slices_kernel": "candidates(S3)", "mark_candidates_kernel": "candidates(S3)", "count_chunks_kernel": "candidates(S3)",
     "plan_rounds_kernel": "candidates(S3)", "compact_kernel": "candidates(S3)",
     "approx_ub_kernel": "approx(S4)", "ub_thr_kernel": "approx(S4)", "ub_cut_kernel": "approx(S4)",
+    "approx_hot_kernel": "approx(S4)", "hot_prep_kernel": "qc_gemm(S1)",
     "approx_xcd_kernel": "approx(S4)", "approx_kernel": "approx(S4)", "approx_stream_kernel": "approx(S4)",
     "approx_matvec_kernel": "approx(S4)", "gcut_kernel": "approx(S4)",
     "select_kernel": "select(S5)",
@@ -54,6 +55,16 @@ def main():
                 res[STAGE[k]] += mult * v * 1024.0 / nb
     j = {k: int(v) for k, v in res.items()}
     j["docs_per_gpu"] = docs
+    # the counters are valid for ONE build of the kernels: bench.py drops them when the sources differ
+    try:
+        import subprocess
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+        sys.path.insert(0, root)
+        import bench
+        j["kernels_sha"] = bench.kernels_sha()
+        j["commit"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception as e:   # noqa: BLE001
+        j["kernels_sha"], j["commit"] = None, None
     j["per_kernel"] = per_kernel
     j["_note"] = ("HBM-side bytes per batch = (2*FETCH_SIZE + WRITE_SIZE) KiB over all dispatches of the stage's kernels / batches, "
                   "separate rocprofv3 --pmc passes of the default bench command; FETCH_SIZE doubled per MI355X_MICROARCH.md "
