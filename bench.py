@@ -76,6 +76,10 @@ def parse():
                     help="run the sharded RCCL protocol even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--dist-impl", choices=["c", "torch"], default="c",
                     help="sharded protocol through np_hip_search_batch_sharded (RCCL below the C ABI) or the torch.distributed harness")
+    ap.add_argument("--shards", type=int, default=0,
+                    help="document shards of the corpus (0 = one per rank, the north_star layout).  With S < N ranks the job runs "
+                         "N/S REPLICAS of an S-way sharded index: rank r holds shard r %% S in replica group r // S, the groups "
+                         "answer DIFFERENT batches concurrently (S = 1: every GPU holds the whole index, no collective at all)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin (each step = one full batch pass; the "
                          "small launch-bound kernels of one batch overlap the memory-bound ones of the next)")
@@ -123,7 +127,13 @@ def main():
         raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or a.force_dist
+    n_shards = a.shards if a.shards > 0 else world
+    if world % n_shards:
+        raise SystemExit(f"--shards {n_shards} does not divide the {world} ranks")
+    n_repl = world // n_shards
+    shard, repl = rank % n_shards, rank // n_shards      # replica group `repl` = ranks [repl * S, (repl + 1) * S)
+    use_dist = world > 1 or a.force_dist                 # process group: timing barrier / max-over-ranks, id exchange
+    use_shards = n_shards > 1 or a.force_dist            # the sharded search protocol (RCCL all-gathers inside a replica group)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -141,7 +151,7 @@ def main():
     spec = synth.SynthSpec(num_docs=a.docs, num_centroids=a.centroids, dim=dim, nbits=a.nbits,
                            doc_len_min=len_min, doc_len_max=a.doc_len, seed=1236, **gen)
     cen = synth.centroids(spec)
-    opts = dict(device=local_rank, shard_rank=rank, shard_count=world, max_batch=a.batch, n_contexts=max(1, a.streams))
+    opts = dict(device=local_rank, shard_rank=shard, shard_count=n_shards, max_batch=a.batch, n_contexts=max(1, a.streams))
     if a.workspace_gib > 0:
         opts["workspace_bytes"] = int(a.workspace_gib * (1 << 30))
     t0 = time.time()
@@ -171,39 +181,49 @@ def main():
     L = api.lib()
     cp = prm._c()
 
-    if use_dist and a.dist_impl == "c":
+    def qbatch(i):   # replica groups walk the query batches at different offsets: different batches at the same time
+        return (i + repl) % a.query_batches
+
+    if use_shards and a.dist_impl == "c":
         # the whole protocol below the C ABI (np_hip_search_batch_sharded, RCCL all-gathers issued by the library on
         # the call's stream): one communicator per stream so the collectives of batch i overlap the kernels of batch
         # i+1; rank 0's ncclUniqueId reaches the other ranks through a torch.distributed broadcast
         from next_plaid_amd.dist import CShardedSearcher, ShardComm
 
-        def exchange(b):
+        grp = None
+        if use_dist and n_repl > 1:   # new_group is collective over ALL ranks: every rank creates every replica group
+            grps = [dist.new_group(ranks=list(range(g * n_shards, (g + 1) * n_shards))) for g in range(n_repl)]
+            grp = grps[repl]
+
+        def exchange(b):              # rank 0 of the replica group draws the id, the group's other ranks receive it
             obj = [b]
-            dist.broadcast_object_list(obj, src=0)
+            dist.broadcast_object_list(obj, src=repl * n_shards, group=grp)
             return obj[0]
-        comms = [ShardComm(ix, rank, world, exchange=exchange if world > 1 else None) for _ in range(nstr)]
+        comms = [ShardComm(ix, shard, n_shards, exchange=exchange if n_shards > 1 else None) for _ in range(nstr)]
         sss = [CShardedSearcher(ix, comms[s], stream=streams[s]) for s in range(nstr)]
         ss = sss[0]
 
         def step(i):
             s = i % nstr
-            return sss[s].search_batch_device(dq[i % a.query_batches], doff, off, prm, out=(o_ids[s], o_sc[s], o_cnt[s]))
-    elif use_dist:
+            return sss[s].search_batch_device(dq[qbatch(i)], doff, off, prm, out=(o_ids[s], o_sc[s], o_cnt[s]))
+    elif use_shards:
         # torch.distributed harness of the same protocol (dist.py): one searcher per stream, each with its own process
         # group (= its own RCCL communicator); every rank issues the same round-robin order
         from next_plaid_amd.dist import HipShardBackend, ShardedSearcher
+        if n_repl > 1:
+            raise SystemExit("--dist-impl torch runs one replica group only (use the default C implementation with --shards)")
         groups = [dist.new_group(ranks=list(range(world))) for _ in range(nstr)]
         sss = [ShardedSearcher([HipShardBackend(ix, stream=streams[s])], use_dist=True, group=groups[s])
                for s in range(nstr)]
         ss = sss[0]
 
         def step(i):
-            return sss[i % nstr].search_batch_device(dq[i % a.query_batches], doff, off, prm)
+            return sss[i % nstr].search_batch_device(dq[qbatch(i)], doff, off, prm)
     else:
         def step(i):
             s = i % nstr
             api._check(L.np_hip_search_batch_device(
-                ix._h, C.c_void_p(dq[i % a.query_batches].data_ptr()), C.c_void_p(doff.data_ptr()),
+                ix._h, C.c_void_p(dq[qbatch(i)].data_ptr()), C.c_void_p(doff.data_ptr()),
                 off.ctypes.data_as(C.c_void_p), a.batch, dim, C.byref(cp), None, -1, C.c_void_p(o_ids[s].data_ptr()),
                 C.c_void_p(o_sc[s].data_ptr()), C.c_void_p(o_cnt[s].data_ptr()), C.c_void_p(streams[s].cuda_stream)))
             return o_ids[s], o_sc[s], o_cnt[s]
@@ -230,7 +250,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    qps = a.batch * a.steps / dt
+    qps = a.batch * a.steps * n_repl / dt      # every replica group answered `steps` batches of its own in that time
 
     # ---- p50 latency of one batch (per-step synchronisation; not part of `value`) ---------------------------------------
     lat = []
@@ -336,7 +356,7 @@ def main():
             if a.parity_queries > 0:
                 npq = min(a.parity_queries, nq)
                 ref = ox.search_batch(qs[:npq], po)
-                got = ss.search_batch(qs[:npq], prm) if (use_dist and cix is ix) else cix.search_batch(qs[:npq], prm)
+                got = ss.search_batch(qs[:npq], prm) if (use_shards and cix is ix) else cix.search_batch(qs[:npq], prm)
                 agree = sum(int(np.array_equal(g.passage_ids, r.passage_ids)) for g, r in zip(got, ref))
                 top1 = sum(int(g.passage_ids[:1].tolist() == r.passage_ids[:1].tolist()) for g, r in zip(got, ref))
                 rel = max((float(np.max(np.abs(g.scores - r.scores) / np.maximum(np.abs(r.scores), 1e-6)))
@@ -362,10 +382,12 @@ def main():
         "config": {"workload": f"{a.docs} docs x {a.doc_len if len_min == a.doc_len else f'{len_min}-{a.doc_len}'} tok x d128 "
                                f"(nbits={a.nbits}), 2^{k2} centroids, nprobe={a.nprobe}, batch={a.batch}x{a.query_tokens} tok, "
                                f"n_full_scores={a.n_full_scores}, t_cs={thr}, top_k={a.top_k}; one fixed corpus sharded "
-                               f"{world} way(s): {docs_local} docs on rank 0's GPU",
-                   "docs_total": a.docs, "docs_per_gpu": docs_local, "batch": a.batch,
-                   "parallelism": (f"doc-shard x{world} + RCCL all-gather ({'np_hip_search_batch_sharded' if a.dist_impl == 'c' else 'torch.distributed harness'})"
-                                   if use_dist else "single GPU")},
+                               f"{n_shards} way(s) x {n_repl} replica group(s): {docs_local} docs on rank 0's GPU",
+                   "docs_total": a.docs, "docs_per_gpu": docs_local, "batch": a.batch, "shards": n_shards, "replicas": n_repl,
+                   "parallelism": ((f"doc-shard x{n_shards} + RCCL all-gather ({'np_hip_search_batch_sharded' if a.dist_impl == 'c' else 'torch.distributed harness'})"
+                                    if use_shards else "whole index per GPU")
+                                   + (f", x{n_repl} replica groups on different batches" if n_repl > 1 else ""))
+                                  if use_dist else "single GPU"},
         "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
         "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stages.items()},
         "index_build_s": round(t_build, 2), "hbm_index_bytes": int(ix.info.device_bytes),

@@ -122,7 +122,15 @@ struct Tuning {
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
-  int s4_hot = 50;       // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level filter)
+  int s4_hot = 200;      // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level
+                         // filter).  The hot level is not L2-request bound, so extra hot rows are nearly free and a larger share
+                         // leaves fewer documents to the exact bound: 40 / 100 / 160 / 250 -> S4 4.02 / 3.92 / 3.62 / 3.62 ms at 10 M
+  int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
+  int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim
+                         // on a line all XCDs share costs ~50 ns, serialised): 2.06 -> 1.68 ms at 10 M documents
+  int ub_static = 0;     // the same for the exact-bound kernel: measured WORSE there (single-level S4 4.43 -> 5.17 ms: workgroups
+                         // that run ahead pull the next query's table into the L2), so it keeps the cursor
+  int s4_probe = 0;      // DIAGNOSTIC (results invalid when != 0): phases of the hot kernel to skip, for timing them
   int ub_nbx = 96;       // filter workgroups per XCD: 3 per CU (48 KB of LDS each).  64 makes the stage itself 3 % faster (0.70 vs 0.73 ms at
                          // 1 M, 4.43 vs 4.57 ms at 10 M documents) but the sustained 3-stream rate at 10 M drops 10.8 k -> 10.3 k queries/s
   int ub_steal = 16384;  // filter: an idle XCD joins a running query that has at least this many unclaimed documents (0x7fffffff = never)

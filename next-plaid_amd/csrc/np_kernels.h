@@ -1771,7 +1771,11 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         int32_t* __restrict__ slots /* [8][B+1] = -1 */,
                                                         int32_t* __restrict__ ticket /* [1] = -1 */, int B,
                                                         int steal_min /* unclaimed documents worth joining a query for */,
-                                                        Counters* ctr, int count_tokens /* add the lists' token counts to ctr */) {
+                                                        Counters* ctr, int count_tokens /* add the lists' token counts to ctr */,
+                                                        int direct_wpq /* > 0: no hand-out, workgroups [j * wpq, (j+1) * wpq) take the
+                                                                          round's j-th query (short lists: every query at once) */,
+                                                        int static_claims /* waves take the claims round-robin, no cursor atomic (see
+                                                                             approx_hot_kernel); queries are never shared between XCDs */) {
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
   constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // distinct codes of one document staged per pass (32 KB of LDS per
@@ -1800,11 +1804,17 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   __shared__ int s_q;
   for (int step = 0;; ++step) {
     __syncthreads();
-    if (tid == 0)
+    if (direct_wpq > 0) {
+      if (step > 0) break;
+      const int j = rb + (int)blockIdx.x / direct_wpq;
+      if (j >= re) break;
+      if (tid == 0) s_q = rp.order[j];
+    } else if (tid == 0)
       s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
         // no query left to start: join the one with the most unclaimed documents, if that is worth pulling its table
         // into this XCD's L2 (the end of the launch otherwise waits for the XCDs that drew the last queries)
         int best = -3;
+        if (static_claims) return best;
         int64_t most = steal_min;
         for (int j = rb; j < re; ++j) {
           const int b2 = rp.order[j];
@@ -1839,12 +1849,17 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     if (hb)
       for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
     __syncthreads();
+    // static_claims: wave g of the NWS waves working on this query takes claims g, g + NWS, ... (no cursor atomic)
+    const int64_t NWS = direct_wpq > 0 ? (int64_t)direct_wpq * 4 : (int64_t)(gridDim.x >> 3) * 4;
+    const int64_t gw = direct_wpq > 0 ? (int64_t)((int)blockIdx.x % direct_wpq) * 4 + wave : (int64_t)(blockIdx.x >> 3) * 4 + wave;
+    int64_t istat = gw * DPW;
     uint32_t inext = 0;
-    if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
+    if (!static_claims && lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
     for (;;) {
-      const int64_t i0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
+      const int64_t i0 = static_claims ? istat : (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
       if (i0 >= n) break;
-      if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);   // the next claim travels while this one is processed
+      istat += NWS * DPW;
+      if (!static_claims && lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);   // the next claim travels while this one is processed
       const int64_t i = i0 + grp;
       const bool valid = i < n;
       uint4 m;
@@ -2250,12 +2265,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
     const uint4* __restrict__ cand_meta, const int32_t* __restrict__ n_cand, RoundPlan rp, int round, int max_rounds,
     const CT* __restrict__ codes, const uint32_t* __restrict__ qflag, const int32_t* __restrict__ qoff, int n_sel,
     uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift, uint32_t* __restrict__ cursor, int32_t* __restrict__ slots,
-    int32_t* __restrict__ ticket, int B, int steal_min, Counters* ctr) {
+    int32_t* __restrict__ ticket, int B, int steal_min, Counters* ctr,
+    int probe /* DIAGNOSTIC ONLY (results invalid when != 0): 1 skip the walk, 2 skip the scan, 4 skip the staging */,
+    int static_claims /* 1: round-robin claims, 0: claims from the per-query cursor */) {
   constexpr int LPD = ROWB / 16;   // lanes per document in the walk (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per claim
   constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // codes of one document staged per pass
   constexpr int CPS = CAP / 32;                     // codes a staging lane loads (half a wave per document)
-  constexpr int CPL = CAP / 64;                     // codes a scanning lane tests (the whole wave on one document)
   constexpr int RS = CAP + 16 / (int)sizeof(CT);    // row stride: 16 B of padding keeps rows 16-B aligned and off each other's banks
   extern __shared__ uint32_t s_bits[];   // KP / 32 words: hot centroids of the current query
   __shared__ uint32_t s_hist[NP_UB_BINS];
@@ -2271,25 +2287,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
   unsigned long long toks = 0, ucnt = 0, rows = 0;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   for (int step = 0;; ++step) {
     __syncthreads();
     if (tid == 0)
-      s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() {
-        int best = -3;
-        int64_t most = steal_min;
-        for (int j = rb; j < re; ++j) {
-          const int b2 = rp.order[j];
-          const int64_t n2 = n_cand[b2];
-          if (qflag[b2] || n2 <= (int64_t)n_sel) continue;
-          const int64_t left = n2 - (int64_t)__hip_atomic_load(&cursor[b2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (left >= most) {
-            most = left;
-            best = b2;
-          }
-        }
-        return best;
-      });
+      s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() { return -3; });   // round-robin claims: no sharing
     __syncthreads();
     const int b = __builtin_amdgcn_readfirstlane(s_q);
     if (b < 0) break;
@@ -2321,15 +2322,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((uint64_t)thi << 32) | tlo), 0, (int)(KP * ROWB), 0x00020000);
     uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+    // Claims.  A claim from a per-query cursor costs one device-scope atomic on a line every XCD's cursor shares (~50 ns
+    // each, serialised: with every other phase switched off, NP_S4_PROBE=7, the 372 k claims of a launch at 10 M documents
+    // take 2.3 ms).  A document costs the same work to within a few per cent, so by default the waves of the XCD take the
+    // query's claims ROUND-ROBIN: wave g of NW takes claims g, g + NW, ... -- no atomic, the next claim's records prefetched
+    // a whole iteration ahead (hot kernel 2.06 -> 1.68 ms).  static_claims = 0 keeps the cursor (claims two ahead).
+    const int64_t NW = (int64_t)(gridDim.x >> 3) * 4;
     uint32_t inext = 0;
-    if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
+    int64_t i0, i1;
+    if (static_claims) {
+      i0 = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW;
+      i1 = i0 + NW * DPW;
+    } else {
+      if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)(2 * DPW));
+      i0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
+      i1 = i0 + DPW;
+    }
+    uint4 m = metab[min(i0 + grp, n - 1)];
     for (;;) {
-      const int64_t i0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
       if (i0 >= n) break;
-      if (lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);   // the next claim travels while this one is processed
+      if (!static_claims && lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
+      const uint4 m_next = metab[min(i1 + grp, n - 1)];   // prefetch (clamped: a claim past the end is never used)
       const int64_t i = i0 + grp;
       const bool valid = i < n;
-      const uint4 m = metab[valid ? i : n - 1];
       const int nd = valid ? (int)m.y : 0;
       if (jl == 0) {
         s_cl[wave][grp] = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
@@ -2352,9 +2367,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         // ---- (1) stage codes [p0, p0 + CAP) of every document of the claim: one coalesced read per list, half a wave per
         // document, all loads of a batch of documents in flight before the first LDS write (one memory round trip per
         // batch).  Positions past a list's end hold whatever follows it in memory: the scan below knows the lengths.
-        constexpr int SB = DPW / 2 < 8 ? DPW / 2 : 8;   // staging steps per batch (two documents per step)
+        constexpr int SB = DPW / 2;   // staging steps, two documents each: the whole claim in ONE burst of loads
 #pragma unroll 1
-        for (int sb = 0; sb < DPW / 2; sb += SB) {
+        for (int sb = 0; sb < ((probe & 4) ? 0 : DPW / 2); sb += SB) {
           uint2 raw[SB];
 #pragma unroll
           for (int j = 0; j < SB; ++j) {
@@ -2373,35 +2388,62 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- (2) scan: the whole wave tests one document's staged codes against the bitmap and compacts the hot ones to
-        // the front of the same row (every code is in a register before the first write)
-#pragma unroll 2
-        for (int sl = 0; sl < DPW; ++sl) {
-          const int cnt = min(max(__builtin_amdgcn_readfirstlane(s_nd[wave][sl]) - p0, 0), CAP);
-          int tot = 0;
-          if (cnt > 0) {
-            uint32_t c[CPL];
+        // ---- (2) scan: lanes 0 and 1 of a document's group each take one half of its staged codes [0, cnt), test them
+        // against the bitmap and compact the hot ones to the front of their own half (a write never passes the lane's read
+        // position); lane 1 then closes its hot codes up behind lane 0's.  All documents of the claim advance together, four
+        // codes per lane and step: ONE LDS read for the codes, four independent bitmap reads, then the writes -- two LDS
+        // round trips per four codes (one code per step left the wave waiting on ~90 dependent LDS round trips per claim).
+        {
+          const int cnt = min(max(nd - p0, 0), CAP);
+          const int part = (((cnt + 1) >> 1) + 3) & ~3;          // halves start 8-B (u16) / 16-B (u32) aligned
+          const int start = jl == 0 ? 0 : part, end = jl == 0 ? min(part, cnt) : cnt;
+          CT* row = &s_codes[wave][grp][0];
+          int itmax = (jl < 2 && !(probe & 2)) ? end - start : 0;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) itmax = max(itmax, __shfl_xor(itmax, o));
+          itmax = __builtin_amdgcn_readfirstlane(itmax);
+          int wpos = start;
+          for (int it = 0; it < itmax; it += 4) {
+            const int pos = start + it;
+            const bool act = jl < 2 && pos < end;
+            uint32_t c[4];
             if constexpr (sizeof(CT) == 2) {
-              const uint32_t w2 = *reinterpret_cast<const uint32_t*>(&s_codes[wave][sl][CPL * lane]);
-              c[0] = w2 & 0xFFFFu;
-              c[1] = w2 >> 16;
+              const uint2 w2 = *reinterpret_cast<const uint2*>(row + (act ? pos : 0));
+              c[0] = w2.x & 0xFFFFu; c[1] = w2.x >> 16; c[2] = w2.y & 0xFFFFu; c[3] = w2.y >> 16;
             } else {
-              c[0] = s_codes[wave][sl][lane];
+              const uint4 w4 = *reinterpret_cast<const uint4*>(row + (act ? pos : 0));
+              c[0] = w4.x; c[1] = w4.y; c[2] = w4.z; c[3] = w4.w;
             }
-            bool h[CPL];
-            unsigned long long bal[CPL];
+            uint32_t bw[4];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-              h[k] = CPL * lane + k < cnt && ((s_bits[c[k] >> 5] >> (c[k] & 31)) & 1u);
-              bal[k] = __ballot(h[k]);
-            }
+            for (int k = 0; k < 4; ++k) bw[k] = s_bits[min(c[k], (uint32_t)(KP - 1)) >> 5];   // past the list: any word (masked below)
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-              if (h[k]) s_codes[wave][sl][tot + (int)__popcll(bal[k] & lt_mask)] = (CT)c[k];
-              tot += (int)__popcll(bal[k]);
+            for (int k = 0; k < 4; ++k) {
+              const bool h = act && pos + k < end && ((bw[k] >> (c[k] & 31)) & 1u);
+              if (h) row[wpos] = (CT)c[k];
+              wpos += h ? 1 : 0;
             }
           }
-          if (lane == 0) s_hcnt[wave][sl] = tot;
+          const int hmine = wpos - start;
+          const int h0 = __shfl(hmine, lane & ~(LPD - 1)), h1 = __shfl(hmine, (lane & ~(LPD - 1)) + 1);
+          int cmax = (jl == 1 && h0 < part) ? hmine : 0;   // close-up: row[h0 + k] = row[part + k], k < h1 (h0 <= part: reads stay ahead of writes)
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+          cmax = __builtin_amdgcn_readfirstlane(cmax);
+          if (cmax > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool mover = jl == 1 && h0 < part;
+            for (int k0 = 0; k0 < cmax; k0 += 4) {
+              CT c[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) c[k] = row[mover && k0 + k < hmine ? part + k0 + k : 0];
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (mover && k0 + k < hmine) row[h0 + k0 + k] = c[k];
+            }
+          }
+          if (jl == 0) s_hcnt[wave][grp] = h0 + h1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2411,7 +2453,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         int hmax = hn;
 #pragma unroll
         for (int o = LPD; o < 64; o <<= 1) hmax = max(hmax, __shfl_xor(hmax, o));
-        hmax = __builtin_amdgcn_readfirstlane(hmax);
+        hmax = (probe & 1) ? 0 : __builtin_amdgcn_readfirstlane(hmax);
         if (jl == 0) rows += (unsigned long long)hn;
         const CT* mine = &s_codes[wave][grp][0];
         for (int t = 0; t < hmax; t += 8) {
@@ -2454,6 +2496,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         atomicAdd(&s_hist[min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
       }
       __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next claim
+      i0 = i1;
+      m = m_next;
+      i1 = static_claims ? i1 + NW * DPW : (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
     }
     __syncthreads();
     for (int i = tid; i < NP_UB_BINS; i += 256) {

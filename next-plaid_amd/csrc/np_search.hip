@@ -617,15 +617,19 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       auto xcursor = [&](int lvl) { return w.ub_cursor.as<uint32_t>() + (size_t)lvl * B; };
       const bool oob = ix->tune.ub_nt == 2 && KP * RB < ((int64_t)1 << 30);   // the table behind a 32-bit buffer offset
       // exact u8 bound of the records meta[begin[b] .. begin[b] + count[b]) -> U, histogram (optional)
+      // direct_wpq > 0: a short list per query (S1, about n_sel documents): wpq workgroups per query, every query at once,
+      // instead of one query per XCD at a time (8 hand-out steps of ~25 us each for a handful of claims)
       auto launch_ub = [&](int lvl, const uint4* meta, const int32_t* begin, const int32_t* count, uint16_t* U, uint32_t* hist,
-                           int count_tokens) {
+                           int count_tokens, int direct_wpq) {
         int32_t* sl = xslots(lvl);
         int32_t* tk = sl + 8 * (B + 1);
+        const unsigned grid = direct_wpq > 0 ? (unsigned)(B * direct_wpq) : 8 * nbx;
 #define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                        \
-  approx_ub_kernel<ROWB, CT, NT><<<8 * nbx, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(), \
-                                                          rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), \
-                                                          cs->n_sel, U, hist, hshift, xcursor(lvl), sl, tk, B,              \
-                                                          ix->tune.ub_steal, w.ctr.as<Counters>(), count_tokens)
+  approx_ub_kernel<ROWB, CT, NT><<<grid, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(),   \
+                                                       rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(),   \
+                                                       cs->n_sel, U, hist, hshift, xcursor(lvl), sl, tk, B,                \
+                                                       ix->tune.ub_steal, w.ctr.as<Counters>(), count_tokens, direct_wpq,   \
+                                                       ix->tune.ub_static)
 #define NP_LAUNCH_UB_RB(CT, NT)                 \
   do {                                          \
     if (RB == 32) NP_LAUNCH_UB(32, CT, NT);     \
@@ -653,7 +657,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       cp.all_src = w.cand_meta.as<uint4>();
       cp.n_all = w.n_cand.as<int32_t>();
       if (!two_level) {
-        launch_ub(0, w.cand_meta.as<uint4>(), nullptr, w.n_cand.as<int32_t>(), w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), 1);
+        launch_ub(0, w.cand_meta.as<uint4>(), nullptr, w.n_cand.as<int32_t>(), w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), 1, 0);
         ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, slack, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
                                          w.qflag.as<uint32_t>(), w.ub_thr.as<uint32_t>());
         cp.src = w.cand_meta.as<uint4>();
@@ -680,7 +684,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
                                                            w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, \
                                                            w.qflag.as<uint32_t>(), d_qoff, cs->n_sel, w.ub.as<uint16_t>(),  \
                                                            w.ub_hist.as<uint32_t>(), hshift, xcursor(0), sl, sl + 8 * (B + 1), \
-                                                           B, ix->tune.ub_steal, w.ctr.as<Counters>());                    \
+                                                           B, ix->tune.ub_steal, w.ctr.as<Counters>(), ix->tune.s4_probe,   \
+                                                           ix->tune.hot_static);                                           \
   } while (0)
 #define NP_LAUNCH_HOT_RB(CT)                    \
   do {                                          \
@@ -705,7 +710,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
         cp.dst = w.list_meta.as<uint4>();
         cp.n_dst = w.n_l1.as<int32_t>();
         ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(cp, rp, r);
-        launch_ub(1, w.list_meta.as<uint4>(), nullptr, w.n_l1.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0);
+        launch_ub(1, w.list_meta.as<uint4>(), nullptr, w.n_l1.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0,
+                  ix->tune.ub_direct);
         ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist2.as<uint32_t>(), hshift, slack, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
                                          w.qflag.as<uint32_t>(), w.ub_thr2.as<uint32_t>());
         // S2 = the other documents with U' >= tau: exact bound too (appended behind S1)
@@ -714,7 +720,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
         cp.dst_begin = w.n_l1.as<int32_t>();
         cp.n_dst = w.n_l2.as<int32_t>();
         ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(cp, rp, r);
-        launch_ub(2, w.list_meta.as<uint4>(), w.n_l1.as<int32_t>(), w.n_l2.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0);
+        launch_ub(2, w.list_meta.as<uint4>(), w.n_l1.as<int32_t>(), w.n_l2.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0, 0);
         // every document with U' >= tau now has its exact bound in the histogram: the cut over S1 + S2 is the single-level
         // filter's cut (the n_sel-th largest exact U of ALL candidates lies in S1 + S2), tau can only rise
         ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist2.as<uint32_t>(), hshift, slack, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,

@@ -90,7 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 100)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 200), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1)):
         hx.tune(k, v)
 
 
@@ -270,8 +270,10 @@ def test_s4_filter_preserves_selection(mid, tuned):
         st0 = dict(hx.last_stats)
         hx.tune("s4_filter", 1)
         surv = set()
+        hx.tune("s4_hot", 0)           # this test is about the single-level filter (the two-level one has its own below)
         for ub_mode in (0, 1, 2):      # plain / non-temporal / bounds-checked buffer loads of the u8 table
             hx.tune("ub_nt", ub_mode)
+            hx.tune("ub_static", ub_mode & 1)
             hx.tune("ub_nbx", (96, 8, 64)[ub_mode])    # workgroups per XCD: any number walks the same claims
             got = hx.search_batch(batch, p)
             st1 = dict(hx.last_stats)
@@ -308,6 +310,9 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         rows = {}
         for hot in (0, 10, 100, 300, 500):
             hx.tune("s4_hot", hot)
+            hx.tune("ub_direct", 0 if hot == 300 else 8)   # short-list launch: per-XCD hand-out or one group of workgroups per query
+            hx.tune("ub_static", 1 if hot in (10, 500) else 0)   # claims from a cursor (with stealing) or round-robin
+            hx.tune("hot_static", 0 if hot in (10, 300) else 1)
             got = hx.search_batch(batch, p)
             st = dict(hx.last_stats)
             for i, (g, r) in enumerate(zip(got, ref)):
