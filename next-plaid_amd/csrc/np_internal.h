@@ -122,9 +122,10 @@ struct Tuning {
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
-  int s4_hot = 200;      // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level
-                         // filter).  The hot level is not L2-request bound, so extra hot rows are nearly free and a larger share
-                         // leaves fewer documents to the exact bound: 40 / 100 / 160 / 250 -> S4 4.02 / 3.92 / 3.62 / 3.62 ms at 10 M
+  int s4_hot = 100;      // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level
+                         // filter).  More hot centroids: fewer documents left to the exact bound (S1 + S2: 2.66 M / 1.19 M of 11.9 M
+                         // at 100 / 200) but more table rows and walk steps per document in the hot kernel, which is VALU-bound:
+                         // 40 / 100 / 200 / 300 -> S4 4.02 / 2.73 / 2.92 / 3.00 ms at 10 M documents
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim
                          // on a line all XCDs share costs ~50 ns, serialised): 2.06 -> 1.68 ms at 10 M documents
@@ -136,6 +137,7 @@ struct Tuning {
   int ub_steal = 16384;  // filter: an idle XCD joins a running query that has at least this many unclaimed documents (0x7fffffff = never)
   int ub_nt = 2;         // filter loads: 0 plain, 1 non-temporal records / code lists, 2 bounds-checked buffer loads of the table
   int s6_xcd = 1;        // one XCD per query in S6
+  int s6_tiles = 1;      // QC-reuse S6: one launch of the one-tile kernel per 32-token query tile (0: the multi-tile kernels)
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };

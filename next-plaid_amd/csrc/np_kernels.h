@@ -43,6 +43,25 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 }
 __device__ __forceinline__ int mfma_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }
 
+// Maximum of a non-negative int over the wave, wave-uniform result.  DPP row shifts / row broadcasts on the VALU (the
+// GFX9 reduction idiom) instead of six ds_bpermute round trips through the LDS pipe per __shfl_xor butterfly.
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));   // row_shr:8  -> lane 15 of each row = row maximum
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3 -> lane 63 = maximum
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// value of lane J (0 or 1) of this lane's group of G lanes (G a power of two): a quad permute for G <= 4
+template <int G, int J>
+__device__ __forceinline__ int group_lane(int v, int lane) {
+  if constexpr (G == 2) return __builtin_amdgcn_mov_dpp(v, J == 0 ? 0xA0 : 0xF5, 0xf, 0xf, true);        // [0,0,2,2] / [1,1,3,3]
+  else if constexpr (G == 4) return __builtin_amdgcn_mov_dpp(v, J == 0 ? 0x00 : 0x55, 0xf, 0xf, true);   // [0,0,0,0] / [1,1,1,1]
+  else return __shfl(v, (lane & ~(G - 1)) + J);
+}
+
 struct Counters {  // per-call work counters (np_stats)
   unsigned long long n_cells, n_ivf_ids, n_candidates, n_cand_tokens, n_exact_docs, n_exact_tokens, n_cand_codes;
   unsigned long long n_rounds;     // candidate-pool rounds the slice needed (max over slices)
@@ -2278,7 +2297,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
   __shared__ __attribute__((aligned(16))) CT s_codes[4][DPW][RS];
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
-  __shared__ int s_hcnt[4][DPW];
   __shared__ int s_q;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
@@ -2354,10 +2372,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
           ucnt += (unsigned long long)nd;
         }
       }
-      int nmax = nd;
-#pragma unroll
-      for (int o = LPD; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-      nmax = __builtin_amdgcn_readfirstlane(nmax);
+      const int nmax = wave_max_nonneg(nd);
       uint32_t st[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) st[k] = 0;
@@ -2390,18 +2405,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         __builtin_amdgcn_wave_barrier();
         // ---- (2) scan: lanes 0 and 1 of a document's group each take one half of its staged codes [0, cnt), test them
         // against the bitmap and compact the hot ones to the front of their own half (a write never passes the lane's read
-        // position); lane 1 then closes its hot codes up behind lane 0's.  All documents of the claim advance together, four
-        // codes per lane and step: ONE LDS read for the codes, four independent bitmap reads, then the writes -- two LDS
-        // round trips per four codes (one code per step left the wave waiting on ~90 dependent LDS round trips per claim).
-        {
-          const int cnt = min(max(nd - p0, 0), CAP);
-          const int part = (((cnt + 1) >> 1) + 3) & ~3;          // halves start 8-B (u16) / 16-B (u32) aligned
+        // position).  All documents of the claim advance together, four codes per lane and step: ONE LDS read for the codes,
+        // four independent bitmap reads, then the writes -- two LDS round trips per four codes.  The loop bound comes from
+        // the claim's longest list (no reduction); the two halves stay where they are, the walk takes them one after the other.
+        const int cnt = min(max(nd - p0, 0), CAP);
+        const int part = (((cnt + 1) >> 1) + 3) & ~3;          // halves start 8-B (u16) / 16-B (u32) aligned
+        CT* row = &s_codes[wave][grp][0];
+        int hmine = 0;
+        if (!(probe & 2)) {
           const int start = jl == 0 ? 0 : part, end = jl == 0 ? min(part, cnt) : cnt;
-          CT* row = &s_codes[wave][grp][0];
-          int itmax = (jl < 2 && !(probe & 2)) ? end - start : 0;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) itmax = max(itmax, __shfl_xor(itmax, o));
-          itmax = __builtin_amdgcn_readfirstlane(itmax);
+          const int itmax = (((min(nmax - p0, CAP) + 1) >> 1) + 3) & ~3;   // >= every document's half
           int wpos = start;
           for (int it = 0; it < itmax; it += 4) {
             const int pos = start + it;
@@ -2424,73 +2437,60 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
               wpos += h ? 1 : 0;
             }
           }
-          const int hmine = wpos - start;
-          const int h0 = __shfl(hmine, lane & ~(LPD - 1)), h1 = __shfl(hmine, (lane & ~(LPD - 1)) + 1);
-          int cmax = (jl == 1 && h0 < part) ? hmine : 0;   // close-up: row[h0 + k] = row[part + k], k < h1 (h0 <= part: reads stay ahead of writes)
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) cmax = max(cmax, __shfl_xor(cmax, o));
-          cmax = __builtin_amdgcn_readfirstlane(cmax);
-          if (cmax > 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const bool mover = jl == 1 && h0 < part;
-            for (int k0 = 0; k0 < cmax; k0 += 4) {
-              CT c[4];
-#pragma unroll
-              for (int k = 0; k < 4; ++k) c[k] = row[mover && k0 + k < hmine ? part + k0 + k : 0];
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-                if (mover && k0 + k < hmine) row[h0 + k0 + k] = c[k];
-            }
-          }
-          if (jl == 0) s_hcnt[wave][grp] = h0 + h1;
+          hmine = wpos - start;
         }
+        const int h0 = group_lane<LPD, 0>(hmine, lane), h1 = group_lane<LPD, 1>(hmine, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- (3) walk the hot codes in lockstep (LPD lanes per row, 8 gathers in flight per lane; positions past a
-        // document's hot list carry an out-of-range offset: the bounds check answers without a memory request)
-        const int hn = s_hcnt[wave][grp];
-        int hmax = hn;
+        // document's hot codes carry an out-of-range offset: the bounds check answers without a memory request).
+        // Segment A = lane 0's hot codes at row[0 ..), segment B = lane 1's at row[part ..).
+        if (jl == 0) rows += (unsigned long long)(h0 + h1);
+#pragma unroll 1
+        for (int seg = 0; seg < 2; ++seg) {
+          const int hn = seg == 0 ? h0 : h1;
+          const int hmax = (probe & 1) ? 0 : wave_max_nonneg(hn);
+          const CT* mine = row + (seg == 0 ? 0 : part);
+          for (int t = 0; t < hmax; t += 8) {
+            uint32_t c[8];
+            if constexpr (sizeof(CT) == 2) {
+              const uint4 cw = *reinterpret_cast<const uint4*>(mine + t);
+              c[0] = cw.x & 0xFFFFu; c[1] = cw.x >> 16; c[2] = cw.y & 0xFFFFu; c[3] = cw.y >> 16;
+              c[4] = cw.z & 0xFFFFu; c[5] = cw.z >> 16; c[6] = cw.w & 0xFFFFu; c[7] = cw.w >> 16;
+            } else {
+              const uint4 ca = *reinterpret_cast<const uint4*>(mine + t), cb = *reinterpret_cast<const uint4*>(mine + t + 4);
+              c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w;
+              c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
+            }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            uint4 v[8];
 #pragma unroll
-        for (int o = LPD; o < 64; o <<= 1) hmax = max(hmax, __shfl_xor(hmax, o));
-        hmax = (probe & 1) ? 0 : __builtin_amdgcn_readfirstlane(hmax);
-        if (jl == 0) rows += (unsigned long long)hn;
-        const CT* mine = &s_codes[wave][grp][0];
-        for (int t = 0; t < hmax; t += 8) {
-          uint32_t c[8];
-          if constexpr (sizeof(CT) == 2) {
-            const uint4 cw = *reinterpret_cast<const uint4*>(mine + t);
-            c[0] = cw.x & 0xFFFFu; c[1] = cw.x >> 16; c[2] = cw.y & 0xFFFFu; c[3] = cw.y >> 16;
-            c[4] = cw.z & 0xFFFFu; c[5] = cw.z >> 16; c[6] = cw.w & 0xFFFFu; c[7] = cw.w >> 16;
-          } else {
-            const uint4 ca = *reinterpret_cast<const uint4*>(mine + t), cb = *reinterpret_cast<const uint4*>(mine + t + 4);
-            c[0] = ca.x; c[1] = ca.y; c[2] = ca.z; c[3] = ca.w;
-            c[4] = cb.x; c[5] = cb.y; c[6] = cb.z; c[7] = cb.w;
-          }
-          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-          uint4 v[8];
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t off = (t + k < hn) ? c[k] * (uint32_t)ROWB + (uint32_t)(jl * 16) : 0x7FFFFFF0u;
+              const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)off, 0, 0);
+              v[k] = make_uint4(r.x, r.y, r.z, r.w);
+            }
+            asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const uint32_t off = (t + k < hn) ? c[k] * (uint32_t)ROWB + (uint32_t)(jl * 16) : 0x7FFFFFF0u;
-            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)off, 0, 0);
-            v[k] = make_uint4(r.x, r.y, r.z, r.w);
-          }
-          asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x), "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+              for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) st[4 * j + e] = max(st[4 * j + e], (w4[j] >> (8 * e)) & 0xFFu);
+                for (int e = 0; e < 4; ++e) st[4 * j + e] = max(st[4 * j + e], (w4[j] >> (8 * e)) & 0xFFu);
+            }
           }
         }
       }
       uint32_t sum = 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) sum += (16 * jl + k < Lq) ? max(st[k], lam) : 0u;   // padding tokens carry no bound
+      if constexpr (LPD == 2) {
+        sum += (uint32_t)__builtin_amdgcn_mov_dpp((int)sum, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]: the group's other lane
+      } else {
 #pragma unroll
-      for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
+        for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
+      }
       if (valid && jl == 0) {
         U[pbase + i] = (uint16_t)sum;
         atomicAdd(&s_hist[min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
@@ -2882,6 +2882,8 @@ struct ExactP {
   int gx;                   // workgroups per query
   const uint32_t* qflag;    // [B] query has a non-finite or huge value (prep_queries_kernel)
   int fast_ok;              // index values finite and bounded: with an unflagged query every S6 product is finite
+  int qt0;                  // exact_qct_kernel<.., NQT = 1, ..>: the 32-token query tile this launch scores (queries longer than
+  int acc;                  // 32 tokens take one launch per tile); acc = continue the q-ordered sum from exact[] (tiles > 0)
 };
 
 #define NP_EXACT_DPW 4   // documents per wave
@@ -3370,15 +3372,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQT ==
   const uint2* lut2 = reinterpret_cast<const uint2*>(lut);
   const int LQP = p.LQP;
   const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
-  const int Lq = p.qoff[b + 1] - p.qoff[b];
+  // One launch per 32-token query tile when NQT == 1 (p.qt0 = the tile): the two-tile instantiation needs 242 VGPRs (two
+  // waves per SIMD) and ran a 48-token batch at 2.46 ms against 0.60 ms for 32 tokens; two one-tile launches re-read the
+  // residuals but keep three waves per SIMD.  Tiles > 0 continue the q-ordered sum from exact[] (same order as one pass).
+  const int qt0 = NQT == 1 ? p.qt0 : 0;
+  const int Lq = max(0, min(32 * NQT, p.qoff[b + 1] - p.qoff[b] - 32 * qt0));   // query tokens of this launch's tile(s)
   const int nqt = (Lq + 31) >> 5;
   const int nsel = p.nsel[b];
   const uint64_t cut = p.cut ? p.cut[b] : 0ull;
   const bool fast = p.fast_ok != 0 && p.qflag[b] == 0;   // workgroup-uniform
+  if (qt0 > 0 && Lq == 0) return;                         // this query has no token in the tile: nothing to add
   // slot (s, kk, e) of the MFMA k dimension <-> dim kk*DIM/2 + 8s + e, for A (tokens) and B (query) alike
-  const __bf16* Qb = p.Qb + (int64_t)b * LQP * DIM + kk * (DIM / 2);
-  const __bf16* Ql = p.Qb_lo + (int64_t)b * LQP * DIM + kk * (DIM / 2);
-  const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP);   // row base; columns added per load
+  const __bf16* Qb = p.Qb + ((int64_t)b * LQP + 32 * qt0) * DIM + kk * (DIM / 2);
+  const __bf16* Ql = p.Qb_lo + ((int64_t)b * LQP + 32 * qt0) * DIM + kk * (DIM / 2);
+  const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP) + 128 * qt0;   // row base; columns added per load
   const uint32_t row_bytes = (uint32_t)LQP * 4u;
   bf16x8 bh0[NS], bl0[SPLIT == 3 ? NS : 1];
 #pragma unroll
@@ -3395,6 +3402,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQT ==
       if (lane == 0) p.exact[oj] = 0.f;
       continue;
     }
+    const float prior = (NQT == 1 && p.acc) ? p.exact[oj] : 0.f;
     const uint32_t doc = p.sel_doc[oj];
     const int64_t off = p.doc_off[doc];
     const int len = (int)(p.doc_off[doc + 1] - off);
@@ -3534,7 +3542,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQT ==
         }
       }
     }
-    float total = 0.f;
+    float total = prior;
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
       if (qt < nqt) {

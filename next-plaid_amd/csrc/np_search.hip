@@ -241,12 +241,27 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     exact_f32_kernel<DIM, NBITS, NQT><<<dim3(gx, B), 256, lds, st>>>(p);
   } else if (precision == 1 || precision == 2) {
-    // Lq <= 64: transposed form (4 float4 QC loads per tile, no per-row shuffles); longer queries keep the
-    // row-max form, whose running maxima need one register per query tile instead of sixteen
-    if (NQT <= 2 && !ix->tune.exact_rowmax) {
+    // Transposed form (4 float4 QC loads per tile, no per-row shuffles), ONE LAUNCH PER 32-TOKEN QUERY TILE: the one-tile
+    // instantiation keeps three waves per SIMD; a two-tile one needs 242 VGPRs and ran 48-token queries 4x slower than
+    // 32-token ones (2.46 vs 0.60 ms at 10 M documents).  s6_tiles = 0 restores the multi-tile kernels.
+    if (!ix->tune.exact_rowmax && (NQT == 1 || ix->tune.s6_tiles)) {
       ExactP px = p;
       dim3 grid(gx, B);
       if (B >= 8 && ix->tune.s6_xcd) {   // one XCD per query (see exact_qct_kernel)
+        px.xcd_B = B;
+        px.gx = (int)gx;
+        grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
+      }
+      for (int qt = 0; qt < p.LQP / 32; ++qt) {
+        px.qt0 = qt;
+        px.acc = qt > 0;
+        if (precision == 1) exact_qct_kernel<DIM, NBITS, 1, 1><<<grid, 256, 0, st>>>(px);
+        else exact_qct_kernel<DIM, NBITS, 1, 3><<<grid, 256, 0, st>>>(px);
+      }
+    } else if (NQT <= 2 && !ix->tune.exact_rowmax) {
+      ExactP px = p;
+      dim3 grid(gx, B);
+      if (B >= 8 && ix->tune.s6_xcd) {
         px.xcd_B = B;
         px.gx = (int)gx;
         grid = dim3(8u * (unsigned)((B + 7) / 8) * gx, 1);
@@ -813,6 +828,8 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.gx = 0;
     ep.qflag = w.qflag.as<uint32_t>();
     ep.fast_ok = ix->s6_fast_ok ? 1 : 0;
+    ep.qt0 = 0;
+    ep.acc = 0;
     switch (ix->dim) {
       case 32: NP_TRY((launch_exact_nb<32>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
       case 64: NP_TRY((launch_exact_nb<64>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
