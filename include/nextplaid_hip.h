@@ -177,7 +177,7 @@ int64_t np_hip_index_ivf_size(const np_index* index);
  * NP_<UPPER-CASE NAME>, and can be changed on a live handle with this call (sweep tools, kernel-variant parity tests);
  * both paths clamp through one table.  Knobs: "s4_mode" 0..8, "s4_minb" >= 1, "s4_nbx" 8..512, "s4_swz" 0/1,
  * "s4_filter" 0/1, "s4_hot" 0..500 (per-mille of hot centroids in the first filter level; 0 = single-level filter),
- * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "ub_direct" 0..16, "ub_static" 0/1, "hot_static" 0/1, "s4_probe" 0..7 (diagnostic: results invalid when != 0), "s6_xcd" 0/1, "s6_tiles" 0/1, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
+ * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "ub_direct" 0..16, "ub_static" 0/1, "hot_static" 0/1, "s4_probe" 0..7 (diagnostic: results invalid when != 0), "s6_xcd" 0/1, "s6_tiles" 0/1, "s6_lds" 0..2, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
  * Results are identical for every setting; not synchronised with concurrent searches.  Unknown name:
  * NP_ERR_INVALID_ARGUMENT. */
 int np_hip_index_tune(np_index* index, const char* name, int32_t value);

@@ -137,6 +137,7 @@ struct Tuning {
   int ub_steal = 16384;  // filter: an idle XCD joins a running query that has at least this many unclaimed documents (0x7fffffff = never)
   int ub_nt = 2;         // filter loads: 0 plain, 1 non-temporal records / code lists, 2 bounds-checked buffer loads of the table
   int s6_xcd = 1;        // one XCD per query in S6
+  int s6_lds = 1;        // QC-reuse S6: query fragments in LDS + C-in rows prefetched one tile ahead (exact_qcl_kernel); 0 = exact_qct_kernel
   int s6_tiles = 1;      // QC-reuse S6: one launch of the one-tile kernel per 32-token query tile (0: the multi-tile kernels)
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel

@@ -3573,6 +3573,226 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQT ==
   (void)ndocs;
 }
 
+// S6, QC-reuse form with the QUERY FRAGMENTS IN LDS and the C-in rows gathered one tile ahead (round 3; NQT = 1 per launch).
+// exact_qct_kernel holds the query's 8 hi + 8 lo B fragments in 64 VGPRs for the whole kernel: 155 VGPRs, three waves per
+// SIMD, no room to prefetch the C-in rows -- and its PMC profile is a stalled one (MFMA pipe 38 % busy, VALU + MFMA issue
+// 0.25 ms of 0.59 ms, 15 M of 20 M C-in row requests miss the L2).  Here the fragments are read from LDS per k-step (rows
+// padded by 16 B: the 1 KiB a wave reads per step spreads over all banks), which frees the registers for (a) the codes
+// two tiles ahead and the C-in rows ONE TILE AHEAD of their MFMAs, so the L2-miss latency of the row gather overlaps a
+// whole tile of matrix work, and (b) four waves per SIMD.  Arithmetic and summation order identical to exact_qct_kernel.
+template <int DIM, int NBITS, int SPLIT, int WPE /* waves per SIMD the register budget is cut for */>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) exact_qcl_kernel(ExactP p) {
+  constexpr int NS = DIM / 16;
+  constexpr int PD = DIM * NBITS / 8;
+  constexpr int PH = PD / 2;
+  constexpr int NW = PH / 4;
+  constexpr int WPB = (NBITS == 4) ? 1 : 2;
+  constexpr int QS = DIM + 8;   // LDS row stride of the query fragments in bf16 (16 B of padding)
+  static_assert(DIM % 32 == 0 && (NBITS == 2 || NBITS == 4) && PH % 4 == 0, "unsupported DIM/NBITS");
+  __shared__ uint32_t lut[256 * WPB * 2];
+  __shared__ __attribute__((aligned(16))) __bf16 sQh[32 * QS];
+  __shared__ __attribute__((aligned(16))) __bf16 sQl[SPLIT == 3 ? 32 * QS : 8];
+  int b = blockIdx.y, bx = blockIdx.x;
+  if (p.xcd_B > 0) {
+    const int slot = blockIdx.x >> 3;
+    b = (slot / p.gx) * 8 + (blockIdx.x & 7);
+    bx = slot % p.gx;
+    if (b >= p.xcd_B) return;
+  }
+  const int tid = threadIdx.x;
+  {
+    constexpr int PER = 8 / NBITS;
+    constexpr uint32_t MASK = (1u << NBITS) - 1u;
+    uint16_t hh[4] = {0, 0, 0, 0}, ll[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const float w = p.wlut[((uint32_t)tid >> (8 - NBITS * (e + 1))) & MASK];
+      const __bf16 h = (__bf16)w;
+      const __bf16 l = (__bf16)(w - (float)h);
+      hh[e] = __builtin_bit_cast(uint16_t, h);
+      ll[e] = __builtin_bit_cast(uint16_t, l);
+    }
+#pragma unroll
+    for (int w2 = 0; w2 < WPB; ++w2) {
+      lut[(tid * WPB + w2) * 2 + 0] = (uint32_t)hh[2 * w2] | ((uint32_t)hh[2 * w2 + 1] << 16);
+      lut[(tid * WPB + w2) * 2 + 1] = (uint32_t)ll[2 * w2] | ((uint32_t)ll[2 * w2 + 1] << 16);
+    }
+  }
+  const int LQP = p.LQP;
+  const int qt0 = p.qt0;
+  {  // this launch's 32-token query tile -> LDS (16 B per thread and step)
+    const __bf16* Qb = p.Qb + ((int64_t)b * LQP + 32 * qt0) * DIM;
+    const __bf16* Ql = p.Qb_lo + ((int64_t)b * LQP + 32 * qt0) * DIM;
+    for (int i = tid; i < 32 * DIM / 8; i += 256) {
+      const int r = i / (DIM / 8), c8 = i - r * (DIM / 8);
+      *reinterpret_cast<uint4*>(&sQh[r * QS + 8 * c8]) = *reinterpret_cast<const uint4*>(Qb + (int64_t)r * DIM + 8 * c8);
+      if constexpr (SPLIT == 3)
+        *reinterpret_cast<uint4*>(&sQl[r * QS + 8 * c8]) = *reinterpret_cast<const uint4*>(Ql + (int64_t)r * DIM + 8 * c8);
+    }
+  }
+  __syncthreads();
+  const uint2* lut2 = reinterpret_cast<const uint2*>(lut);
+  const int lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
+  const int Lq = max(0, min(32, p.qoff[b + 1] - p.qoff[b] - 32 * qt0));
+  const int nsel = p.nsel[b];
+  const uint64_t cut = p.cut ? p.cut[b] : 0ull;
+  const bool fast = p.fast_ok != 0 && p.qflag[b] == 0;
+  if (qt0 > 0 && Lq == 0) return;
+  const __bf16* qh = &sQh[li * QS + kk * (DIM / 2)];
+  const __bf16* ql = &sQl[SPLIT == 3 ? li * QS + kk * (DIM / 2) : 0];
+  const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP) + 128 * qt0 + 16 * kk;
+  const uint32_t row_bytes = (uint32_t)LQP * 4u;
+  for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
+    const int j = (bx * 4 + wave) * NP_EXACT_DPW + dd;
+    if (j >= nsel) break;
+    const int64_t oj = (int64_t)b * p.n_sel + j;
+    if (p.sel_keys[oj] < cut) {
+      if (lane == 0) p.exact[oj] = 0.f;
+      continue;
+    }
+    const float prior = p.acc ? p.exact[oj] : 0.f;
+    const uint32_t doc = p.sel_doc[oj];
+    const int64_t off = p.doc_off[doc];
+    const int len = (int)(p.doc_off[doc + 1] - off);
+    float m[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[r] = NP_NEG_INF;
+    // pipeline: codes two tiles ahead, C-in rows + residual words + 1/n one tile ahead
+    auto tok_of = [&](int t0) { return off + min(t0 + li, len - 1); };
+    uint32_t code1 = 0, code2 = 0;      // codes of tiles t+1, t+2
+    uint32_t rw_n[NW];
+    float rn_n = 0.f;
+    float4 cin_n[4];
+    auto load_rest = [&](int t0) {      // residual words and 1/n of tile t0
+      const bool valid = t0 + li < len;
+      const int64_t tok = tok_of(t0);
+      rn_n = valid ? p.inv_norm[tok] : __builtin_nanf("");
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(p.residuals + tok * PD + kk * PH);
+      if constexpr (NW % 4 == 0) {
+#pragma unroll
+        for (int w4 = 0; w4 < NW / 4; ++w4) {
+          const uint4 v = reinterpret_cast<const uint4*>(rp)[w4];
+          rw_n[4 * w4] = v.x; rw_n[4 * w4 + 1] = v.y; rw_n[4 * w4 + 2] = v.z; rw_n[4 * w4 + 3] = v.w;
+        }
+      } else if constexpr (NW % 2 == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < NW / 2; ++w2) {
+          const uint2 v = reinterpret_cast<const uint2*>(rp)[w2];
+          rw_n[2 * w2] = v.x; rw_n[2 * w2 + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int w1 = 0; w1 < NW; ++w1) rw_n[w1] = rp[w1];
+      }
+    };
+    auto load_cin = [&](uint32_t code) {   // rows q = 8g + 4kk + (0..3) of the token's QCT row: four float4
+      const char* qrow = QCb + code * row_bytes;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) cin_n[g] = *reinterpret_cast<const float4*>(qrow + 32 * g);
+    };
+    if (len > 0) {
+      const uint32_t code0 = p.codes[tok_of(0)];
+      code1 = p.codes[tok_of(32)];
+      load_rest(0);
+      load_cin(code0);
+    }
+    for (int t0 = 0; t0 < len; t0 += 32) {
+      const float rn = rn_n;
+      uint32_t rw[NW];
+#pragma unroll
+      for (int w1 = 0; w1 < NW; ++w1) rw[w1] = rw_n[w1];
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        acc[4 * g] = cin_n[g].x; acc[4 * g + 1] = cin_n[g].y; acc[4 * g + 2] = cin_n[g].z; acc[4 * g + 3] = cin_n[g].w;
+      }
+      if (t0 + 32 < len) {        // next tile: its code arrived a tile ago
+        code2 = p.codes[tok_of(t0 + 64)];
+        load_rest(t0 + 32);
+        load_cin(code1);
+        code1 = code2;
+      }
+      // k-steps: the query fragments of step s+1 are read from LDS while step s runs; a scheduling barrier per step keeps
+      // the compiler from hoisting every step's LDS reads (fragments + LUT words) to the top of the tile (that is the 64
+      // VGPRs this kernel exists to give back)
+      bf16x8 bh_c = *reinterpret_cast<const bf16x8*>(qh), bl_c = bh_c;
+      if constexpr (SPLIT == 3) bl_c = *reinterpret_cast<const bf16x8*>(ql);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        bf16x8 bh_n = bh_c, bl_n = bl_c;
+        if (s + 1 < NS) {
+          bh_n = *reinterpret_cast<const bf16x8*>(qh + 8 * (s + 1));
+          if constexpr (SPLIT == 3) bl_n = *reinterpret_cast<const bf16x8*>(ql + 8 * (s + 1));
+        }
+        uint32_t wh[4], wl[4];
+        if constexpr (NBITS == 4) {
+          const uint32_t word = rw[s];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint2 e = lut2[(word >> (8 * i)) & 0xFFu];
+            wh[i] = e.x;
+            wl[i] = e.y;
+          }
+        } else {
+          const uint32_t word = rw[s >> 1] >> (16 * (s & 1));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const uint32_t byte = (word >> (8 * i)) & 0xFFu;
+            const uint2 e0 = lut2[byte * 2], e1 = lut2[byte * 2 + 1];
+            wh[2 * i] = e0.x; wl[2 * i] = e0.y;
+            wh[2 * i + 1] = e1.x; wl[2 * i + 1] = e1.y;
+          }
+        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 vh = {wh[0], wh[1], wh[2], wh[3]};
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, vh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_c, ah, acc, 0, 0, 0);   // rows = q, cols = tokens
+        if constexpr (SPLIT == 3) {
+          const u32x4 vl = {wl[0], wl[1], wl[2], wl[3]};
+          const bf16x8 al = __builtin_bit_cast(bf16x8, vl);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_c, al, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl_c, ah, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bh_c = bh_n;
+        bl_c = bl_n;
+      }
+      if (fast) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[r] * rn;
+          asm("v_max_f32 %0, %1, %2" : "=v"(m[r]) : "v"(m[r]), "v"(x));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[r] * rn;
+          m[r] = fmaxf(m[r], x + (x - x));
+        }
+      }
+    }
+    float total = prior;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = m[r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+      m[r] = v;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = 8 * g + 4 * hk + e;
+          const float x = readlane_f(m[4 * g + e], hk * 32);
+          if (q < Lq && x > NP_NEG_INF) total += x;
+        }
+    if (lane == 0) p.exact[oj] = total;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // S7  stable top-k by (exact desc [finite first], approx rank asc)   (search.rs:496-515)
 // ---------------------------------------------------------------------------------------------

@@ -255,8 +255,16 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
       for (int qt = 0; qt < p.LQP / 32; ++qt) {
         px.qt0 = qt;
         px.acc = qt > 0;
-        if (precision == 1) exact_qct_kernel<DIM, NBITS, 1, 1><<<grid, 256, 0, st>>>(px);
-        else exact_qct_kernel<DIM, NBITS, 1, 3><<<grid, 256, 0, st>>>(px);
+        if (ix->tune.s6_lds == 2) {   // query fragments in LDS, C-in rows one tile ahead; registers cut for 4 waves per SIMD
+          if (precision == 1) exact_qcl_kernel<DIM, NBITS, 1, 4><<<grid, 256, 0, st>>>(px);
+          else exact_qcl_kernel<DIM, NBITS, 3, 4><<<grid, 256, 0, st>>>(px);
+        } else if (ix->tune.s6_lds == 1) {   // the same at 3 waves per SIMD (no spills)
+          if (precision == 1) exact_qcl_kernel<DIM, NBITS, 1, 3><<<grid, 256, 0, st>>>(px);
+          else exact_qcl_kernel<DIM, NBITS, 3, 3><<<grid, 256, 0, st>>>(px);
+        } else {
+          if (precision == 1) exact_qct_kernel<DIM, NBITS, 1, 1><<<grid, 256, 0, st>>>(px);
+          else exact_qct_kernel<DIM, NBITS, 1, 3><<<grid, 256, 0, st>>>(px);
+        }
       }
     } else if (NQT <= 2 && !ix->tune.exact_rowmax) {
       ExactP px = p;
