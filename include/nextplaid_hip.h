@@ -55,7 +55,8 @@ typedef struct np_open_opts {
                            larger batches are processed in slices */
   int32_t max_query_tokens; /* per-query token cap used to size workspaces (default 64;
                            grows automatically, this is only the initial reservation) */
-  int64_t workspace_bytes;  /* soft cap for per-context scratch (0 = default 8 GiB) */
+  int64_t workspace_bytes;  /* soft cap for per-context scratch (0 = default: the HBM left free by the resident index,
+                               shared by the contexts, between 2 and 16 GiB) */
 } np_open_opts;
 
 /* Mirrors SearchParameters (search.rs:26-69).  batch_size is unused by search and omitted. */

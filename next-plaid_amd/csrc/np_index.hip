@@ -58,7 +58,7 @@ int normalise_opts(const np_open_opts* in, np_open_opts* o) {
   if (o->n_contexts > 16) o->n_contexts = 16;
   if (o->max_batch <= 0) o->max_batch = 64;
   if (o->max_query_tokens <= 0) o->max_query_tokens = 64;
-  if (o->workspace_bytes <= 0) o->workspace_bytes = (int64_t)8 << 30;
+  // workspace_bytes <= 0: chosen when the index is resident (default_workspace: up to 16 GiB per context of what is free)
   return NP_OK;
 }
 
@@ -98,6 +98,21 @@ void read_tuning_env(Tuning* t) {
     const char* e = getenv(k[0]);
     if (e && *e) (void)set_tuning(t, k[1], atoi(e));
   }
+}
+
+// Default per-context scratch budget: what the device has free once the index is resident, shared by the contexts, between
+// 2 and 16 GiB.  The candidate pool is sized by it; the host enqueues the worst-case number of pool rounds of a batch
+// (B x n_docs entries / pool) and the empty ones cost ~45 us of launches each: 16 GiB is 3 rounds at 10 M documents where
+// 8 GiB was 6.  A 12.5 M x 300-token shard (268 GB) leaves 12 GiB per context with three contexts.
+static void default_workspace(DeviceIndex* ix) {
+  if (ix->opts.workspace_bytes > 0) return;
+  size_t free_b = 0, total_b = 0;
+  int64_t ws = (int64_t)8 << 30;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const int64_t share = ((int64_t)free_b - ((int64_t)4 << 30)) / std::max(ix->opts.n_contexts, 1);
+    ws = std::min<int64_t>((int64_t)16 << 30, std::max<int64_t>((int64_t)2 << 30, share));
+  }
+  ix->opts.workspace_bytes = ws;
 }
 
 static int check_device(int dev) {
@@ -713,6 +728,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     NP_TRY(rc);
   }
   NP_TRY(build_inv_norm(ix));
+  default_workspace(ix);
   cleanup.p = nullptr;
   *out = ix;
   return NP_OK;
@@ -1082,6 +1098,7 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     NP_TRY(rc);
   }
   NP_TRY(build_inv_norm(ix));
+  default_workspace(ix);
   cleanup.p = nullptr;
   *out = ix;
   return NP_OK;

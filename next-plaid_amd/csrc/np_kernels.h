@@ -2305,6 +2305,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
   unsigned long long toks = 0, ucnt = 0, rows = 0;
+  // the scan reads whole 4-code groups and looks every code up in the bitmap, also past a list's end: the staging area
+  // must never hold anything but codes (< K), so it starts zeroed (afterwards it only ever receives list entries)
+  for (int i = tid; i < (int)(sizeof(s_codes) / 4); i += 256) reinterpret_cast<uint32_t*>(&s_codes[0][0][0])[i] = 0u;
   for (int step = 0;; ++step) {
     __syncthreads();
     if (tid == 0)
@@ -2415,27 +2418,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         if (!(probe & 2)) {
           const int start = jl == 0 ? 0 : part, end = jl == 0 ? min(part, cnt) : cnt;
           const int itmax = (((min(nmax - p0, CAP) + 1) >> 1) + 3) & ~3;   // >= every document's half
+          // Every staged position holds a valid code (< K: the staging reads only list entries or the zero padding of the
+          // array), so the bitmap read needs no clamp; a cold code is written too, at a position the next hot code (or
+          // nobody) overwrites -- wpos never passes the codes already in registers -- so the loop body has no branch.
           int wpos = start;
+          int rem = jl < 2 ? end - start : 0;     // codes this lane still has to test
           for (int it = 0; it < itmax; it += 4) {
-            const int pos = start + it;
-            const bool act = jl < 2 && pos < end;
+            const int pos = min(start + it, CAP - 4);
             uint32_t c[4];
             if constexpr (sizeof(CT) == 2) {
-              const uint2 w2 = *reinterpret_cast<const uint2*>(row + (act ? pos : 0));
+              const uint2 w2 = *reinterpret_cast<const uint2*>(row + pos);
               c[0] = w2.x & 0xFFFFu; c[1] = w2.x >> 16; c[2] = w2.y & 0xFFFFu; c[3] = w2.y >> 16;
             } else {
-              const uint4 w4 = *reinterpret_cast<const uint4*>(row + (act ? pos : 0));
+              const uint4 w4 = *reinterpret_cast<const uint4*>(row + pos);
               c[0] = w4.x; c[1] = w4.y; c[2] = w4.z; c[3] = w4.w;
             }
             uint32_t bw[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bw[k] = s_bits[min(c[k], (uint32_t)(KP - 1)) >> 5];   // past the list: any word (masked below)
+            for (int k = 0; k < 4; ++k) bw[k] = s_bits[c[k] >> 5];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const bool h = act && pos + k < end && ((bw[k] >> (c[k] & 31)) & 1u);
-              if (h) row[wpos] = (CT)c[k];
-              wpos += h ? 1 : 0;
+              const uint32_t h = (k < rem) ? ((bw[k] >> (c[k] & 31)) & 1u) : 0u;
+              if (rem > 0) row[wpos] = (CT)c[k];
+              wpos += (int)h;
             }
+            rem -= 4;
           }
           hmine = wpos - start;
         }

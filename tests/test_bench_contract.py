@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_default_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default_10m.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default_10m.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -25,7 +25,7 @@ def test_default_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["traffic"] is None or (r["traffic"] > 0 and r["traffic_source"]["kernels_sha"])   # counters name the build they belong to
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -35,7 +35,7 @@ def test_default_line_has_the_contract_fields():
 
 def test_traffic_file_is_keyed_by_workload():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert t["docs_per_gpu"] == 10_000_000
+    assert t["docs_per_gpu"] == 10_000_000 and len(t["kernels_sha"]) == 16     # bench.py drops the counters of another build
     for k in ("qc_gemm(S1)", "probe(S2)", "candidates(S3)", "approx(S4)", "select(S5)", "exact(S6)"):
         assert t[k] > 0, k
 

@@ -1,11 +1,51 @@
 #!/usr/bin/env python3
-"""Regenerates the measured tables of DESIGN.md (between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r02_*.json."""
+"""Installs the evidence of a final GPU call under profiles/ and regenerates the measured tables of DESIGN.md
+(between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r03_*.
+
+  design_tables.py install <gpurun_out tag>     copy gpurun_out/<tag>/... to profiles/r03_* (names below)
+  design_tables.py                              regenerate the tables from profiles/r03_*
+"""
 import json
 import os
 import re
+import shutil
+import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 P = os.path.join(ROOT, "profiles") + "/"
+R = "r03"
+
+GROUPS = {
+    f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
+    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m"],
+    f"{R}_bench_regimes.jsonl": ["dist05", "dist08", "dist08_single", "lq48_10m", "lq48_1m", "nfs8192_10m", "k19_10m", "c3_np32", "c3_np8"],
+}
+SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k"}
+
+
+def install(tag):
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    for dst, name in SINGLES.items():
+        shutil.copy(os.path.join(src, f"b_{name}.json"), P + dst)
+    for dst, names in GROUPS.items():
+        with open(P + dst, "w") as f:
+            for n in names:
+                p = os.path.join(src, f"b_{n}.json")
+                if not os.path.exists(p) or os.path.getsize(p) == 0:
+                    print("missing", n)
+                    continue
+                d = json.load(open(p))
+                d["name"] = n
+                f.write(json.dumps(d) + "\n")
+    for a, b in (("stats_d10m.md", f"{R}_kernel_stats_10m.md"), ("stats_d10m.csv", f"{R}_kernel_stats_10m.csv"),
+                 ("stats_d1m.md", f"{R}_kernel_stats_1m.md"), ("stats_d1m.csv", f"{R}_kernel_stats_1m.csv"),
+                 ("pmc_d10m.md", f"{R}_pmc_10m.md"), ("traffic_d10m.json", "traffic.json"), ("host.txt", f"{R}_host.txt")):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copy(os.path.join(src, a), P + b)
+    with open(P + f"{R}_test_gpu.log", "w") as f:
+        for a in ("test_all.log", "smoke.log"):
+            if os.path.exists(os.path.join(src, a)):
+                f.write(open(os.path.join(src, a)).read())
 
 
 def load(n):
@@ -13,67 +53,118 @@ def load(n):
 
 
 def lines(n):
-    return [json.loads(l) for l in open(P + n) if l.strip()]
+    return {json.loads(l)["name"]: json.loads(l) for l in open(P + n) if l.strip()}
 
 
-d10, d1, tr = load("r02_bench_default_10m.json"), load("r02_bench_1m.json"), load("traffic.json")
-rows = [("S1 `qc_gemm`", "qc_gemm(S1)", "ms_centroid"), ("S2 probe", "probe(S2)", "ms_probe"),
-        ("S3 candidates", "candidates(S3)", "ms_candidates"), ("S4 filter + exact survivors", "approx(S4)", "ms_approx"),
-        ("S5 select", "select(S5)", "ms_select"), ("S6 exact (prec 2)", "exact(S6)", "ms_exact")]
-t = ["| stage | 10 M docs: ms / batch | achieved vs §8(d) algorithmic roofline | 1 M docs: ms / batch | achieved |", "|---|---:|---|---:|---|"]
-for name, k, ms in rows:
-    a, b = d10["roofline"]["all"][k], d1["roofline"]["all"][k]
-    t.append(f"| {name} | {d10['stages'][ms]:.3f} | {a['achieved']:.0f} {a['unit']} = {100*a['frac']:.1f} % of {a['bound'].upper()} peak | "
-             f"{d1['stages'][ms]:.3f} | {b['achieved']:.0f} {b['unit']} = {100*b['frac']:.1f} % |")
-t.append(f"| S7 top-k | {d10['stages']['ms_topk']:.3f} | | {d1['stages']['ms_topk']:.3f} | |")
-t.append(f"| **one batch alone (p50)** | **{d10['p50_batch_latency_ms']:.2f}** | | **{d1['p50_batch_latency_ms']:.2f}** | |")
-t.append(f"| **sustained, 3 streams** | **{d10['ms_per_step']:.2f} → {d10['value']:.0f} queries/s** | PCIe-inclusive {d10['value_pcie_inclusive']:.0f} | "
-         f"**{d1['ms_per_step']:.2f} → {d1['value']:.0f} queries/s** | PCIe-inclusive {d1['value_pcie_inclusive']:.0f} |")
-s10, s1 = d10["stages"], d1["stages"]
-t += ["", f"Per batch of 64 queries at 10 M documents: {s10['n_cells']:.0f} probed cells, {s10['n_ivf_ids']/1e6:.1f} M posting entries, "
-          f"{s10['n_candidates']/1e6:.1f} M candidates ({s10['n_candidates']/64/1e3:.0f} k / query), {s10['n_cand_tokens']/1e9:.2f} G candidate tokens → "
-          f"{s10['n_cand_codes']/1e6:.0f} M distinct (doc, code) rows gathered by the filter, {s10['n_survivors']/1e3:.0f} k survivors, "
-          f"{s10['n_exact_docs']:.0f} docs / {s10['n_exact_tokens']/1e6:.2f} M tokens exact-scored. At 1 M: {s1['n_candidates']/1e6:.2f} M candidates, "
-          f"{s1['n_cand_codes']/1e6:.1f} M rows, {s1['n_survivors']/1e3:.0f} k survivors. Index build in HBM {d10['index_build_s']:.1f} s (10 M), "
-          f"{d1['index_build_s']:.2f} s (1 M). CPU baseline (oracle C restatement, {d10['cpu_baseline']['cores']} threads, {d10['cpu_baseline']['cpu_model']}): "
-          f"{d10['cpu_baseline']['value']:.1f} queries/s at 10 M, {d1['cpu_baseline']['value']:.1f} at 1 M. `roofline.traffic` (PMC, 10 M): "
-          f"S4 {tr['approx(S4)']/1e9:.2f} GB, S6 {tr['exact(S6)']/1e9:.2f} GB, S3 {tr['candidates(S3)']/1e9:.2f} GB per batch.", "",
-      f"Round 1 → round 2 on the config-2 workload (1 M documents): 27.1 k → {d1['value']/1e3:.1f} k queries/s, S4 0.83 → {s1['ms_approx']:.2f} ms, "
-      f"S6 0.72 → {s1['ms_exact']:.2f} ms, S2 0.34 → {s1['ms_probe']:.2f} ms; the 10 M-document configuration did not run at all in round 1 (u32 row "
-      f"offsets, `B × n_docs` workspace) and went 4.4 k (first working state, `profiles/r02a_bench_10m_prefilter.json`) → {d10['value']/1e3:.1f} k "
-      f"queries/s this round."]
-measured = "\n".join(t)
+def stage_cells(s):
+    return (f"{s['ms_centroid']:.2f} | {s['ms_probe']:.2f} | {s['ms_candidates']:.2f} | {s['ms_approx']:.2f} | {s['ms_select']:.2f} | "
+            f"{s['ms_exact']:.2f}")
 
-v = lines("r02_bench_variants_10m.jsonl")
-names = ["precision 2 (default; split-bf16 QC-reuse)", "precision 0 (exact-f32 MFMA everywhere)", "precision 1 (bf16 QC-reuse)",
-         "precision 3 (plain bf16 MaxSim)", "precision 2, t_cs = None"]
-c5 = ["| 10 M docs, B = 64 | queries/s | p50 ms | S6 ms | max rel. score error vs oracle | top-10 ids identical |", "|---|---:|---:|---:|---:|---:|"]
-for n, d in zip(names, v):
-    pv = d["parity_vs_oracle"]
-    c5.append(f"| {n} | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {d['stages']['ms_exact']:.2f} | {pv['max_rel_score_err']:.1e} | "
-              f"{pv['topk_ids_identical']}/{pv['queries']} |")
-tn = v[4]["stages"]
-c5 += ["", f"(Top-1 identical 64/64 in every row; the ids that differ under precision 1/3 are near-ties inside the stated tolerance. With `t_cs = None` "
-           f"every probed cell counts: {tn['n_candidates']/64/1e6:.1f} M of the 10 M documents are candidates of each query, {tn['n_cand_codes']/1e9:.1f} G "
-           f"rows per batch, {tn['n_rounds']:.0f} pool rounds.)"]
-c5 = "\n".join(c5)
 
-sh = lines("r02_bench_shard_sizes.jsonl")
-st = ["| documents on the GPU (= one rank of) | queries/s | p50 ms | S1 | S2 | S3 | S4 | S5 | S6 |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
-lab = ["10 M (1 GPU, the N=1 line)", "5 M (2-way)", "2.5 M (4-way)", "1.25 M (8-way)", "1.25 M, through `np_hip_search_batch_sharded` (RCCL, world 1)"]
-for l, d in zip(lab, [d10] + sh):
-    s = d["stages"]
-    st.append(f"| {l} | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {s['ms_centroid']:.2f} | {s['ms_probe']:.2f} | {s['ms_candidates']:.2f} | "
-              f"{s['ms_approx']:.2f} | {s['ms_select']:.2f} | {s['ms_exact']:.2f} |")
-st += ["", "(Single-GPU runs of a corpus of that size: S6 is the full `n_sel` here, whereas a rank of the real split exact-scores only its share of the global cut.)"]
-st = "\n".join(st)
+def tables():
+    d10, d1, tr = load(f"{R}_bench_default_10m.json"), load(f"{R}_bench_1m.json"), load("traffic.json")
+    rows = [("S1 `qc_gemm` (+ hot prep)", "qc_gemm(S1)", "ms_centroid"), ("S2 probe", "probe(S2)", "ms_probe"),
+            ("S3 candidates", "candidates(S3)", "ms_candidates"), ("S4 two-level filter + exact survivors", "approx(S4)", "ms_approx"),
+            ("S5 select", "select(S5)", "ms_select"), ("S6 exact (prec 2)", "exact(S6)", "ms_exact")]
+    t = ["| stage | 10 M docs: ms / batch | achieved vs §8(d) algorithmic roofline | 1 M docs: ms / batch | achieved |", "|---|---:|---|---:|---|"]
+    for name, k, ms in rows:
+        a, b = d10["roofline"]["all"][k], d1["roofline"]["all"][k]
+        t.append(f"| {name} | {d10['stages'][ms]:.3f} | {a['achieved']:.0f} {a['unit']} = {100*a['frac']:.1f} % of {a['bound'].upper()} peak | "
+                 f"{d1['stages'][ms]:.3f} | {b['achieved']:.0f} {b['unit']} = {100*b['frac']:.1f} % |")
+    t.append(f"| S7 top-k | {d10['stages']['ms_topk']:.3f} | | {d1['stages']['ms_topk']:.3f} | |")
+    t.append(f"| **one batch alone (p50)** | **{d10['p50_batch_latency_ms']:.2f}** | | **{d1['p50_batch_latency_ms']:.2f}** | |")
+    t.append(f"| **sustained, 3 streams** | **{d10['ms_per_step']:.2f} → {d10['value']:.0f} queries/s** | PCIe-inclusive {d10['value_pcie_inclusive']:.0f} | "
+             f"**{d1['ms_per_step']:.2f} → {d1['value']:.0f} queries/s** | PCIe-inclusive {d1['value_pcie_inclusive']:.0f} |")
+    s10, s1 = d10["stages"], d1["stages"]
+    cb10, cb1 = d10["cpu_baseline"], d1["cpu_baseline"]
+    t += ["", f"Per batch of 64 queries at 10 M documents: {s10['n_cells']:.0f} probed cells, {s10['n_ivf_ids']/1e6:.1f} M posting entries, "
+              f"{s10['n_candidates']/1e6:.1f} M candidates ({s10['n_candidates']/64/1e3:.0f} k / query), {s10['n_cand_tokens']/1e9:.2f} G candidate tokens = "
+              f"{s10['n_cand_dcodes']/1e6:.0f} M distinct (document, code) pairs scanned by the hot level → {s10['n_cand_codes']/1e6:.0f} M u8 table rows gathered "
+              f"(both levels), {s10['n_level2']/1e6:.2f} M documents at the exact level, {s10['n_survivors']/1e3:.0f} k survivors, "
+              f"{s10['n_exact_docs']:.0f} docs / {s10['n_exact_tokens']/1e6:.2f} M tokens exact-scored. At 1 M: {s1['n_candidates']/1e6:.2f} M candidates, "
+              f"{s1['n_cand_codes']/1e6:.1f} M rows, {s1['n_survivors']/1e3:.0f} k survivors. Index build in HBM {d10['index_build_s']:.1f} s (10 M), "
+              f"{d1['index_build_s']:.2f} s (1 M); {d10['hbm_bytes_per_token']:.1f} B per token. CPU baseline (oracle C restatement, {cb10['cores']} threads, "
+              f"{cb10['cpu_model']}): {cb10['value']:.1f} queries/s at 10 M, {cb1['value']:.1f} at 1 M. `roofline.traffic` (PMC, 10 M): "
+              f"S4 {tr['approx(S4)']/1e9:.2f} GB, S6 {tr['exact(S6)']/1e9:.2f} GB, S3 {tr['candidates(S3)']/1e9:.2f} GB per batch.", "",
+          f"Round 2 → round 3: 10 M documents 10.9 k → {d10['value']/1e3:.1f} k queries/s (p50 6.21 → {d10['p50_batch_latency_ms']:.2f} ms, S4 4.54 → "
+          f"{s10['ms_approx']:.2f} ms, index 231 → {d10['hbm_index_bytes']/1e9:.0f} GB); 1 M documents 37.0 k → {d1['value']/1e3:.1f} k queries/s "
+          f"(S4 0.72 → {s1['ms_approx']:.2f} ms)."]
+    measured = "\n".join(t)
 
-path = os.path.join(ROOT, "DESIGN.md")
-x = open(path).read()
-for tag, body in (("measured", measured), ("c5", c5), ("shards", st)):
-    x, n = re.subn(rf"<!-- BEGIN:{tag} -->\n.*?\n<!-- END:{tag} -->", lambda m: f"<!-- BEGIN:{tag} -->\n{body}\n<!-- END:{tag} -->", x, flags=re.S)
-    assert n == 1, tag
-open(path, "w").write(x)
-c3 = load("r02_bench_c3_shape.json")
-print("c3:", c3["value"], c3["p50_batch_latency_ms"], c3["parity_vs_oracle"], c3["cpu_baseline"]["value"], c3["stages"]["ms_centroid"],
-      c3["roofline"]["all"]["qc_gemm(S1)"]["frac"])
+    reg = lines(f"{R}_bench_regimes.jsonl")
+    var = lines(f"{R}_bench_variants_10m.jsonl")
+
+    def par(d):
+        pv = d.get("parity_vs_oracle")
+        return "—" if not pv else f"{pv['topk_ids_identical']}/{pv['queries']}"
+
+    dist = ["| distinct codes per token (`--rand256`) | candidates / query | u8 rows / batch | queries/s | S3 ms | S4 ms | top-10 = oracle |", "|---|---:|---:|---:|---:|---:|---:|"]
+    for lab, d in (("0.23 (51, the default corpus)", d10), ("0.50 (121)", reg.get("dist05")), ("0.80 (200)", reg.get("dist08")),
+                   ("0.80, single-level filter (`NP_S4_HOT=0`)", reg.get("dist08_single"))):
+        if not d:
+            continue
+        s = d["stages"]
+        dist.append(f"| {lab} | {s['n_candidates']/64/1e3:.0f} k | {s['n_cand_codes']/1e6:.0f} M | {d['value']:.0f} | {s['ms_candidates']:.2f} | {s['ms_approx']:.2f} | {par(d)} |")
+    dist = "\n".join(dist)
+
+    rg = ["| line (10 M docs × 300 tok unless stated) | queries/s | p50 ms | S1 | S2 | S3 | S4 | S5 | S6 | CPU oracle q/s | top-10 = oracle |",
+          "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    labs = [("lq48_10m", "48-token queries (ONNX encoder default, `next-plaid-onnx/src/lib.rs:628-630`)"),
+            ("lq48_1m", "48-token queries, 1 M docs"),
+            ("nfs8192_10m", "`n_full_scores = 8192` (ColGREP, `colgrep/src/index/mod.rs:771-777`)"),
+            ("k19_10m", "K = 2¹⁹ (the crate's k-means heuristic at this size, `kmeans.rs:303-309`): batched path"),
+            ("c3_np32", "config 3 shape: 8 841 823 docs, clipped LogNormal lengths (mean 73, max 180), K = 2¹⁸, nbits 2, nprobe 32"),
+            ("c3_np8", "config 3 shape, nprobe 8")]
+    for k, lab in labs:
+        d = reg.get(k)
+        if not d:
+            continue
+        cpu = (d.get("cpu_baseline") or {}).get("value")
+        rg.append(f"| {lab} | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {stage_cells(d['stages'])} | {'—' if not cpu else f'{cpu:.1f}'} | {par(d)} |")
+    c4 = load(f"{R}_bench_c4_shard_12500k.json")
+    cpu = (c4.get("cpu_baseline") or {}).get("value")
+    rg.append(f"| config 4's shard: 12.5 M docs on one GPU ({c4['hbm_index_bytes']/1e9:.1f} GB, {c4['hbm_bytes_per_token']:.1f} B/token) | {c4['value']:.0f} | "
+              f"{c4['p50_batch_latency_ms']:.2f} | {stage_cells(c4['stages'])} | {'—' if not cpu else f'{cpu:.1f}'} | {par(c4)} |")
+    rg = "\n".join(rg)
+
+    c5 = ["| 10 M docs, B = 64 | queries/s | p50 ms | S4 ms | S6 ms | max rel. score error vs oracle | top-10 ids identical |", "|---|---:|---:|---:|---:|---:|---:|"]
+    for lab, d in (("precision 2 (default; split-bf16 QC-reuse)", d10), ("precision 0 (exact-f32 MFMA everywhere)", var.get("prec0")),
+                   ("precision 1 (bf16 QC-reuse)", var.get("prec1")), ("precision 3 (plain bf16 MaxSim)", var.get("prec3")),
+                   ("precision 2, single-level filter (`NP_S4_HOT=0`)", var.get("single_level_10m")), ("precision 2, t_cs = None", var.get("tcs_none"))):
+        if not d:
+            continue
+        pv = d["parity_vs_oracle"]
+        c5.append(f"| {lab} | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {d['stages']['ms_approx']:.2f} | {d['stages']['ms_exact']:.2f} | "
+                  f"{pv['max_rel_score_err']:.1e} | {pv['topk_ids_identical']}/{pv['queries']} |")
+    c5 = "\n".join(c5)
+
+    sh = lines(f"{R}_bench_shard_sizes.jsonl")
+    st = ["| documents on the GPU (= one rank of) | queries/s | p50 ms | S1 | S2 | S3 | S4 | S5 | S6 |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    for lab, d in (("10 M (1 GPU, the N=1 line)", d10), ("5 M (2-way)", sh.get("shard_5m")), ("2.5 M (4-way)", sh.get("shard_2500k")),
+                   ("1.25 M (8-way)", sh.get("shard_1250k")), ("1.25 M, through `np_hip_search_batch_sharded` (RCCL, world 1)", sh.get("shard_1250k_rccl"))):
+        if d:
+            st.append(f"| {lab} | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {stage_cells(d['stages'])} |")
+    st += ["", "(Single-GPU runs of a corpus of that size: S6 is the full `n_sel` here, whereas a rank of the real split exact-scores only its share of the global cut.)"]
+    st = "\n".join(st)
+
+    hy = ["| 8 GPUs as | per-GPU line | projected queries/s | batch latency |", "|---|---|---:|---:|"]
+    for S, k, lab in ((8, "shard_1250k", "1.25 M"), (4, "shard_2500k", "2.5 M"), (2, "shard_5m", "5 M"), (1, None, "10 M")):
+        d = d10 if k is None else sh.get(k)
+        if d:
+            hy.append(f"| {S} shard(s) × {8 // S} replica group(s) | {lab} docs: {d['value']:.0f} q/s | {8 // S * d['value']:.0f} | ≈ {d['p50_batch_latency_ms']:.1f} ms + collectives |")
+    hy += ["", "(Upper bounds: the collectives of S > 1 are not in the one-GPU lines; S = 1 has none. Pure sharding minimises latency, pure replication maximises throughput.)"]
+    hy = "\n".join(hy)
+
+    path = os.path.join(ROOT, "DESIGN.md")
+    x = open(path).read()
+    for tag, body in (("measured", measured), ("distinct", dist), ("regimes", rg), ("c5", c5), ("shards", st), ("hybrid", hy)):
+        x, n = re.subn(rf"<!-- BEGIN:{tag} -->\n.*?<!-- END:{tag} -->", lambda m: f"<!-- BEGIN:{tag} -->\n{body}\n<!-- END:{tag} -->", x, flags=re.S)
+        assert n == 1, tag
+    open(path, "w").write(x)
+    print("tables written")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "install":
+        install(sys.argv[2])
+    tables()

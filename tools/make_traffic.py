@@ -26,7 +26,7 @@ STAGE = {
     "approx_xcd_kernel": "approx(S4)", "approx_kernel": "approx(S4)", "approx_stream_kernel": "approx(S4)",
     "approx_matvec_kernel": "approx(S4)", "gcut_kernel": "approx(S4)",
     "select_kernel": "select(S5)",
-    "exact_qct_kernel": "exact(S6)", "exact_qc_kernel": "exact(S6)", "exact_f32_kernel": "exact(S6)", "exact_bf16_kernel": "exact(S6)",
+    "exact_qct_kernel": "exact(S6)", "exact_qcl_kernel": "exact(S6)", "exact_qc_kernel": "exact(S6)", "exact_f32_kernel": "exact(S6)", "exact_bf16_kernel": "exact(S6)",
     "topk_kernel": "topk(S7)",
 }
 
