@@ -297,9 +297,48 @@ __global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __rest
   if (tid == 0 && !ucodes) ulen[d] = base;
 }
 
-__global__ void ulen_padded_kernel(const int32_t* __restrict__ ulen, int64_t n, int64_t* __restrict__ out) {
+// ---- list layout (round 3, second step): one fixed-stride BLOCK per document + an overflow region ---------------------
+// d_ucodes = [ n_docs blocks of S entries | overflow lists ].  Block d = a 16-byte header {u32 #distinct codes, u32
+// document length, u32 overflow index, u32 0} followed by the document's sorted distinct codes when they fit the block
+// (#distinct <= S - HDR entries); a longer list lives in the overflow region (4-entry aligned, at overflow index * 4) and
+// the block carries only the header.  S is chosen at open: a multiple of 64 bytes that holds 99 % of the lists (at most 256
+// bytes: one 8-byte load per lane of half a wave).  With the block address computable from the document id, the hot level of the
+// S4 filter needs NO per-candidate record: S3 hands it bare document ids and the 16-byte record gather of compact_kernel
+// (one 128-byte line per candidate at 1.9 % density, 0.32 ms per batch at 10 M documents) disappears; the header arrives
+// with the list.  Every other consumer keeps addressing lists through the 40-bit offset of doc_meta / the records.
+#define NP_UBLOCK_MAX_U16 128   // entries (256 B: one 8-byte load per lane of half a wave): 8 header + 120 codes
+#define NP_UBLOCK_MAX_U32 64    // entries (256 B): 4 header + 60 codes
+
+__global__ void ulen_hist_kernel(const int32_t* __restrict__ ulen, int64_t n, uint32_t* __restrict__ hist /* [130]: 0..128, >128 */) {
+  __shared__ uint32_t s_h[130];
+  if (threadIdx.x < 130) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&s_h[min(ulen[i], 129)], 1u);
+  __syncthreads();
+  if (threadIdx.x < 130 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+// overflow entries of document i (its whole list, 4-entry aligned) or 0 when the list fits its block
+__global__ void ulen_overflow_kernel(const int32_t* __restrict__ ulen, int64_t n, int fit, int64_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = ((int64_t)ulen[i] + NP_ULIST_ALIGN - 1) / NP_ULIST_ALIGN * NP_ULIST_ALIGN;
+  if (i < n) out[i] = ulen[i] > fit ? ((int64_t)ulen[i] + NP_ULIST_ALIGN - 1) / NP_ULIST_ALIGN * NP_ULIST_ALIGN : 0;
+}
+
+// uoff[d] = entry offset of document d's list; the block header of d
+__global__ void ublock_layout_kernel(int64_t n, const int64_t* __restrict__ doc_off, const int32_t* __restrict__ ulen,
+                                     const int64_t* __restrict__ ovf_incl /* inclusive scan of the overflow sizes */,
+                                     int S, int hdr, int fit, int64_t base_b, void* __restrict__ ucodes, int wide,
+                                     int64_t* __restrict__ uoff) {
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const int32_t u = ulen[d];
+  const bool ovf = u > fit;
+  const int64_t ovf_size = ovf ? ((int64_t)u + NP_ULIST_ALIGN - 1) / NP_ULIST_ALIGN * NP_ULIST_ALIGN : 0;
+  const int64_t ovf_excl = ovf_incl[d] - ovf_size;
+  uoff[d] = ovf ? base_b + ovf_excl : d * (int64_t)S + hdr;
+  uint4* h = reinterpret_cast<uint4*>(static_cast<char*>(ucodes) + d * (int64_t)S * (wide ? 4 : 2));
+  *h = make_uint4((uint32_t)u, (uint32_t)(doc_off[d + 1] - doc_off[d]), ovf ? (uint32_t)(ovf_excl / NP_ULIST_ALIGN) : 0u, 0u);
 }
 
 
@@ -510,17 +549,54 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
     unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->codes(), nullptr, nullptr, ix->d_ulen + d0);
   }
   NP_HIP(hipGetLastError());
-  int64_t total = 0;
+  // block stride: the smallest multiple of 16 bytes that holds the header and 99.9 % of the lists (at most the staging row)
+  const int hdr = (int)(16 / ix->code_bytes());
+  const int smax = ix->code_wide ? NP_UBLOCK_MAX_U32 : NP_UBLOCK_MAX_U16;
+  int fit = smax - hdr;
+  if (N > 0) {
+    uint32_t* d_hist = nullptr;
+    uint32_t h_hist[130];
+    NP_HIP(hipMalloc(&d_hist, sizeof h_hist));
+    hipError_t e = hipMemset(d_hist, 0, sizeof h_hist);
+    if (e == hipSuccess) {
+      ulen_hist_kernel<<<(unsigned)std::min<int64_t>((N + 255) / 256, 1024), 256>>>(ix->d_ulen, N, d_hist);
+      e = hipMemcpy(h_hist, d_hist, sizeof h_hist, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_hist);
+    NP_HIP(e);
+    const int64_t allow = N / 100;    // lists allowed to overflow (1 %: the filter re-reads only those)
+    int64_t over = 0;
+    int q = 129;
+    while (q > 0 && over + h_hist[q] <= allow) over += h_hist[q--];   // q = the smallest capacity leaving <= 0.1 % outside
+    fit = std::min(fit, std::max(q, 1));
+  }
+  // the stride is a multiple of 64 bytes (blocks start on 64-B sectors: a 192-B block is three sectors, a 16-B aligned
+  // 208-B one 4.1 on average), at most 256 bytes
+  const int per64 = (int)(64 / ix->code_bytes());
+  const int S = std::max(per64, std::min(smax, (hdr + fit + per64 - 1) / per64 * per64));
+  fit = S - hdr;
+  ix->ublock_stride = S;
+  ix->ublock_hdr = hdr;
+  const int64_t base_b = N * (int64_t)S;   // first entry of the overflow region
+  int64_t ovf_total = 0;
+  int64_t* d_ovf = nullptr;                // inclusive scan of the overflow sizes
+  struct FreeOvf {
+    int64_t** p;
+    ~FreeOvf() { (void)hipFree(*p); }
+  } free_ovf{&d_ovf};
   if (N > 0) {
     int64_t* d_pad = nullptr;
     void* d_temp = nullptr;
     NP_TRY(dev_alloc(&d_pad, (size_t)N, nullptr));
-    ulen_padded_kernel<<<(unsigned)((N + 255) / 256), 256>>>(ix->d_ulen, N, d_pad);
-    size_t tb = 0;
-    hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_pad, d_uoff + 1, (int)N);
-    if (e == hipSuccess) e = hipMalloc(&d_temp, std::max<size_t>(tb, 16));
-    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_pad, d_uoff + 1, (int)N);
-    if (e == hipSuccess) e = hipMemcpy(&total, d_uoff + N, 8, hipMemcpyDeviceToHost);
+    hipError_t e = hipMalloc(&d_ovf, (size_t)N * 8);
+    if (e == hipSuccess) {
+      ulen_overflow_kernel<<<(unsigned)((N + 255) / 256), 256>>>(ix->d_ulen, N, fit, d_pad);
+      size_t tb = 0;
+      e = hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_pad, d_ovf, (int)N);
+      if (e == hipSuccess) e = hipMalloc(&d_temp, std::max<size_t>(tb, 16));
+      if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(d_temp, tb, d_pad, d_ovf, (int)N);
+      if (e == hipSuccess) e = hipMemcpy(&ovf_total, d_ovf + (N - 1), 8, hipMemcpyDeviceToHost);
+    }
     (void)hipFree(d_pad);
     (void)hipFree(d_temp);
     if (e != hipSuccess) {
@@ -528,13 +604,14 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
       return e == hipErrorOutOfMemory ? NP_ERR_OUT_OF_MEMORY : NP_ERR_DEVICE_UNAVAILABLE;
     }
   }
+  const int64_t total = base_b + ovf_total;
   if (total >= ((int64_t)1 << 40)) {   // candidate records carry a 40-bit list offset
-    set_error("Index load failed: %lld distinct (document, code) pairs exceed the 40-bit list offset; use more shards",
+    set_error("Index load failed: %lld distinct-code list entries exceed the 40-bit list offset; use more shards",
               (long long)total);
     return NP_ERR_INDEX_LOAD;
   }
   ix->n_ucodes = total;
-  // pass 2: the lists, dense (+8 entries: list readers fetch up to 8 bytes past a list's last code)
+  // pass 2: headers, then the lists (+8 entries: list readers fetch up to 8 bytes past a list's last code)
   {
     const size_t bytes = ((size_t)total + 8) * ix->code_bytes();
     hipError_t e = hipMalloc(&ix->d_ucodes, bytes);
@@ -546,6 +623,9 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
     ix->device_bytes += bytes;
     NP_HIP(hipMemset(ix->d_ucodes, 0, bytes));
   }
+  if (N > 0)
+    ublock_layout_kernel<<<(unsigned)((N + 255) / 256), 256>>>(N, ix->d_doc_offsets, ix->d_ulen, d_ovf, S, hdr, fit, base_b,
+                                                               ix->d_ucodes, ix->code_wide, d_uoff);
   for (int64_t d0 = 0; d0 < N; d0 += (int64_t)1 << 30) {
     const int64_t n = std::min<int64_t>((int64_t)1 << 30, N - d0);
     unique_codes_kernel<<<(unsigned)n, 256>>>(ix->d_doc_offsets + d0, ix->codes(), ix->d_ucodes, d_uoff + d0, ix->d_ulen + d0);

@@ -6,9 +6,10 @@
 //                                       (folds codec.rs:168-214's two LUTs into one)
 //   codes       u16 [T] (K <= 65536) or u32 [T]   centroid id per token   (N.codes.npy, i64 on disk, range-checked at load)
 //   residuals   u8  [T][pd]             packed buckets, unchanged   (N.residuals.npy)
-//   ucodes      u16 / u32 [U]           derived at open: the documents' sorted DISTINCT-code lists, DENSE (document d's list
-//                                       starts at the offset its doc_meta record carries, 8-byte aligned; U = their total
-//                                       + padding); S4 gathers these.  ulen i32 [n_docs] = list lengths
+//   ucodes      u16 / u32 [U]           derived at open: the documents' sorted DISTINCT-code lists: one fixed-stride block per
+//                                       document (16-byte header + codes; the stride holds 99.9 % of the lists) followed by an
+//                                       overflow region for longer lists; the doc_meta record carries the list's offset either
+//                                       way.  S4 reads these.  ulen i32 [n_docs] = list lengths
 //   inv_norm    f32 [T]                 derived at open: 1/||centroid + residual|| per token (S6 QC-reuse form)
 //   tok_pos     u16 [T]                 derived at open: codes / residuals / inv_norm keep each document's tokens ORDERED BY
 //                                       CODE (MaxSim is a max over tokens: order-free), tok_pos = the original position
@@ -158,6 +159,8 @@ struct DeviceIndex {
   int code_wide = 0;
   void* d_ucodes = nullptr;       // [n_ucodes] dense per-document sorted distinct-code lists, same element type (derived)
   int64_t n_ucodes = 0;           // entries of d_ucodes without the tail padding
+  int ublock_stride = 0;          // entries per document block of d_ucodes (header + codes; lists that do not fit: overflow region)
+  int ublock_hdr = 0;             // entries of a block's 16-byte header {#distinct, doc length, overflow index, 0}
   int32_t* d_ulen = nullptr;      // [n_docs] number of distinct codes per document (derived)
   uint4* d_useg = nullptr;        // [n_docs] 8 x u16: distinct codes below each eighth of the centroid range (derived)
   uint4* d_doc_meta = nullptr;    // [n_docs] the 16-B candidate record of every document {doc, n distinct codes, offset of its

@@ -1118,9 +1118,9 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
       m &= m - 1;
       const uint32_t d = (uint32_t)((w0 + k) * 32 + bit);
       if (pos < limit) {
-        outm[pos] = doc_meta[d];   // {doc, distinct codes, token offset lo, offset hi | doc length << 8}: one 16-B gather
-        if (out) out[pos] = d;     // the bare id list: only the unfiltered selection / the debug trace read it
-      }
+        if (doc_meta) outm[pos] = doc_meta[d];   // {doc, distinct codes, list offset lo, offset hi | doc length << 8}: one 16-B gather
+        if (out) out[pos] = d;     // the bare id list: the hot level of the filter (it finds a document's list block from the id and
+      }                            // writes the records itself), the unfiltered selection, the debug trace
       ++pos;
     }
   }
@@ -2281,7 +2281,10 @@ __global__ void __launch_bounds__(256) hot_lam_kernel(const uint32_t* __restrict
 template <int ROWB, typename CT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) approx_hot_kernel(
     const uint8_t* __restrict__ QCU, int64_t K, int64_t KP, const uint8_t* __restrict__ cmaxu, const uint32_t* __restrict__ lam_b,
-    const uint4* __restrict__ cand_meta, const int32_t* __restrict__ n_cand, RoundPlan rp, int round, int max_rounds,
+    const uint32_t* __restrict__ cand_ids /* [pool] shard-local document ids (compact_kernel) */,
+    uint4* __restrict__ cand_meta /* [pool] OUT: the candidates' 16-B records, for the cuts and the exact level */,
+    int ublock_stride /* entries per document block of `codes` */, int64_t ovf_base /* first entry of the overflow region */,
+    const int32_t* __restrict__ n_cand, RoundPlan rp, int round, int max_rounds,
     const CT* __restrict__ codes, const uint32_t* __restrict__ qflag, const int32_t* __restrict__ qoff, int n_sel,
     uint16_t* __restrict__ U, uint32_t* __restrict__ hist, int hshift, uint32_t* __restrict__ cursor, int32_t* __restrict__ slots,
     int32_t* __restrict__ ticket, int B, int steal_min, Counters* ctr,
@@ -2291,12 +2294,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
   constexpr int DPW = 64 / LPD;    // documents per claim
   constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // codes of one document staged per pass
   constexpr int CPS = CAP / 32;                     // codes a staging lane loads (half a wave per document)
-  constexpr int RS = CAP + 16 / (int)sizeof(CT);    // row stride: 16 B of padding keeps rows 16-B aligned and off each other's banks
+  constexpr int HDR = 16 / (int)sizeof(CT);         // entries of a block's 16-byte header {#distinct, doc length, overflow index, 0}
+  constexpr int RS = HDR + CAP;                     // LDS row = a whole list block: header + up to CAP codes (rows 16-B aligned,
+                                                    // 272 B apart: off each other's banks)
   extern __shared__ uint32_t s_bits[];   // KP / 32 words: hot centroids of the current query
   __shared__ uint32_t s_hist[NP_UB_BINS];
   __shared__ __attribute__((aligned(16))) CT s_codes[4][DPW][RS];
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
+  __shared__ uint32_t s_did[4][DPW];
   __shared__ int s_q;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jl = lane & (LPD - 1), grp = lane / LPD;
@@ -2304,7 +2310,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
   const int x = blockIdx.x & 7;
   if (round >= rp.round_tab[2 * max_rounds]) return;
   const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
-  unsigned long long toks = 0, ucnt = 0, rows = 0;
+  uint32_t toks32 = 0, ucnt32 = 0, rows32 = 0;   // per-lane work counters (a lane sees one document per claim: 32 bits are plenty)
   // the scan reads whole 4-code groups and looks every code up in the bitmap, also past a list's end: the staging area
   // must never hold anything but codes (< K), so it starts zeroed (afterwards it only ever receives list entries)
   for (int i = tid; i < (int)(sizeof(s_codes) / 4); i += 256) reinterpret_cast<uint32_t*>(&s_codes[0][0][0])[i] = 0u;
@@ -2316,10 +2322,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
     const int b = __builtin_amdgcn_readfirstlane(s_q);
     if (b < 0) break;
     const int64_t n = n_cand[b];
-    if (qflag[b] || n <= (int64_t)n_sel) continue;   // the cuts keep every candidate of this query
     const int64_t pbase = rp.cand_base[b];
-    const uint4* metab = cand_meta + pbase;
+    const uint32_t* idb = cand_ids + pbase;
+    uint4* metab = cand_meta + pbase;
+    if (qflag[b] || n <= (int64_t)n_sel) {
+      // the cuts keep every candidate of this query: no bound to compute, but the later stages still want the records
+      for (int64_t i = ((int64_t)(blockIdx.x >> 3) * 256 + tid); i < n; i += (int64_t)(gridDim.x >> 3) * 256) {
+        const uint32_t d = idb[i];
+        const uint4 hd = *reinterpret_cast<const uint4*>(codes + (int64_t)d * ublock_stride);
+        const int64_t cl = (int)hd.x > ublock_stride - HDR ? ovf_base + (int64_t)hd.z * 4 : (int64_t)d * ublock_stride + HDR;
+        metab[i] = make_uint4(d, hd.x, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
+      }
+      continue;
+    }
     const int Lq = qoff[b + 1] - qoff[b];
+    const int fit = ublock_stride - HDR;             // codes a block holds
     const uint32_t lam = lam_b[b];   // hot_lam_kernel
     // ---- hot bitmap: bit c = M[c] > Lambda
     {
@@ -2359,20 +2376,50 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
       i0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
       i1 = i0 + DPW;
     }
-    uint4 m = metab[min(i0 + grp, n - 1)];
+    uint32_t did = idb[min(i0 + grp, n - 1)];
+    constexpr int EPL = 8 / (int)sizeof(CT);   // entries per lane of a block load
     for (;;) {
       if (i0 >= n) break;
       if (!static_claims && lane == 0) inext = atomicAdd(&cursor[b], (uint32_t)DPW);
-      const uint4 m_next = metab[min(i1 + grp, n - 1)];   // prefetch (clamped: a claim past the end is never used)
+      const uint32_t did_next = idb[min(i1 + grp, n - 1)];   // prefetch (clamped: a claim past the end is never used)
       const int64_t i = i0 + grp;
       const bool valid = i < n;
-      const int nd = valid ? (int)m.y : 0;
+      // ---- (0) the claim's list BLOCKS -> LDS rows, header included, in one burst: half a wave per document, 8 bytes per
+      // lane (a block is at most 256 bytes).  The block address comes from the document id alone: no per-candidate record
+      // was gathered for this.  (16 bytes per lane: 1.9 instead of 1.3 ms for the whole kernel.  Issuing the next claim's
+      // loads during this claim's scan and walk -- the loads held in registers across them -- measured no gain, 1.8 ms
+      // with the extra register pressure, and was dropped.)
+      __builtin_amdgcn_wave_barrier();       // the previous claim's rows are consumed
+      if (jl == 0) s_did[wave][grp] = valid ? did : idb[n - 1];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (!(probe & 4)) {
+        uint2 raw[DPW / 2];
+#pragma unroll
+        for (int j = 0; j < DPW / 2; ++j) {
+          const int sl = 2 * j + half;
+          const CT* bp = codes + (int64_t)s_did[wave][sl] * ublock_stride;
+          raw[j] = *reinterpret_cast<const uint2*>(bp + min(EPL * hl, ublock_stride - EPL));   // lanes past the block repeat its last piece
+        }
+#pragma unroll
+        for (int j = 0; j < DPW / 2; ++j) {
+          const int sl = 2 * j + half;
+          *reinterpret_cast<uint2*>(&s_codes[wave][sl][EPL * hl]) = raw[j];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint4 hd = *reinterpret_cast<const uint4*>(&s_codes[wave][grp][0]);   // {#distinct, doc length, overflow index, 0}
+      const int nd = valid ? (int)hd.x : 0;
+      const bool ovf = nd > fit;
+      const int64_t cl = ovf ? ovf_base + (int64_t)hd.z * 4 : (int64_t)did * ublock_stride + HDR;
       if (jl == 0) {
-        s_cl[wave][grp] = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
+        s_cl[wave][grp] = cl;
         s_nd[wave][grp] = nd;
         if (valid) {
-          toks += (unsigned long long)(m.w >> 8);
-          ucnt += (unsigned long long)nd;
+          toks32 += hd.y;
+          ucnt32 += (uint32_t)nd;
+          metab[i] = make_uint4(did, (uint32_t)nd, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
         }
       }
       const int nmax = wave_max_nonneg(nd);
@@ -2382,12 +2429,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
       for (int p0 = 0; p0 < nmax; p0 += CAP) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();     // s_cl / s_nd written, the previous pass's lists consumed
+        // lists that fit their block are already staged; only a claim with an overflow list (0.1 % of the documents) or a
+        // second window of a long list goes back to memory
+        const bool restage = p0 > 0 || nmax > fit;   // wave-uniform
         // ---- (1) stage codes [p0, p0 + CAP) of every document of the claim: one coalesced read per list, half a wave per
         // document, all loads of a batch of documents in flight before the first LDS write (one memory round trip per
         // batch).  Positions past a list's end hold whatever follows it in memory: the scan below knows the lengths.
         constexpr int SB = DPW / 2;   // staging steps, two documents each: the whole claim in ONE burst of loads
 #pragma unroll 1
-        for (int sb = 0; sb < ((probe & 4) ? 0 : DPW / 2); sb += SB) {
+        for (int sb = 0; sb < ((probe & 4) || !restage ? 0 : DPW / 2); sb += SB) {
           uint2 raw[SB];
 #pragma unroll
           for (int j = 0; j < SB; ++j) {
@@ -2396,12 +2446,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
             const CT* cp = codes + s_cl[wave][sl];
             // clamped to the list's last CPS-aligned group: an aligned 8-byte load, at most CPS - 1 entries past the end
             const int pos = min(p0 + CPS * hl, max(nds - 1, 0) & ~(CPS - 1));
-            raw[j] = *reinterpret_cast<const uint2*>(cp + pos);
+            raw[j] = make_uint2(0u, 0u);
+            if (nds > (p0 > 0 ? p0 : fit)) raw[j] = *reinterpret_cast<const uint2*>(cp + pos);   // only the lists not staged yet
           }
 #pragma unroll
           for (int j = 0; j < SB; ++j) {
             const int sl = 2 * (sb + j) + half;
-            *reinterpret_cast<uint2*>(&s_codes[wave][sl][CPS * hl]) = raw[j];
+            if (p0 > 0 || s_nd[wave][sl] > fit) *reinterpret_cast<uint2*>(&s_codes[wave][sl][HDR + CPS * hl]) = raw[j];
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2413,7 +2464,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         // the claim's longest list (no reduction); the two halves stay where they are, the walk takes them one after the other.
         const int cnt = min(max(nd - p0, 0), CAP);
         const int part = (((cnt + 1) >> 1) + 3) & ~3;          // halves start 8-B (u16) / 16-B (u32) aligned
-        CT* row = &s_codes[wave][grp][0];
+        CT* row = &s_codes[wave][grp][HDR];   // the codes of the row (behind the block header)
         int hmine = 0;
         if (!(probe & 2)) {
           const int start = jl == 0 ? 0 : part, end = jl == 0 ? min(part, cnt) : cnt;
@@ -2452,7 +2503,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
         // ---- (3) walk the hot codes in lockstep (LPD lanes per row, 8 gathers in flight per lane; positions past a
         // document's hot codes carry an out-of-range offset: the bounds check answers without a memory request).
         // Segment A = lane 0's hot codes at row[0 ..), segment B = lane 1's at row[part ..).
-        if (jl == 0) rows += (unsigned long long)(h0 + h1);
+        if (jl == 0) rows32 += (uint32_t)(h0 + h1);
 #pragma unroll 1
         for (int seg = 0; seg < 2; ++seg) {
           const int hn = seg == 0 ? h0 : h1;
@@ -2504,7 +2555,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
       }
       __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next claim
       i0 = i1;
-      m = m_next;
+      did = did_next;
       i1 = static_claims ? i1 + NW * DPW : (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)inext);
     }
     __syncthreads();
@@ -2513,6 +2564,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
       if (v) atomicAdd(&hb[i], v);
     }
   }
+  unsigned long long toks = toks32, ucnt = ucnt32, rows = rows32;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     toks += __shfl_xor(toks, o);

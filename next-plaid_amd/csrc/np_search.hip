@@ -424,7 +424,8 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   NP_TRY(w.qinv.reserve((size_t)B * 4));
   NP_TRY(w.qflag.reserve((size_t)B * 4));
   // two-level filter (np_kernels.h, "S4, first filter level"): the hot bitmap of a query lives in LDS (K / 8 bytes)
-  const bool two_level = use_filter && ix->tune.s4_hot > 0 && KP / 8 <= 64 * 1024 && KP * RB < ((int64_t)1 << 31);
+  const bool two_level = use_filter && ix->tune.s4_hot > 0 && KP / 8 <= 64 * 1024 && KP * RB < ((int64_t)1 << 31) &&
+                         ix->ublock_stride > 0;
   const size_t slot_words = (size_t)(8 * (B + 1) + 1);   // hand-out slots + ticket of one filter launch
   if (use_filter) {
     NP_TRY(w.QCU.reserve((size_t)B * KP * RB));
@@ -628,9 +629,12 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   // ---- per round: S3 compaction -> S4 -> S5 (stage events bracket round 0, which holds the whole batch unless
   // the candidates overflow the pool; later rounds are charged to S5)
   for (int r = 0; r < (have_cands ? max_rounds : 0); ++r) {
-    compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks,
-                                                     w.chunk_counts.as<int32_t>(), use_filter ? nullptr : w.cand.as<uint32_t>(), rp, r,
-                                                     ix->d_doc_meta, w.cand_meta.as<uint4>());
+    // two-level filter: bare ids only -- the hot level finds a document's list block from the id and writes the 16-B records
+    // itself (no record gather here: a 128-B line per candidate at 1.9 % density was this kernel's whole cost)
+    const bool ids_only = two_level && ix->ublock_stride > 0;
+    compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks, w.chunk_counts.as<int32_t>(),
+                                                     (use_filter && !ids_only) ? nullptr : w.cand.as<uint32_t>(), rp, r,
+                                                     ids_only ? nullptr : ix->d_doc_meta, w.cand_meta.as<uint4>());
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
     if (use_filter) {
       const int hshift = RB == 32 ? 2 : (RB == 64 ? 3 : (RB == 128 ? 4 : 5));   // U <= 255 * RB fits NP_UB_BINS << hshift
@@ -703,7 +707,9 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
       NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hot_kernel<ROWB, CT>),                             \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                                 \
     approx_hot_kernel<ROWB, CT><<<8 * nbx, 256, dyn, st>>>(w.QCU.as<uint8_t>(), ix->K, KP, w.cmaxu.as<uint8_t>(),         \
-                                                           w.ub_thr2.as<uint32_t>() + B, w.cand_meta.as<uint4>(),              \
+                                                           w.ub_thr2.as<uint32_t>() + B, w.cand.as<uint32_t>(),                \
+                                                           w.cand_meta.as<uint4>(), ix->ublock_stride,                         \
+                                                           (int64_t)ix->n_docs * ix->ublock_stride,                            \
                                                            w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, \
                                                            w.qflag.as<uint32_t>(), d_qoff, cs->n_sel, w.ub.as<uint16_t>(),  \
                                                            w.ub_hist.as<uint32_t>(), hshift, xcursor(0), sl, sl + 8 * (B + 1), \
