@@ -334,6 +334,33 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
 
 
+def test_long_documents_overflow_blocks_and_windows():
+    """Distinct-code lists live in fixed-stride blocks sized for 99 % of the documents; longer lists sit in an overflow
+    region, and lists longer than the filter's 128-code staging window take several passes.  A corpus of 150-700-token
+    documents makes EVERY list overflow and most of them span 2-4 windows: filtered (two-level and single-level) and
+    unfiltered searches must still agree bit for bit, and with the oracle."""
+    spec, a = make_arrays(num_docs=3000, num_centroids=2048, dim=128, nbits=4, doc_len_min=150, doc_len_max=700, n_topics=40,
+                          rand256=160, seed=97)
+    ox, hx = oracle_index(a), hip_index(a)
+    qs, src = synth.make_queries(spec, 12, n_tokens=32, cen=a["centroids"])
+    qs = list(qs) + [qs[0][:9]]
+    p = P(n_full_scores=256, top_k=64, n_ivf_probe=4, centroid_score_threshold=None)
+    hx.tune("s4_filter", 0)
+    ref = hx.search_batch(qs, p)
+    hx.tune("s4_filter", 1)
+    for hot in (100, 0, 400):
+        hx.tune("s4_hot", hot)
+        got = hx.search_batch(qs, p)
+        st = dict(hx.last_stats)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert np.array_equal(g.passage_ids, r.passage_ids) and np.array_equal(g.scores, r.scores), f"hot={hot} q{i}"
+        assert st["n_cand_dcodes"] / max(st["n_candidates"], 1) > 128, st      # the lists really are longer than one window
+        assert 0 < st["n_survivors"] < st["n_candidates"]
+    for g, o in zip(got, ox.search_batch(qs, to_oracle_params(p))):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
+    check_trace(hx, ox, qs[1], P(n_full_scores=128, top_k=10, n_ivf_probe=4), what="long documents")
+
+
 def test_candidate_pool_rounds(mid):
     """The candidate arrays are one pool sized by workspace_bytes, not B x n_docs: a batch whose candidates do not
     fit it together is processed in rounds (first-fit in query order).  A deliberately small budget with a wide probe

@@ -17,7 +17,7 @@ R = "r03"
 
 GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
-    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m"],
+    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m", "hot50", "hot200", "hot300"],
     f"{R}_bench_regimes.jsonl": ["dist05", "dist08", "dist08_single", "lq48_10m", "lq48_1m", "nfs8192_10m", "k19_10m", "c3_np32", "c3_np8"],
 }
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k"}
@@ -147,6 +147,15 @@ def tables():
     st += ["", "(Single-GPU runs of a corpus of that size: S6 is the full `n_sel` here, whereas a rank of the real split exact-scores only its share of the global cut.)"]
     st = "\n".join(st)
 
+    hs = ["| S4 filter, 10 M documents | u8 table rows gathered / batch | documents at the exact level | S4 ms | queries/s |", "|---|---:|---:|---:|---:|"]
+    for lab, d in (("single level (the round-2 kernel on the round-3 layout, `NP_S4_HOT=0`)", var.get("single_level_10m")),
+                   ("two levels, 5 % hot", var.get("hot50")), ("two levels, 10 % hot (default)", d10), ("two levels, 20 % hot", var.get("hot200")),
+                   ("two levels, 30 % hot", var.get("hot300"))):
+        if d:
+            x = d["stages"]
+            hs.append(f"| {lab} | {x['n_cand_codes']/1e6:.0f} M | {(x['n_level2'] or x['n_candidates'])/1e6:.2f} M | {x['ms_approx']:.2f} | {d['value']:.0f} |")
+    hs = "\n".join(hs)
+
     hy = ["| 8 GPUs as | per-GPU line | projected queries/s | batch latency |", "|---|---|---:|---:|"]
     for S, k, lab in ((8, "shard_1250k", "1.25 M"), (4, "shard_2500k", "2.5 M"), (2, "shard_5m", "5 M"), (1, None, "10 M")):
         d = d10 if k is None else sh.get(k)
@@ -157,7 +166,7 @@ def tables():
 
     path = os.path.join(ROOT, "DESIGN.md")
     x = open(path).read()
-    for tag, body in (("measured", measured), ("distinct", dist), ("regimes", rg), ("c5", c5), ("shards", st), ("hybrid", hy)):
+    for tag, body in (("measured", measured), ("hotsweep", hs), ("distinct", dist), ("regimes", rg), ("c5", c5), ("shards", st), ("hybrid", hy)):
         x, n = re.subn(rf"<!-- BEGIN:{tag} -->\n.*?<!-- END:{tag} -->", lambda m: f"<!-- BEGIN:{tag} -->\n{body}\n<!-- END:{tag} -->", x, flags=re.S)
         assert n == 1, tag
     open(path, "w").write(x)
