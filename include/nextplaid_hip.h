@@ -196,7 +196,12 @@ int np_hip_index_info(const np_index* index, np_info* out); /* index.rs:1290-131
  *                  subset_len == 0 = empty subset (every result empty)
  *   out_ids/out_scores  [B * top_k], query i at [i*top_k, i*top_k + out_counts[i]); scores descending
  *   out_counts     [B]
- * Host pointers; H2D/D2H copies are inside the call. */
+ * Host pointers; H2D/D2H copies are inside the call.
+ * Geometry: every index the crate writes with embedding_dim <= 128 is searchable -- nbits 1, 2, 4, 8 (codec.rs:161-166),
+ * any dim with dim * nbits % 8 == 0.  `dim` here, np_info.embedding_dim / nbits, decompressed rows, exported and encoded
+ * residual rows are always in the geometry of the index FILES; inside, rows are stored at the next of the four kernel
+ * widths (32 / 64 / 96 / 128, zero-padded) and 1-bit buckets as 2-bit segments.  A wider index opens (info, decompress,
+ * export work) and search returns NP_ERR_SHAPE: the wrapper's signal to take the CPU path. */
 int np_hip_search_batch(const np_index* index, const float* queries, const int32_t* q_tok_offsets,
                         int32_t B, int32_t dim, const np_search_params* params,
                         const int64_t* subset, int64_t subset_len,

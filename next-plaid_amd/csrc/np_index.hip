@@ -211,7 +211,13 @@ __global__ void __launch_bounds__(256) centroid_bound_kernel(const float* __rest
 
 static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bucket_weights) {
   NP_TRY(dev_alloc(&ix->d_centroids, (size_t)ix->K * ix->dim, &ix->device_bytes));
-  NP_HIP(hipMemcpy(ix->d_centroids, centroids, (size_t)ix->K * ix->dim * sizeof(float), hipMemcpyHostToDevice));
+  if (ix->ldim == ix->dim) {
+    NP_HIP(hipMemcpy(ix->d_centroids, centroids, (size_t)ix->K * ix->dim * sizeof(float), hipMemcpyHostToDevice));
+  } else {   // rows zero-padded to the storage width (np_internal.h storage_dim)
+    NP_HIP(hipMemset(ix->d_centroids, 0, (size_t)ix->K * ix->dim * sizeof(float)));
+    NP_HIP(hipMemcpy2D(ix->d_centroids, (size_t)ix->dim * sizeof(float), centroids, (size_t)ix->ldim * sizeof(float),
+                       (size_t)ix->ldim * sizeof(float), (size_t)ix->K, hipMemcpyHostToDevice));
+  }
   {
     uint32_t* d_b = nullptr;
     uint32_t h_b[2] = {0, 0};
@@ -226,9 +232,12 @@ static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bu
     ix->cmax = sqrtf(ss) * 1.0001f;   // the f32 sum of squares is within ~dim * 2^-24 of the real one
     ix->filter_ok = h_b[1] == 0;
   }
-  const int nb = 1 << ix->nbits;
+  const int nb = 1 << ix->nbits, lnb = 1 << ix->lnbits;
   std::vector<float> wl(nb);
-  for (int s = 0; s < nb; ++s) wl[s] = bucket_weights[bitrev((uint32_t)s, ix->nbits)];
+  for (int s = 0; s < nb; ++s) {   // 1-bit files stored as 2-bit: buckets 2 and 3 never occur
+    const uint32_t b = bitrev((uint32_t)s, ix->nbits);
+    wl[s] = b < (uint32_t)lnb ? bucket_weights[b] : 0.f;
+  }
   bool wok = true;
   for (int s = 0; s < nb; ++s) wok = wok && std::isfinite(wl[s]) && std::fabs(wl[s]) < 1e6f;
   ix->s6_fast_ok = ix->filter_ok && ix->cmax < 1e6f && wok;
@@ -440,7 +449,7 @@ static int sort_tokens(DeviceIndex* ix) {
 
 // ---- derived: 1 / ||centroid[code] + residual|| per token (codec.rs:443-467's normaliser) ------------------
 // one wave per 64 consecutive tokens; lanes sweep the dims of one token at a time (coalesced rows)
-__global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim, int nbits, int pd,
+__global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim /* row stride */, int ldim /* dims that count */, int nbits, int pd,
                                                        const float* __restrict__ centroids,
                                                        const float* __restrict__ wlut,
                                                        CodeArr codes,
@@ -456,7 +465,7 @@ __global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim, int n
     if (tok >= T) break;
     const uint32_t code = codes[tok];
     float ss = 0.f;
-    for (int j = lane; j < dim; j += 64) {
+    for (int j = lane; j < ldim; j += 64) {
       const uint32_t byte = residuals[tok * pd + j / per];
       const int e = j % per;
       const float x = centroids[(int64_t)code * dim + j] + wlut[(byte >> (8 - nbits * (e + 1))) & mask];
@@ -477,7 +486,7 @@ static int build_inv_norm(DeviceIndex* ix) {
   NP_TRY(dev_alloc(&ix->d_inv_norm, (size_t)ix->T, &ix->device_bytes));
   if (ix->T > 0) {
     const int64_t nblk = (ix->T + 255) / 256;
-    inv_norm_kernel<<<(unsigned)nblk, 256>>>(ix->T, ix->dim, ix->nbits, ix->pd, ix->d_centroids, ix->d_wlut, ix->codes(),
+    inv_norm_kernel<<<(unsigned)nblk, 256>>>(ix->T, ix->dim, ix->ldim, ix->nbits, ix->pd, ix->d_centroids, ix->d_wlut, ix->codes(),
                                              ix->d_residuals, ix->d_inv_norm);
   }
   NP_HIP(hipGetLastError());
@@ -654,6 +663,66 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
 }
 
 // ---- from host arrays / files ----------------------------------------------------------------------
+// ---- file geometry -> storage geometry (np_internal.h storage_dim / storage_nbits) --------------------------------
+// one thread per storage byte.  widen: a 1-bit file byte (8 dims, first dim in bit 7) becomes two 2-bit storage bytes whose
+// segment e holds bitrev2(bucket) = bucket << 1 (the bit layout of codec.rs:356-411 at nbits = 2).
+__global__ void __launch_bounds__(256) repack_rows_kernel(const uint8_t* __restrict__ src, int64_t n, int lpd, int pd,
+                                                          int widen, uint8_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * pd) return;
+  const int64_t t = i / pd;
+  const int jb = (int)(i - t * pd);
+  uint32_t out = 0;
+  if (widen) {
+    const int sb = jb >> 1;
+    if (sb < lpd) {
+      const uint32_t nib = ((uint32_t)src[t * lpd + sb] >> ((jb & 1) ? 0 : 4)) & 15u;
+      out = ((nib & 8u) << 4) | ((nib & 4u) << 3) | ((nib & 2u) << 2) | ((nib & 1u) << 1);
+    }
+  } else if (jb < lpd) {
+    out = src[t * lpd + jb];
+  }
+  dst[i] = (uint8_t)out;
+}
+
+// the inverse, for np_hip_index_export
+__global__ void __launch_bounds__(256) unpack_rows_kernel(const uint8_t* __restrict__ src, int64_t n, int lpd, int pd,
+                                                          int widen, uint8_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * lpd) return;
+  const int64_t t = i / lpd;
+  const int jb = (int)(i - t * lpd);
+  uint32_t out;
+  if (widen) {
+    const uint32_t hi = src[t * pd + 2 * jb], lo = src[t * pd + 2 * jb + 1];
+    const uint32_t nh = ((hi >> 4) & 8u) | ((hi >> 3) & 4u) | ((hi >> 2) & 2u) | ((hi >> 1) & 1u);
+    const uint32_t nl = ((lo >> 4) & 8u) | ((lo >> 3) & 4u) | ((lo >> 2) & 2u) | ((lo >> 1) & 1u);
+    out = (nh << 4) | nl;
+  } else {
+    out = src[t * pd + jb];
+  }
+  dst[i] = (uint8_t)out;
+}
+
+static int upload_repacked(DeviceIndex* ix, const uint8_t* rows, int64_t first_tok, int64_t n_tok) {
+  const int64_t PIECE = (int64_t)1 << 20;   // tokens per staging piece
+  uint8_t* d_stage = nullptr;
+  NP_HIP(hipMalloc(&d_stage, (size_t)std::min(PIECE, n_tok) * ix->lpd));
+  hipError_t e = hipSuccess;
+  const int widen = ix->lnbits != ix->nbits;
+  for (int64_t s = 0; s < n_tok && e == hipSuccess; s += PIECE) {
+    const int64_t n = std::min(PIECE, n_tok - s);
+    e = hipMemcpy(d_stage, rows + s * ix->lpd, (size_t)n * ix->lpd, hipMemcpyHostToDevice);
+    if (e != hipSuccess) break;
+    repack_rows_kernel<<<(unsigned)((n * ix->pd + 255) / 256), 256>>>(d_stage, n, ix->lpd, ix->pd, widen,
+                                                                     ix->d_residuals + (first_tok + s) * ix->pd);
+    e = hipDeviceSynchronize();
+  }
+  (void)hipFree(d_stage);
+  NP_HIP(e);
+  return NP_OK;
+}
+
 int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIndex** out) {
   *out = nullptr;
   np_open_opts o;
@@ -700,9 +769,12 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
   ix->K = h.K;
   ix->KP = (h.K + 63) / 64 * 64;
   ix->code_wide = h.K > 65536 ? 1 : 0;   // u16 codes whenever every centroid id fits (2 B per token instead of 4)
-  ix->dim = h.dim;
-  ix->nbits = h.nbits;
-  ix->pd = h.dim * h.nbits / 8;
+  ix->ldim = h.dim;
+  ix->lnbits = h.nbits;
+  ix->lpd = h.dim * h.nbits / 8;
+  ix->dim = storage_dim(h.dim);
+  ix->nbits = storage_nbits(h.dim, h.nbits);
+  ix->pd = ix->dim * ix->nbits / 8;
   NP_TRY(upload_codec(ix, h.centroids, h.bucket_weights));
 
   // doc offsets of the shard + its token range inside the host arrays
@@ -759,9 +831,12 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
           NP_HIP(hipMemcpy((uint16_t*)ix->d_codes + (s - tb), tmp16.data(), (size_t)n * 2, hipMemcpyHostToDevice));
         }
       }
-      if (b > a)
+      if (b > a && ix->pd == ix->lpd) {
         NP_HIP(hipMemcpy(ix->d_residuals + (a - tb) * ix->pd, c.residuals + (a - pos) * ix->pd,
                          (size_t)(b - a) * ix->pd, hipMemcpyHostToDevice));
+      } else if (b > a) {   // file rows -> storage rows (zero-padded, 1-bit buckets widened to 2-bit segments)
+        NP_TRY(upload_repacked(ix, c.residuals + (a - pos) * ix->lpd, a - tb, b - a));
+      }
       pos += c.n_tokens;
     }
     if (pos < te) {
@@ -1091,9 +1166,9 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
   ix->K = s->num_centroids;
   ix->KP = (ix->K + 63) / 64 * 64;
   ix->code_wide = ix->K > 65536 ? 1 : 0;
-  ix->dim = s->dim;
-  ix->nbits = s->nbits;
-  ix->pd = s->dim * s->nbits / 8;
+  ix->dim = ix->ldim = s->dim;        // the generator writes storage geometry directly (spec checked above)
+  ix->nbits = ix->lnbits = s->nbits;
+  ix->pd = ix->lpd = s->dim * s->nbits / 8;
   ix->max_doc_len = s->len_table_size > 0 ? table_max : s->doc_len_max;
   NP_TRY(upload_codec(ix, s->centroids, s->bucket_weights));
 
@@ -1336,8 +1411,17 @@ int np_hip_index_export(const np_index* ix, int64_t* doc_lengths, int64_t* codes
       }
     }
   }
-  if (residuals && ix->T > 0)
+  if (residuals && ix->T > 0 && ix->pd == ix->lpd) {
     NP_HIP(hipMemcpy(residuals, ix->d_residuals, (size_t)ix->T * ix->pd, hipMemcpyDeviceToHost));
+  } else if (residuals && ix->T > 0) {   // storage rows -> file rows
+    uint8_t* d_rows = nullptr;
+    NP_HIP(hipMalloc(&d_rows, (size_t)ix->T * ix->lpd));
+    unpack_rows_kernel<<<(unsigned)((ix->T * ix->lpd + 255) / 256), 256>>>(ix->d_residuals, ix->T, ix->lpd, ix->pd,
+                                                                          ix->lnbits != ix->nbits, d_rows);
+    hipError_t e = hipMemcpy(residuals, d_rows, (size_t)ix->T * ix->lpd, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rows);
+    NP_HIP(e);
+  }
   if (ivf && ix->ivf_size > 0) {
     std::vector<uint32_t> tmp((size_t)ix->ivf_size);
     NP_HIP(hipMemcpy(tmp.data(), ix->d_ivf, tmp.size() * 4, hipMemcpyDeviceToHost));
@@ -1367,8 +1451,8 @@ int np_hip_index_info(const np_index* ix, np_info* out) {
   out->num_documents = ix->N_total;
   out->num_embeddings = ix->n_emb_total;
   out->num_partitions = ix->K;
-  out->embedding_dim = ix->dim;
-  out->nbits = ix->nbits;
+  out->embedding_dim = ix->ldim;
+  out->nbits = ix->lnbits;
   out->avg_doclen = ix->avg_doclen;
   out->shard_doc_begin = ix->doc_begin;
   out->shard_doc_end = ix->doc_begin + ix->n_docs;

@@ -150,7 +150,8 @@ struct DeviceIndex {
   double avg_doclen = 0.0;
   int64_t doc_begin = 0, n_docs = 0;
   int64_t K = 0, KP = 0;  // KP = K rounded up to 64
-  int32_t dim = 0, nbits = 0, pd = 0;
+  int32_t dim = 0, nbits = 0, pd = 0;     // STORAGE geometry: what every kernel is instantiated on (see storage_dim below)
+  int32_t ldim = 0, lnbits = 0, lpd = 0;  // geometry of the index files and of the caller's queries / embeddings
   int64_t T = 0;
   int64_t max_doc_len = 0;
   float* d_centroids = nullptr;
@@ -190,6 +191,14 @@ struct DeviceIndex {
   mutable std::vector<Context*> contexts;
   mutable uint64_t use_clock = 0;
 };
+
+// Any index the crate can write is searchable up to dim 128: rows are stored zero-padded to the next instantiated width
+// (queries are padded with zeros too, so the padded dims add exact zeros to every dot product; norms and outputs stop at
+// ldim), and 1-bit residuals are stored as 2-bit ones (bucket b -> segment b << 1, weights {w0, w1, 0, 0}: the same values).
+// 8-bit residuals keep their layout and take the all-f32 S6 kernel at every precision.  codec.rs:161-166 accepts nbits
+// in {1, 2, 4, 8} and any dim with dim * nbits % 8 == 0.
+static inline int storage_dim(int dim) { return dim <= 0 || dim > 128 ? dim : (dim + 31) / 32 * 32; }
+static inline int storage_nbits(int dim, int nbits) { return (nbits == 1 && dim <= 128) ? 2 : nbits; }
 
 // np_index.hip
 int build_device_index(const HostIndex& h, const np_open_opts* opts, DeviceIndex** out);

@@ -87,6 +87,17 @@ __global__ void __launch_bounds__(256) clear_regions_kernel(ClearList cl) {
   }
 }
 
+// caller rows [n][ldim] -> storage rows [n][dim], zero padded (np_internal.h storage_dim): the padded dims add exact zeros
+// to every dot product
+__global__ void __launch_bounds__(256) pad_rows_kernel(const float* __restrict__ src, int64_t n, int ldim, int dim,
+                                                       float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * dim) return;
+  const int64_t r = i / dim;
+  const int k = (int)(i - r * dim);
+  dst[i] = k < ldim ? src[r * ldim + k] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // prep: Qt[b][k][q] f32 (k-major, zero padded to LQP) and Qb[b][q][k] bf16
 // ---------------------------------------------------------------------------------------------
@@ -2606,12 +2617,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // one wave per listed document; lanes (q = lane & 31, half = lane >> 5): half h takes the document's distinct codes
 // h, h+2, ...; 32 query tokens at a time
-template <int DIM>
+// TAIL: the index files' dim (ldim <= DIM, rows zero-padded) is not a multiple of 8 -- unrolled_dot adds the last ldim % 8
+// products one by one AFTER the eight partial sums, so the padded row cannot simply run through the 8-wide loop.
+template <int DIM, bool TAIL>
 __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restrict__ qrows, const int32_t* __restrict__ qoff,
                                                             const float* __restrict__ centroids,
                                                             const uint4* __restrict__ meta, const int32_t* __restrict__ n_list,
                                                             RoundPlan rp, int round, CodeArr codes,
-                                                            float* __restrict__ approx) {
+                                                            float* __restrict__ approx, int ldim) {
 #pragma clang fp contract(off)
   constexpr int QS = DIM + 4;   // LDS row stride (floats): conflict-free b128 reads across 32 rows
   __shared__ float sQ[32 * QS];
@@ -2654,8 +2667,9 @@ __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restr
         f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, p45 = {0.f, 0.f}, p67 = {0.f, 0.f};
         const float* xq = &sQ[ql * QS];
         const float* yc = &sC[wave][half][0];
+        const int kfull = TAIL ? (ldim & ~7) : DIM;
 #pragma unroll 4
-        for (int k = 0; k < DIM; k += 8) {
+        for (int k = 0; k < kfull; k += 8) {
           const float4 x0 = *reinterpret_cast<const float4*>(xq + k), x1 = *reinterpret_cast<const float4*>(xq + k + 4);
           const float4 y0 = *reinterpret_cast<const float4*>(yc + k), y1 = *reinterpret_cast<const float4*>(yc + k + 4);
           p01 = p01 + (f32x2){x0.x, x0.y} * (f32x2){y0.x, y0.y};
@@ -2668,6 +2682,8 @@ __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restr
         sum = sum + (p01.y + p45.y);
         sum = sum + (p23.x + p67.x);
         sum = sum + (p23.y + p67.y);
+        if constexpr (TAIL)
+          for (int k = kfull; k < ldim; ++k) sum = sum + xq[k] * yc[k];
         if (j < nd && sum > mx) mx = sum;          // search.rs:286-291: `if centroid_score > max_score`
         __builtin_amdgcn_wave_barrier();            // sC is rewritten by the next step
       }
@@ -2943,6 +2959,7 @@ struct ExactP {
   int fast_ok;              // index values finite and bounded: with an unflagged query every S6 product is finite
   int qt0;                  // exact_qct_kernel<.., NQT = 1, ..>: the 32-token query tile this launch scores (queries longer than
   int acc;                  // 32 tokens take one launch per tile); acc = continue the q-ordered sum from exact[] (tiles > 0)
+  int ldim;                 // dims of the index files (<= DIM; the rest of a stored row is padding and stays out of the norm)
 };
 
 #define NP_EXACT_DPW 4   // documents per wave
@@ -3009,7 +3026,7 @@ __global__ void __launch_bounds__(256) exact_f32_kernel(ExactP p) {
           for (int e = 0; e < PER; ++e) {
             const int jdim = (w * 4 + i) * PER + e;
             const float c = reinterpret_cast<const float*>(cp)[jdim];
-            const float x = c + seg_weight<NBITS>(sW, byte, e);
+            const float x = (kk * H + jdim < p.ldim) ? c + seg_weight<NBITS>(sW, byte, e) : 0.f;
             v[jdim] = x;
             ss = fmaf(x, x, ss);
           }
@@ -3122,7 +3139,7 @@ __global__ void __launch_bounds__(256) exact_bf16_kernel(ExactP p) {
           const uint32_t byte = (word >> (8 * i)) & 0xFFu;
 #pragma unroll
           for (int e = 0; e < PER; ++e) {
-            const float x = cc[i * PER + e] + seg_weight<NBITS>(sW, byte, e);
+            const float x = (d0 + i * PER + e < p.ldim) ? cc[i * PER + e] + seg_weight<NBITS>(sW, byte, e) : 0.f;
             a[s][i * PER + e] = (__bf16)x;   // un-normalised; rows are scaled after the MFMA
             ss = fmaf(x, x, ss);
           }
@@ -3993,7 +4010,9 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(const int64_t* __restri
 __global__ void __launch_bounds__(256) decompress_kernel(const int64_t* __restrict__ tok_src /*[n] shard token idx*/,
                                                          const int64_t* __restrict__ out_base /*[n] first output row of the token's document*/,
                                                          const uint16_t* __restrict__ tok_pos /* stored -> original position, or NULL */,
-                                                         int64_t n, int dim, int nbits, int pd,
+                                                         int64_t n, int dim /* stored row width */,
+                                                         int ldim /* dims of the index files = output row width */,
+                                                         int nbits, int pd,
                                                          const float* __restrict__ centroids,
                                                          const float* __restrict__ wlut,
                                                          CodeArr codes,
@@ -4009,17 +4028,17 @@ __global__ void __launch_bounds__(256) decompress_kernel(const int64_t* __restri
   const int per = 8 / nbits;
   const uint32_t mask = (1u << nbits) - 1u;
   float ss = 0.f;
-  for (int j = lane; j < dim; j += 64) {
+  for (int j = lane; j < ldim; j += 64) {
     const uint32_t byte = residuals[tok * pd + j / per];
     const int e = j % per;
     const float x = centroids[(int64_t)code * dim + j] + wlut[(byte >> (8 - nbits * (e + 1))) & mask];
-    out[row * dim + j] = x;
+    out[row * ldim + j] = x;
     ss += x * x;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   const float norm = fmaxf(sqrtf(ss), 1e-12f);
-  for (int j = lane; j < dim; j += 64) out[row * dim + j] = out[row * dim + j] / norm;
+  for (int j = lane; j < ldim; j += 64) out[row * ldim + j] = out[row * ldim + j] / norm;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4063,14 +4082,15 @@ __global__ void __launch_bounds__(256) encode_argmax_kernel(const float* __restr
 __global__ void __launch_bounds__(256) encode_pack_kernel(const float* __restrict__ x, const float* __restrict__ C,
                                                           const int64_t* __restrict__ codes,
                                                           const float* __restrict__ cutoffs, int64_t n_tokens, int dim,
-                                                          int nbits, uint8_t* __restrict__ packed) {
+                                                          int cdim /* row width of C */, int nbits,
+                                                          uint8_t* __restrict__ packed) {
   const int pd = dim * nbits / 8, per = 8 / nbits, ncut = (1 << nbits) - 1;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_tokens * pd) return;
   const int64_t t = i / pd;
   const int jb = (int)(i - t * pd);
   const float* xr = x + t * dim + jb * per;
-  const float* cr = C + codes[t] * dim + jb * per;
+  const float* cr = C + codes[t] * cdim + jb * per;
   uint32_t byte = 0;
   for (int e = 0; e < per; ++e) {
     const float v = __fsub_rn(xr[e], cr[e]);

@@ -16,7 +16,7 @@ namespace np {
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, n_list2, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
-      subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2;
+      subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2, qpad;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
@@ -25,7 +25,7 @@ struct Workspace {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
                      &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
-                     &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2};
+                     &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad};
     for (DevBuf* b : all) b->release();
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
@@ -129,8 +129,9 @@ static int n_sel_of(const np_search_params* p) {
   return (int)std::min<int64_t>(nd, p->n_full_scores);                     // search.rs:461-469 take/take
 }
 
+// STORAGE geometry (np_internal.h storage_dim / storage_nbits): every index with dim <= 128 lands here
 static bool dim_supported(int dim, int nbits) {
-  return (dim == 32 || dim == 64 || dim == 96 || dim == 128) && (nbits == 2 || nbits == 4);
+  return (dim == 32 || dim == 64 || dim == 96 || dim == 128) && (nbits == 2 || nbits == 4 || nbits == 8);
 }
 
 static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_search_params* p) {
@@ -142,13 +143,12 @@ static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_sear
     set_error("Search failed: negative batch size");
     return NP_ERR_INVALID_ARGUMENT;
   }
-  if (dim != ix->dim) {  // ndarray .dot() would panic on this (search.rs:345)
-    set_error("Shape error: query dim %d does not match index dim %d", dim, ix->dim);
+  if (dim != ix->ldim) {  // ndarray .dot() would panic on this (search.rs:345)
+    set_error("Shape error: query dim %d does not match index dim %d", dim, ix->ldim);
     return NP_ERR_SHAPE;
   }
   if (!dim_supported(ix->dim, ix->nbits)) {
-    set_error("Shape error: the HIP search path supports dim in {32,64,96,128} and nbits in {2,4}; index has dim=%d nbits=%d",
-              ix->dim, ix->nbits);
+    set_error("Shape error: the HIP search path supports dim <= 128; index has dim=%d nbits=%d", ix->ldim, ix->lnbits);
     return NP_ERR_SHAPE;
   }
   if (p->n_ivf_probe < 1 || p->top_k < 0 || p->n_full_scores < 0) {
@@ -297,6 +297,23 @@ static int launch_exact_qt(hipStream_t st, const DeviceIndex* ix, const ExactP& 
 template <int DIM>
 static int launch_exact_nb(hipStream_t st, const DeviceIndex* ix, const ExactP& p, int B, int precision, int nbits) {
   if (nbits == 2) return launch_exact_qt<DIM, 2>(st, ix, p, B, precision);
+  if (nbits == 8) {   // one dim per byte, 256 bucket weights: the all-f32 kernel at every precision (>= what was asked for)
+    const unsigned gx = (unsigned)((p.n_sel + 4 * NP_EXACT_DPW - 1) / (4 * NP_EXACT_DPW));
+    if (gx == 0 || B == 0) return NP_OK;
+    const size_t lds = ((size_t)DIM * p.LQP + 256) * sizeof(float);
+#define NP_F32_NB8(NQT)                                                                                              \
+  do {                                                                                                               \
+    if (lds > 64 * 1024)                                                                                             \
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_f32_kernel<DIM, 8, NQT>),                      \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+    exact_f32_kernel<DIM, 8, NQT><<<dim3(gx, B), 256, lds, st>>>(p);                                                 \
+  } while (0)
+    if (p.LQP <= 32) NP_F32_NB8(1);
+    else if (p.LQP <= 64) NP_F32_NB8(2);
+    else NP_F32_NB8(NP_MAX_QT);
+#undef NP_F32_NB8
+    return NP_OK;
+  }
   return launch_exact_qt<DIM, 4>(st, ix, p, B, precision);
 }
 
@@ -352,12 +369,22 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
 static void launch_matvec(hipStream_t st, const DeviceIndex* ix, Workspace& w, const float* d_q, const int32_t* d_qoff, int B,
                           const uint4* meta, const int32_t* n, const RoundPlan& rp, int round) {
   const dim3 grid(64, (unsigned)B);
+#define NP_MATVEC(D)                                                                                                   \
+  do {                                                                                                                 \
+    if (ix->ldim & 7)                                                                                                  \
+      approx_matvec_kernel<D, true><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), \
+                                                          w.approx.as<float>(), ix->ldim);                             \
+    else                                                                                                               \
+      approx_matvec_kernel<D, false><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), \
+                                                           w.approx.as<float>(), ix->ldim);                            \
+  } while (0)
   switch (ix->dim) {
-    case 32: approx_matvec_kernel<32><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
-    case 64: approx_matvec_kernel<64><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
-    case 96: approx_matvec_kernel<96><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
-    default: approx_matvec_kernel<128><<<grid, 256, 0, st>>>(d_q, d_qoff, ix->d_centroids, meta, n, rp, round, ix->ucodes(), w.approx.as<float>()); break;
+    case 32: NP_MATVEC(32); break;
+    case 64: NP_MATVEC(64); break;
+    case 96: NP_MATVEC(96); break;
+    default: NP_MATVEC(128); break;
   }
+#undef NP_MATVEC
 }
 
 // S1..S5 for queries [0,B) whose rows live in d_q (absolute offsets d_qoff/h_qoff).
@@ -384,6 +411,14 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
     set_error("Shape error: %lld centroids x %d query tokens exceed the 4 GiB per-query score table of the HIP path",
               (long long)ix->K, LQP);
     return NP_ERR_SHAPE;
+  }
+  if (ix->ldim != ix->dim) {   // caller rows -> storage rows; everything below sees ix->dim
+    const int64_t r0 = h_qoff[0], nr = (int64_t)h_qoff[B] - r0;
+    NP_TRY(w.qpad.reserve((size_t)std::max<int64_t>(nr, 1) * ix->dim * 4));
+    if (nr > 0)
+      pad_rows_kernel<<<(unsigned)((nr * ix->dim + 255) / 256), 256, 0, st>>>(d_q + r0 * ix->ldim, nr, ix->ldim, ix->dim,
+                                                                              w.qpad.as<float>());
+    d_q = w.qpad.as<float>() - r0 * ix->dim;   // offsets stay absolute
   }
   cs->LQP = LQP;
   cs->n_sel = n_sel_of(&prm);
@@ -844,6 +879,7 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.fast_ok = ix->s6_fast_ok ? 1 : 0;
     ep.qt0 = 0;
     ep.acc = 0;
+    ep.ldim = ix->ldim;
     switch (ix->dim) {
       case 32: NP_TRY((launch_exact_nb<32>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
       case 64: NP_TRY((launch_exact_nb<64>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
@@ -1302,7 +1338,7 @@ int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int6
   int64_t* d_tok = nullptr;
   float* d_out = nullptr;
   NP_HIP(hipMalloc(&d_tok, toks.size() * 16));
-  hipError_t e = hipMalloc(&d_out, toks.size() * (size_t)ix->dim * 4);
+  hipError_t e = hipMalloc(&d_out, toks.size() * (size_t)ix->ldim * 4);
   if (e != hipSuccess) {
     (void)hipFree(d_tok);
     set_error("hipMalloc failed: %s", hipGetErrorString(e));
@@ -1313,10 +1349,10 @@ int np_hip_decompress_documents(const np_index* ix, const int64_t* doc_ids, int6
   if (e == hipSuccess) {
     decompress_kernel<<<(unsigned)((toks.size() + 3) / 4), 256>>>(d_tok, d_tok + toks.size(),
                                                                   ix->tok_sorted ? ix->d_tok_pos : nullptr,
-                                                                  (int64_t)toks.size(), ix->dim, ix->nbits, ix->pd,
+                                                                  (int64_t)toks.size(), ix->dim, ix->ldim, ix->nbits, ix->pd,
                                                                   ix->d_centroids, ix->d_wlut, ix->codes(), ix->d_residuals,
                                                                   d_out);
-    e = hipMemcpy(out_embeddings, d_out, toks.size() * (size_t)ix->dim * 4, hipMemcpyDeviceToHost);
+    e = hipMemcpy(out_embeddings, d_out, toks.size() * (size_t)ix->ldim * 4, hipMemcpyDeviceToHost);
   }
   (void)hipFree(d_tok);
   (void)hipFree(d_out);
@@ -1404,13 +1440,12 @@ int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_
     set_error("encode_tokens: invalid argument");
     return NP_ERR_INVALID_ARGUMENT;
   }
-  if (dim != ix->dim) {
-    set_error("Shape error: embedding dim %d does not match index dim %d", dim, ix->dim);
+  if (dim != ix->ldim) {
+    set_error("Shape error: embedding dim %d does not match index dim %d", dim, ix->ldim);
     return NP_ERR_SHAPE;
   }
   if (!dim_supported(ix->dim, ix->nbits)) {
-    set_error("Shape error: the HIP path supports dim in {32,64,96,128} and nbits in {2,4}; index has dim=%d nbits=%d",
-              ix->dim, ix->nbits);
+    set_error("Shape error: the HIP path supports dim <= 128; index has dim=%d nbits=%d", ix->ldim, ix->lnbits);
     return NP_ERR_SHAPE;
   }
   if (ix->K <= 0) {
@@ -1432,17 +1467,19 @@ int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_
   S = std::max<int64_t>(1, std::min<int64_t>(S, std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB)));
   S = std::min<int64_t>(S, (n_tokens + LQP - 1) / LQP);
   const int64_t TB = S * LQP;
-  const int pd = ix->pd, ncut = (1 << ix->nbits) - 1;
+  const int pd = ix->lpd, ncut = (1 << ix->lnbits) - 1;   // the OUTPUT is in file geometry (codec.rs:356-411)
+  const int sdim = ix->dim;                                // the GEMM runs on storage rows
   NP_TRY(w.q.reserve((size_t)TB * dim * 4));
+  if (sdim != dim) NP_TRY(w.qpad.reserve((size_t)TB * sdim * 4));
   NP_TRY(w.qoff.reserve((size_t)(S + 1) * 4));
-  NP_TRY(w.Qt.reserve((size_t)S * dim * LQP * 4));
-  NP_TRY(w.Qb.reserve((size_t)S * dim * LQP * 2));
-  NP_TRY(w.Qbl.reserve((size_t)S * dim * LQP * 2));
+  NP_TRY(w.Qt.reserve((size_t)S * sdim * LQP * 4));
+  NP_TRY(w.Qb.reserve((size_t)S * sdim * LQP * 2));
+  NP_TRY(w.Qbl.reserve((size_t)S * sdim * LQP * 2));
   NP_TRY(w.QCT.reserve((size_t)S * KP * LQP * 4));
   NP_TRY(w.gmax.reserve((size_t)S * G * LQP * 4));
   NP_TRY(w.out_ids.reserve((size_t)TB * 8));
   NP_TRY(w.cand.reserve((size_t)TB * pd));
-  NP_TRY(w.misc.reserve(64));
+  NP_TRY(w.misc.reserve(std::max<size_t>(64, (size_t)ncut * 4)));
   NP_HIP(hipMemcpyAsync(w.misc.p, bucket_cutoffs, (size_t)ncut * 4, hipMemcpyHostToDevice, st));
   std::vector<int32_t> h_off((size_t)S + 1);
   for (int64_t t0 = 0; t0 < n_tokens; t0 += TB) {
@@ -1451,7 +1488,12 @@ int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_
     for (int s = 0; s <= Sb; ++s) h_off[(size_t)s] = (int32_t)std::min<int64_t>((int64_t)s * LQP, nb);
     NP_HIP(hipMemcpyAsync(w.q.p, embeddings + t0 * dim, (size_t)nb * dim * 4, hipMemcpyHostToDevice, st));
     NP_HIP(hipMemcpyAsync(w.qoff.p, h_off.data(), (size_t)(Sb + 1) * 4, hipMemcpyHostToDevice, st));
-    prep_queries_kernel<<<Sb, 256, 0, st>>>(w.q.as<float>(), w.qoff.as<int32_t>(), dim, LQP, w.Qt.as<float>(),
+    const float* xs = w.q.as<float>();
+    if (sdim != dim) {
+      pad_rows_kernel<<<(unsigned)((nb * sdim + 255) / 256), 256, 0, st>>>(w.q.as<float>(), nb, dim, sdim, w.qpad.as<float>());
+      xs = w.qpad.as<float>();
+    }
+    prep_queries_kernel<<<Sb, 256, 0, st>>>(xs, w.qoff.as<int32_t>(), sdim, LQP, w.Qt.as<float>(),
                                             w.Qb.as<__bf16>(), w.Qbl.as<__bf16>(), 0.f, nullptr, nullptr);
     switch (ix->dim) {
       case 32: launch_gemm<32>(st, ix, w.Qt.as<float>(), Sb, LQP, w.QCT.as<float>(), w.gmax.as<uint32_t>()); break;
@@ -1463,7 +1505,7 @@ int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_
                                                                   LQP, nb, w.out_ids.as<int64_t>());
     encode_pack_kernel<<<(unsigned)((nb * pd + 255) / 256), 256, 0, st>>>(w.q.as<float>(), ix->d_centroids,
                                                                          w.out_ids.as<int64_t>(), w.misc.as<float>(), nb,
-                                                                         dim, ix->nbits, w.cand.as<uint8_t>());
+                                                                         dim, sdim, ix->lnbits, w.cand.as<uint8_t>());
     NP_HIP(hipGetLastError());
     NP_HIP(hipMemcpyAsync(out_codes + t0, w.out_ids.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
     NP_HIP(hipMemcpyAsync(out_packed + t0 * pd, w.cand.p, (size_t)nb * pd, hipMemcpyDeviceToHost, st));

@@ -504,10 +504,10 @@ def test_errors_through_the_abi(mid):
         hx.search(np.zeros((4, 64), np.float32), P())
     with pytest.raises(npa.SearchError):
         hx.search(qs[0], P(n_ivf_probe=0))
-    spec2, a2 = make_arrays(num_docs=50, num_centroids=16, dim=48, nbits=4, doc_len_min=4, doc_len_max=4, seed=1)
-    h48 = hip_index(a2)      # loads fine; dim 48 has no HIP kernel -> Shape error, never a silent fallback
-    with pytest.raises(npa.ShapeError):
-        h48.search(np.zeros((4, 48), np.float32), P())
+    spec2, a2 = make_arrays(num_docs=50, num_centroids=16, dim=192, nbits=4, doc_len_min=4, doc_len_max=4, seed=1)
+    h192 = hip_index(a2)     # loads fine; dim > 128 has no HIP kernel -> Shape error, never a silent fallback
+    with pytest.raises(npa.ShapeError):   # (every dim <= 128 is searchable: tests/test_gpu_geometry.py)
+        h192.search(np.zeros((4, 192), np.float32), P())
 
 
 def test_concurrent_calls_share_one_index(mid):
