@@ -2,7 +2,8 @@
 """Installs the evidence of a final GPU call under profiles/ and regenerates the measured tables of DESIGN.md
 (between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r03_*.
 
-  design_tables.py install <gpurun_out tag>     copy gpurun_out/<tag>/... to profiles/r03_* (names below)
+  design_tables.py install <gpurun_out tag> [--merge]   copy gpurun_out/<tag>/... to profiles/r03_* (names below); --merge keeps
+                                                the committed lines the call did not re-measure
   design_tables.py                              regenerate the tables from profiles/r03_*
 """
 import json
@@ -23,19 +24,29 @@ GROUPS = {
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k"}
 
 
-def install(tag):
+def install(tag, merge=False):
+    """merge: a later, smaller call re-measured some lines -- replace those, keep the rest of the committed evidence."""
     src = os.path.join(ROOT, "gpurun_out", tag)
     for dst, name in SINGLES.items():
+        if merge and not os.path.exists(os.path.join(src, f"b_{name}.json")):
+            continue
         shutil.copy(os.path.join(src, f"b_{name}.json"), P + dst)
     for dst, names in GROUPS.items():
+        old = {}
+        if merge and os.path.exists(P + dst):
+            old = {json.loads(l)["name"]: l for l in open(P + dst) if l.strip()}
         with open(P + dst, "w") as f:
             for n in names:
                 p = os.path.join(src, f"b_{n}.json")
                 if not os.path.exists(p) or os.path.getsize(p) == 0:
-                    print("missing", n)
+                    if n in old:
+                        f.write(old[n] if old[n].endswith("\n") else old[n] + "\n")
+                    else:
+                        print("missing", n)
                     continue
                 d = json.load(open(p))
                 d["name"] = n
+                d["evidence_call"] = tag
                 f.write(json.dumps(d) + "\n")
     for a, b in (("stats_d10m.md", f"{R}_kernel_stats_10m.md"), ("stats_d10m.csv", f"{R}_kernel_stats_10m.csv"),
                  ("stats_d1m.md", f"{R}_kernel_stats_1m.md"), ("stats_d1m.csv", f"{R}_kernel_stats_1m.csv"),
@@ -175,5 +186,5 @@ def tables():
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "install":
-        install(sys.argv[2])
+        install(sys.argv[2], merge="--merge" in sys.argv)
     tables()
