@@ -241,6 +241,7 @@ static int upload_codec(DeviceIndex* ix, const float* centroids, const float* bu
   bool wok = true;
   for (int s = 0; s < nb; ++s) wok = wok && std::isfinite(wl[s]) && std::fabs(wl[s]) < 1e6f;
   ix->s6_fast_ok = ix->filter_ok && ix->cmax < 1e6f && wok;
+  ix->pad_ss = ix->dim > ix->ldim ? (float)(ix->dim - ix->ldim) * (wl[0] * wl[0]) : 0.f;
   NP_TRY(dev_alloc(&ix->d_wlut, nb, &ix->device_bytes));
   NP_HIP(hipMemcpy(ix->d_wlut, wl.data(), nb * sizeof(float), hipMemcpyHostToDevice));
   return NP_OK;

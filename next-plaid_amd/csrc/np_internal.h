@@ -152,6 +152,7 @@ struct DeviceIndex {
   int64_t K = 0, KP = 0;  // KP = K rounded up to 64
   int32_t dim = 0, nbits = 0, pd = 0;     // STORAGE geometry: what every kernel is instantiated on (see storage_dim below)
   int32_t ldim = 0, lnbits = 0, lpd = 0;  // geometry of the index files and of the caller's queries / embeddings
+  float pad_ss = 0.f;                     // (dim - ldim) * wlut[0]^2, see ExactP::pad_ss
   int64_t T = 0;
   int64_t max_doc_len = 0;
   float* d_centroids = nullptr;

@@ -2959,8 +2959,9 @@ struct ExactP {
   int fast_ok;              // index values finite and bounded: with an unflagged query every S6 product is finite
   int qt0;                  // exact_qct_kernel<.., NQT = 1, ..>: the 32-token query tile this launch scores (queries longer than
   int acc;                  // 32 tokens take one launch per tile); acc = continue the q-ordered sum from exact[] (tiles > 0)
-  int ldim;                 // dims of the index files (<= DIM; the rest of a stored row is padding and stays out of the norm)
-};
+  float pad_ss;             // (DIM - file dim) * wlut[0]^2: what the padding of a stored row adds to an inline sum of squares
+};                          // (pad centroid values are 0 and pad residual bytes are 0, so every pad dim reads exactly wlut[0]; the
+                            //  products themselves vanish against the zero-padded query).  0 for an unpadded index.
 
 #define NP_EXACT_DPW 4   // documents per wave
 
@@ -3026,7 +3027,7 @@ __global__ void __launch_bounds__(256) exact_f32_kernel(ExactP p) {
           for (int e = 0; e < PER; ++e) {
             const int jdim = (w * 4 + i) * PER + e;
             const float c = reinterpret_cast<const float*>(cp)[jdim];
-            const float x = (kk * H + jdim < p.ldim) ? c + seg_weight<NBITS>(sW, byte, e) : 0.f;
+            const float x = c + seg_weight<NBITS>(sW, byte, e);
             v[jdim] = x;
             ss = fmaf(x, x, ss);
           }
@@ -3035,7 +3036,7 @@ __global__ void __launch_bounds__(256) exact_f32_kernel(ExactP p) {
       // 1/||row|| is applied to the MFMA output rows (S[t][q] = rn[t] * <raw_t, q>) instead of to
       // the 64 fragment values; lane li holds rn of token t0+li, row r of this lane needs token
       // t0 + mfma_row(r, kk).
-      const float tot = ss + __shfl_xor(ss, 32);
+      const float tot = ss + __shfl_xor(ss, 32) - p.pad_ss;
       const float rn = valid ? 1.0f / fmaxf(sqrtf(tot), 1e-12f) : 0.f;
       float rrow[16];
 #pragma unroll
@@ -3139,13 +3140,13 @@ __global__ void __launch_bounds__(256) exact_bf16_kernel(ExactP p) {
           const uint32_t byte = (word >> (8 * i)) & 0xFFu;
 #pragma unroll
           for (int e = 0; e < PER; ++e) {
-            const float x = (d0 + i * PER + e < p.ldim) ? cc[i * PER + e] + seg_weight<NBITS>(sW, byte, e) : 0.f;
+            const float x = cc[i * PER + e] + seg_weight<NBITS>(sW, byte, e);
             a[s][i * PER + e] = (__bf16)x;   // un-normalised; rows are scaled after the MFMA
             ss = fmaf(x, x, ss);
           }
         }
       }
-      const float tot = ss + __shfl_xor(ss, 32);
+      const float tot = ss + __shfl_xor(ss, 32) - p.pad_ss;
       const float rn = valid ? 1.0f / fmaxf(sqrtf(tot), 1e-12f) : 0.f;
       float rrow[16];
 #pragma unroll

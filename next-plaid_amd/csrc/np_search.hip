@@ -879,7 +879,7 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.fast_ok = ix->s6_fast_ok ? 1 : 0;
     ep.qt0 = 0;
     ep.acc = 0;
-    ep.ldim = ix->ldim;
+    ep.pad_ss = ix->pad_ss;
     switch (ix->dim) {
       case 32: NP_TRY((launch_exact_nb<32>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
       case 64: NP_TRY((launch_exact_nb<64>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
