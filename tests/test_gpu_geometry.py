@@ -13,9 +13,17 @@ import pytest
 from helpers import (O, RTOL_BF16, RTOL_BF16_PLAIN, RTOL_F32, assert_ranking_close, hip_index, make_arrays, oracle_index,
                      synth, to_oracle_params)
 
+import importlib.util
+import os
+
 import next_plaid_amd as npa
+from helpers import GOLDEN
 
 pytestmark = pytest.mark.gpu
+
+_s = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+MG = importlib.util.module_from_spec(_s)
+_s.loader.exec_module(MG)
 
 # (dim, nbits): padded rows (48, 50: 25-byte rows, 24, 100, 8), 1-bit (64 unpadded, 40 padded: 5-byte rows -> 16), 8-bit
 # (32 and 128 unpadded, 72 padded to 96)
@@ -121,6 +129,29 @@ def test_encode_in_file_geometry(geo):
     assert packed.shape == (n, dim * nbits // 8)
     assert np.array_equal(codes, rc) and codes[5] == K - 1
     assert np.array_equal(packed, rp)
+
+
+@pytest.mark.parametrize("geo", [MG.geo_name(k) for k in MG.GEO_SPECS])
+def test_committed_golden_vectors(geo):
+    """tests/golden/search_geometry.npz (minted by the numpy restatement): cells and candidates equal, selected set equal,
+    ranking within the f32 tolerance -- through search() and through the batched entry."""
+    kw = next(k for k in MG.GEO_SPECS if MG.geo_name(k) == geo)
+    spec = synth.SynthSpec(**kw)
+    hx = hip_index(synth.generate_arrays(spec))
+    gold = np.load(os.path.join(GOLDEN, "search_geometry.npz"))
+    qs = [q for q in gold[f"{geo}_queries"]]
+    for name, pk in MG.GEO_CASES:
+        p = P(**pk)
+        batch = hx.search_batch(qs, p)
+        for qi, q in enumerate(qs):
+            k = f"{geo}_{name}_q{qi}"
+            tr = hx.debug_trace(q, p)
+            assert np.array_equal(tr["cells"], gold[k + "_cells"]), f"{k} cells"
+            assert np.array_equal(tr["cand"], gold[k + "_cand"]), f"{k} candidates"
+            assert set(tr["sel"].tolist()) == set(gold[k + "_sel"].tolist()), f"{k} selection"
+            for r in (hx.search(q, p), batch[qi]):
+                assert_ranking_close(r.passage_ids, r.scores, gold[k + "_ids"], gold[k + "_scores"], RTOL_F32, k)
+    hx.close()
 
 
 def test_on_disk_and_sharded_open(tmp_path):

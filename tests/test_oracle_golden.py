@@ -24,7 +24,7 @@ def test_unpack_tables(nbits):
     assert np.array_equal(got, gold)
 
 
-@pytest.mark.parametrize("nbits", [2, 4])
+@pytest.mark.parametrize("nbits", [1, 2, 4, 8])
 def test_decompress_golden(nbits):
     g = np.load(os.path.join(GOLDEN, f"decompress_nbits{nbits}.npz"))
     out = O.decompress(g["packed"], g["codes"], g["centroids"], g["weights"], nbits)
@@ -53,6 +53,24 @@ def test_search_golden(golden_index, case):
         assert_ranking_close(r.passage_ids, r.scores, gold[f"{name}_q{qi}_ids"], gold[f"{name}_q{qi}_scores"],
                              RTOL_F32, f"{name} q{qi}")
         assert r.passage_ids[0] == gold["src"][qi] or sub is not None  # the source doc is found
+
+
+@pytest.mark.parametrize("geo", [MG.geo_name(k) for k in MG.GEO_SPECS])
+def test_search_golden_other_geometries(geo):
+    """dim 50 / 4-bit, dim 40 / 1-bit, dim 72 / 8-bit (codec.rs:161-166 geometries without a kernel instantiation)."""
+    kw = next(k for k in MG.GEO_SPECS if MG.geo_name(k) == geo)
+    spec = synth.SynthSpec(**kw)
+    ix = oracle_index(synth.generate_arrays(spec))
+    gold = np.load(os.path.join(GOLDEN, "search_geometry.npz"))
+    for name, pk in MG.GEO_CASES:
+        p = O.SearchParameters(**pk)
+        for qi, q in enumerate(gold[f"{geo}_queries"]):
+            r = ix.search(q, p, None, trace=True)
+            k = f"{geo}_{name}_q{qi}"
+            assert np.array_equal(r.trace.cells, gold[k + "_cells"]), f"{k} cells"
+            assert np.array_equal(r.trace.cand, gold[k + "_cand"]), f"{k} candidates"
+            assert set(r.trace.sel.tolist()) == set(gold[k + "_sel"].tolist()), f"{k} selection"
+            assert_ranking_close(r.passage_ids, r.scores, gold[k + "_ids"], gold[k + "_scores"], RTOL_F32, k)
 
 
 def test_oracle_vs_numpy_ragged_and_edges():
