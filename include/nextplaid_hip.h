@@ -174,6 +174,22 @@ int np_hip_index_export(const np_index* index, int64_t* doc_lengths, int64_t* co
                         int64_t* ivf, int32_t* ivf_lengths);
 int64_t np_hip_index_ivf_size(const np_index* index);
 
+/* Host only (no device): writes host arrays as an index DIRECTORY in the crate's on-disk format -- the canonical file
+ * set of write_index_from_encoded_chunks (index.rs:373-528): centroids / bucket_cutoffs / bucket_weights / avg_residual /
+ * cluster_threshold .npy, plan.json, per chunk of <= chunk_docs documents {i}.metadata.json, doclens.{i}.json,
+ * {i}.codes.npy, {i}.residuals.npy, then ivf.npy, ivf_lengths.npy and metadata.json.  NPY 1.0 headers padded to 64 bytes
+ * (mmap.rs:1176-1250), every file via temporary name + fsync + rename (utils.rs:16-60).  arrays->ivf / ivf_lengths may
+ * be NULL: the posting lists (ascending unique document ids per centroid, index.rs:479-504) are then built from the
+ * codes.  arrays must hold the whole index (doc_begin = 0).  With np_hip_encode_tokens this is the index-build path:
+ * encode on the GPU, write here, and MmapIndex::load (the crate's or np_hip_index_open) reads the result. */
+typedef struct np_write_opts {
+  int64_t chunk_docs;           /* documents per chunk; 0 = 50 000 (IndexConfig.batch_size, index.rs:92) */
+  const float* bucket_cutoffs;  /* [2^nbits - 1] or NULL (file not written; search does not read it) */
+  const float* avg_residual;    /* [dim] or NULL = zeros (not used by search arithmetic) */
+  float cluster_threshold;      /* update path only (update.rs:372) */
+} np_write_opts;
+int np_hip_index_write_dir(const char* index_dir, const np_index_arrays* arrays, const np_write_opts* opts);
+
 /* Kernel-selection knobs (no reference counterpart).  Each knob is read from the environment once, at open, as
  * NP_<UPPER-CASE NAME>, and can be changed on a live handle with this call (sweep tools, kernel-variant parity tests);
  * both paths clamp through one table.  Knobs: "s4_mode" 0..8, "s4_minb" >= 1, "s4_nbx" 8..512, "s4_swz" 0/1,

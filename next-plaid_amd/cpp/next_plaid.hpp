@@ -262,6 +262,44 @@ class MmapIndex {
   np_info info_{};
 };
 
+// index.rs:373-528 write_index_from_encoded_chunks: encoded chunks (flat here) -> an index directory in the crate's
+// on-disk format.  Host only.  Posting lists are built from the codes (index.rs:479-504).
+struct IndexFiles {
+  size_t num_centroids = 0, dim = 0;
+  int nbits = 4;
+  const float* centroids = nullptr;            // [K, dim]
+  std::vector<float> bucket_weights;           // [2^nbits]
+  std::vector<float> bucket_cutoffs;           // [2^nbits - 1] or empty
+  std::vector<float> avg_residual;             // [dim] or empty (zeros)
+  float cluster_threshold = 0.f;
+  std::vector<int64_t> doc_lengths;            // [N]
+  const int64_t* codes = nullptr;              // [sum doc_lengths]
+  const uint8_t* residuals = nullptr;          // [sum doc_lengths, dim * nbits / 8]
+  size_t chunk_docs = 50000;                   // IndexConfig.batch_size (index.rs:92)
+};
+inline void write_index(const std::string& path, const IndexFiles& f) {
+  if (f.bucket_weights.size() != ((size_t)1 << f.nbits)) throw Error(NP_ERR_CODEC, "Codec error: bucket_weights size");
+  if (!f.bucket_cutoffs.empty() && f.bucket_cutoffs.size() + 1 != ((size_t)1 << f.nbits))
+    throw Error(NP_ERR_CODEC, "Codec error: bucket_cutoffs size");
+  if (!f.avg_residual.empty() && f.avg_residual.size() != f.dim) throw Error(NP_ERR_SHAPE, "Shape error: avg_residual size");
+  np_index_arrays a{};
+  a.num_documents_total = a.num_docs = (int64_t)f.doc_lengths.size();
+  a.num_centroids = (int64_t)f.num_centroids;
+  a.dim = (int32_t)f.dim;
+  a.nbits = f.nbits;
+  a.centroids = f.centroids;
+  a.bucket_weights = f.bucket_weights.data();
+  a.doc_lengths = f.doc_lengths.data();
+  a.codes = f.codes;
+  a.residuals = f.residuals;
+  np_write_opts o{};
+  o.chunk_docs = (int64_t)f.chunk_docs;
+  o.bucket_cutoffs = f.bucket_cutoffs.empty() ? nullptr : f.bucket_cutoffs.data();
+  o.avg_residual = f.avg_residual.empty() ? nullptr : f.avg_residual.data();
+  o.cluster_threshold = f.cluster_threshold;
+  check(np_hip_index_write_dir(path.c_str(), &a, &o));
+}
+
 // next-plaid-api handlers/rerank.rs:57-170: MaxSim of one query against caller-supplied document embeddings
 // (document i = rows doc_tok_offsets[i] .. doc_tok_offsets[i+1] of `docs`).  Returns (order, scores).
 inline std::pair<std::vector<int64_t>, std::vector<float>> rerank_maxsim(const float* query, size_t n_query_tokens,

@@ -7,5 +7,5 @@ There is no CPU fallback in this package: if the HIP library or a GPU is missing
 """
 from .api import (  # noqa: F401
     MmapIndex, SearchParameters, QueryResult, NextPlaidError, IndexLoadError, SearchError,
-    ShapeError, CodecError, DeviceUnavailableError, device_count, library_path, rerank_maxsim, probe_index_dir,
+    ShapeError, CodecError, DeviceUnavailableError, device_count, library_path, rerank_maxsim, probe_index_dir, write_index_dir,
 )

@@ -99,6 +99,11 @@ class np_index_arrays(C.Structure):
                 ("residuals", C.c_void_p)]
 
 
+class np_write_opts(C.Structure):
+    _fields_ = [("chunk_docs", C.c_int64), ("bucket_cutoffs", C.c_void_p), ("avg_residual", C.c_void_p),
+                ("cluster_threshold", C.c_float)]
+
+
 class np_synth_spec(C.Structure):
     _fields_ = [("num_docs", C.c_int64), ("num_centroids", C.c_int64), ("dim", C.c_int32), ("nbits", C.c_int32),
                 ("doc_len_min", C.c_int32), ("doc_len_max", C.c_int32), ("n_topics", C.c_int32),
@@ -109,7 +114,7 @@ class np_synth_spec(C.Structure):
 EXPORTS = [
     "np_hip_device_count", "np_hip_last_error", "np_hip_index_open", "np_hip_index_from_arrays",
     "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_tune", "np_hip_index_close",
-    "np_hip_index_info", "np_hip_index_probe_dir", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
+    "np_hip_index_info", "np_hip_index_probe_dir", "np_hip_index_write_dir", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
     "np_hip_search_phase_b", "np_hip_search_end", "np_hip_n_sel", "np_hip_select_cut", "np_hip_merge_topk",
     "np_hip_merge_packed", "np_hip_elig_words", "np_hip_subset_eligible", "np_hip_or_bitmaps",
     "np_hip_comm_unique_id", "np_hip_comm_create", "np_hip_comm_destroy", "np_hip_search_batch_sharded",
@@ -169,6 +174,7 @@ def lib():
     L.np_hip_index_close.restype = None
     L.np_hip_index_info.argtypes = [vp, C.POINTER(np_info)]
     L.np_hip_index_probe_dir.argtypes = [C.c_char_p, C.POINTER(np_info)]
+    L.np_hip_index_write_dir.argtypes = [C.c_char_p, C.POINTER(np_index_arrays), C.POINTER(np_write_opts)]
     L.np_hip_search_batch.argtypes = [vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64, vp, vp, vp,
                                       C.POINTER(np_stats)]
     L.np_hip_search_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,
@@ -213,6 +219,37 @@ def probe_index_dir(path: str) -> np_info:
     info = np_info()
     _check(lib().np_hip_index_probe_dir(os.fsencode(path), C.byref(info)))
     return info
+
+
+def write_index_dir(path: str, centroids, bucket_weights, doc_lengths, codes, residuals, nbits, ivf=None, ivf_lengths=None,
+                    bucket_cutoffs=None, avg_residual=None, cluster_threshold: float = 0.0, chunk_docs: int = 50000):
+    """write_index_from_encoded_chunks (index.rs:373-528): host arrays -> an index directory in the crate's on-disk
+    format (host only).  Without ivf / ivf_lengths the posting lists are built from the codes (index.rs:479-504)."""
+    cen = np.ascontiguousarray(centroids, np.float32)
+    if cen.ndim != 2:
+        raise ShapeError("centroids must be [K, dim]")
+    w = np.ascontiguousarray(bucket_weights, np.float32)
+    dl = np.ascontiguousarray(doc_lengths, np.int64)
+    cd = np.ascontiguousarray(codes, np.int64)
+    rs = np.ascontiguousarray(residuals, np.uint8)
+    pd = cen.shape[1] * int(nbits) // 8
+    if w.size != (1 << int(nbits)):
+        raise CodecError(f"Codec error: bucket_weights has {w.size} entries, nbits={nbits} needs {1 << int(nbits)}")
+    if cd.size != int(dl.sum()) or rs.size != cd.size * pd:
+        raise ShapeError(f"Shape error: {cd.size} codes / {rs.size} residual bytes for {int(dl.sum())} tokens of {pd} bytes")
+    iv = None if ivf is None else np.ascontiguousarray(ivf, np.int64)
+    il = None if ivf_lengths is None else np.ascontiguousarray(ivf_lengths, np.int32)
+    cut = None if bucket_cutoffs is None else np.ascontiguousarray(bucket_cutoffs, np.float32)
+    avg = None if avg_residual is None else np.ascontiguousarray(avg_residual, np.float32)
+    if cut is not None and cut.size != (1 << int(nbits)) - 1:
+        raise CodecError(f"Codec error: bucket_cutoffs has {cut.size} entries, nbits={nbits} needs {(1 << int(nbits)) - 1}")
+    if avg is not None and avg.size != cen.shape[1]:
+        raise ShapeError("avg_residual must have dim entries")
+    a = np_index_arrays(dl.size, 0, dl.size, cen.shape[0], cen.shape[1], int(nbits), _ptr(cen), _ptr(w),
+                        None if iv is None else _ptr(iv), None if il is None else _ptr(il), _ptr(dl), _ptr(cd), _ptr(rs))
+    o = np_write_opts(int(chunk_docs), None if cut is None else _ptr(cut), None if avg is None else _ptr(avg),
+                      float(cluster_threshold))
+    _check(lib().np_hip_index_write_dir(path.encode(), C.byref(a), C.byref(o)))
 
 
 def rerank_maxsim(query, documents, device: int = 0):

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported():
 def test_struct_sizes_match_header(tmp_path):
     # ctypes mirrors vs the C structs as gcc lays them out from include/nextplaid_hip.h (size AND field offsets)
     import subprocess
-    names = ["np_open_opts", "np_search_params", "np_stats", "np_info", "np_index_arrays", "np_synth_spec"]
+    names = ["np_open_opts", "np_search_params", "np_stats", "np_info", "np_index_arrays", "np_synth_spec", "np_write_opts"]
     src = ["#include <stdio.h>", "#include <stddef.h>", '#include "nextplaid_hip.h"', "int main(void) {"]
     for n in names:
         src.append(f'  printf("{n} %zu\\n", sizeof({n}));')

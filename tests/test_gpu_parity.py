@@ -602,6 +602,39 @@ def test_encode_tokens_matches_oracle(dim, nbits, K, n):
     assert c0.shape == (0,) and p0.shape[0] == 0
 
 
+def test_index_build_path_encode_write_load(tmp_path):
+    """The index-build path end to end (index.rs:289-528): embeddings -> np_hip_encode_tokens (codes + packed residuals on
+    the GPU) -> np_hip_index_write_dir (the crate's file set, posting lists built from the codes) -> MmapIndex::load of
+    that directory.  The loaded index must BE the oracle's index of the same embeddings: files equal to the oracle's
+    encode, search results equal to the oracle's search."""
+    dim, nbits, K, N = 96, 4, 200, 600
+    spec, a = make_arrays(num_docs=N, num_centroids=K, dim=dim, nbits=nbits, doc_len_min=3, doc_len_max=24, seed=97)
+    cen, (cut, wts) = a["centroids"], synth.bucket_tables(spec)
+    lens = np.asarray(a["doc_lengths"], np.int64)
+    emb = synth.reconstruct(a["codes"], a["residuals"], cen, wts, nbits)       # the documents' token embeddings
+    rng = np.random.default_rng(98)
+    emb = emb + (0.05 / np.sqrt(dim)) * rng.standard_normal(emb.shape).astype(np.float32)
+    emb = (emb / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float32)
+    enc = hip_index(a)                                       # any handle with these centroids encodes (codec.rs:297-411)
+    codes, packed = enc.encode_tokens(emb, cut)
+    rc, rp = O.encode_tokens(emb, cen, nbits, cut)
+    assert np.array_equal(codes, rc) and np.array_equal(packed, rp)
+    npa.write_index_dir(str(tmp_path), cen, wts, lens, codes, packed, nbits, bucket_cutoffs=cut, chunk_docs=250)
+    hx = npa.MmapIndex.load(str(tmp_path))
+    ivf, il = synth.build_ivf(rc, lens, K)
+    ox = O.OracleIndex(cen, wts, ivf, il, lens, rc, rp, nbits)
+    e = hx.export()
+    assert np.array_equal(e["codes"], rc) and np.array_equal(e["residuals"], rp)
+    assert np.array_equal(e["ivf"], ivf) and np.array_equal(e["ivf_lengths"], il)
+    qs = [emb[int(o):int(o) + min(int(l), 16)] for o, l in zip(np.cumsum(lens)[:8] - lens[:8], lens[:8])]
+    p = P(n_full_scores=128, top_k=10, n_ivf_probe=8)
+    for i, (g, o) in enumerate(zip(hx.search_batch(qs, p), ox.search_batch(qs, to_oracle_params(p)))):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"built index q{i}")
+        assert g.passage_ids[0] == i                        # a document's own tokens find it
+    for h in (enc, hx):
+        h.close()
+
+
 def test_rerank_maxsim_matches_handler():
     """next-plaid-api handlers/rerank.rs:57-170: scores bit-identical to the sequential multiply-then-add loop,
     stable descending order, the integration test's 2.0 / 1.0 / 0.0 answers, and the two BadRequest cases."""
