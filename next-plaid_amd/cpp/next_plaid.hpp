@@ -136,6 +136,13 @@ class MmapIndex {
     check(rc);
     return MmapIndex(h, index_path);
   }
+  // MmapIndex::reload (index.rs:1767-1775): after delete / update rewrote the directory.  The crate releases its maps before
+  // it loads again; here the device copy is dropped first for the same reason (two copies of a 200 GB index do not fit).
+  // Exclusive access like `&mut self`; a service swaps handles.  Same device policy as load().
+  void reload(const np_open_opts* opts = nullptr) {
+    MmapIndex fresh = (close(), load(path, opts));
+    *this = std::move(fresh);
+  }
   bool on_device() const { return h_ != nullptr; }
   MmapIndex(MmapIndex&& o) noexcept : path(std::move(o.path)), h_(o.h_), info_(o.info_) { o.h_ = nullptr; }
   MmapIndex& operator=(MmapIndex&& o) noexcept {

@@ -323,9 +323,10 @@ def _opts(device=0, shard_rank=0, shard_count=1, n_contexts=2, max_batch=64, max
 class MmapIndex:
     """Device-resident PLAID index; mirror of next_plaid::MmapIndex (index.rs:995-1312)."""
 
-    def __init__(self, handle, path=""):
+    def __init__(self, handle, path="", open_opts=None):
         self._h = handle
         self.path = path
+        self._open_opts = dict(open_opts or {})
         self._info = np_info()
         _check(lib().np_hip_index_info(self._h, C.byref(self._info)))
         self.last_stats: dict | None = None
@@ -337,7 +338,23 @@ class MmapIndex:
         h = C.c_void_p()
         o = _opts(**opts)
         _check(lib().np_hip_index_open(os.fsencode(index_path), C.byref(o), C.byref(h)))
-        return cls(h, index_path)
+        return cls(h, index_path, opts)
+
+    def reload(self):
+        """MmapIndex::reload (index.rs:1767-1775): refresh the resident index from its directory after the files changed
+        (delete / update write new chunk files).  Like the crate -- which releases its maps first -- the old device copy is
+        dropped BEFORE the new one is read: two 200 GB copies do not fit one GPU.  Exclusive access, as `&mut self` there;
+        a service swaps handles instead.  If the directory no longer loads, the error is raised
+        and the handle stays closed."""
+        if not self.path or self.path.startswith("<"):
+            raise IndexLoadError("Index load failed: reload() needs an index opened from a directory")
+        self.close()
+        h = C.c_void_p()
+        o = _opts(**self._open_opts)
+        _check(lib().np_hip_index_open(os.fsencode(self.path), C.byref(o), C.byref(h)))
+        self._h = h
+        _check(lib().np_hip_index_info(self._h, C.byref(self._info)))
+        self.last_stats = None
 
     @classmethod
     def from_arrays(cls, centroids, bucket_weights, ivf, ivf_lengths, doc_lengths, codes, residuals, nbits,

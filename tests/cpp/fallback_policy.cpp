@@ -36,6 +36,8 @@ int main(int argc, char** argv) {
     std::printf("cleared broken=%d\n", (int)next_plaid::is_hip_broken());
     // geometry accessors stay valid on the CPU hand-off (host-only parse), device-only methods say so
     std::printf("geom %zu %zu %zu\n", again.num_documents(), again.embedding_dim(), again.num_partitions());
+    again.reload();   // index.rs:1767: same policy as load, geometry refreshed from the directory
+    std::printf("reloaded %s %zu\n", again.on_device() ? "device" : "cpu", again.num_documents());
     if (!again.on_device()) {
       try {
         (void)again.decompress_documents({0});

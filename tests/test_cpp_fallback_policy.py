@@ -44,8 +44,9 @@ def test_device_failure_hands_off_to_cpu_and_raises_the_flag(exe, index_dir, gpu
         assert "Falling back to CPU" in r.stderr
     assert lines[2] == "cleared broken=0"
     assert lines[3] == "geom 200 64 64", r.stdout          # accessors valid with or without a device handle
+    assert lines[4] == ("reloaded device 200" if gpu_available else "reloaded cpu 200"), r.stdout   # index.rs:1767, load()'s policy
     if not gpu_available:
-        assert lines[4] == "decompress error 6"            # device-only method: a clear Error, not a NULL handle in the ABI
+        assert lines[5] == "decompress error 6"            # device-only method: a clear Error, not a NULL handle in the ABI
 
 
 def test_force_gpu_never_falls_back(exe, index_dir, gpu_available):

@@ -441,6 +441,33 @@ def test_on_disk_index_equals_arrays(tmp_path):
         assert np.array_equal(r1.passage_ids, r2.passage_ids) and np.array_equal(r1.scores, r2.scores)
 
 
+def test_reload_after_the_directory_changed(tmp_path):
+    """MmapIndex::reload (index.rs:1767-1775): delete() rewrites the chunk files and re-sequences the ids
+    (delete.rs:66-120); reload() must serve the new directory -- here: the same corpus without its first 100 documents."""
+    spec, a = make_arrays(num_docs=500, num_centroids=128, dim=128, nbits=4, doc_len_min=5, doc_len_max=40, seed=23)
+    synth.write_index(str(tmp_path), a, chunk_docs=200)
+    hx = npa.MmapIndex.load(str(tmp_path), max_batch=8)
+    qs, src = synth.make_queries(spec, 4, n_tokens=32, cen=a["centroids"])
+    p = P(n_full_scores=128, top_k=5, n_ivf_probe=8)
+    before = hx.search_batch(qs, p)
+    lens = np.asarray(a["doc_lengths"], np.int64)
+    t0 = int(lens[:100].sum())
+    npa.write_index_dir(str(tmp_path), a["centroids"], a["bucket_weights"], lens[100:], a["codes"][t0:], a["residuals"][t0:],
+                        4, chunk_docs=200)
+    assert hx.num_documents() == 500                      # nothing changes until reload
+    hx.reload()
+    assert hx.num_documents() == 400 and hx.num_embeddings() == int(lens[100:].sum())
+    ivf, il = synth.build_ivf(a["codes"][t0:], lens[100:], 128)
+    ox = O.OracleIndex(a["centroids"], a["bucket_weights"], ivf, il, lens[100:], a["codes"][t0:], a["residuals"][t0:], 4)
+    for i, (g, o) in enumerate(zip(hx.search_batch(qs, p), ox.search_batch(qs, to_oracle_params(p)))):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"reloaded q{i}")
+        if src[i] >= 100:
+            assert g.passage_ids[0] == src[i] - 100 == before[i].passage_ids[0] - 100   # ids re-sequenced
+    with pytest.raises(npa.IndexLoadError):
+        hip_index(a).reload()                             # not opened from a directory
+    hx.close()
+
+
 def test_float16_index_files(tmp_path):
     """fast-plaid '<f2' centroids / bucket_weights (mmap.rs:1757-1778): same results as the widened '<f4' files."""
     spec, a = make_arrays(num_docs=600, num_centroids=96, dim=64, nbits=2, doc_len_min=5, doc_len_max=40, seed=19)
