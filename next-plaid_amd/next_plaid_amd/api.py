@@ -301,6 +301,28 @@ class SearchParameters:
     centroid_score_threshold: float | None = 0.4
     precision: int = 2
 
+    # serde (search.rs:26-48): the four counts are required fields, `centroid_batch_size` and `centroid_score_threshold`
+    # carry #[serde(default = ...)] (100 000 / Some(0.4)); an explicit null threshold is None; unknown fields are ignored
+    @classmethod
+    def from_json(cls, text) -> "SearchParameters":
+        import json
+        d = json.loads(text) if isinstance(text, (str, bytes)) else dict(text)
+        for k in ("batch_size", "n_full_scores", "top_k", "n_ivf_probe"):
+            if k not in d:
+                raise ValueError(f"missing field `{k}`")
+            if isinstance(d[k], bool) or not isinstance(d[k], int) or d[k] < 0:
+                raise ValueError(f"invalid type for `{k}`: expected usize")
+        t = d.get("centroid_score_threshold", 0.4)
+        return cls(batch_size=d["batch_size"], n_full_scores=d["n_full_scores"], top_k=d["top_k"], n_ivf_probe=d["n_ivf_probe"],
+                   centroid_batch_size=int(d.get("centroid_batch_size", 100_000)),
+                   centroid_score_threshold=None if t is None else float(t), precision=int(d.get("precision", 2)))
+
+    def to_json(self) -> str:
+        import json
+        return json.dumps(dict(batch_size=self.batch_size, n_full_scores=self.n_full_scores, top_k=self.top_k,
+                               n_ivf_probe=self.n_ivf_probe, centroid_batch_size=self.centroid_batch_size,
+                               centroid_score_threshold=self.centroid_score_threshold))
+
     def _c(self) -> np_search_params:
         t = self.centroid_score_threshold
         return np_search_params(self.top_k, self.n_full_scores, self.n_ivf_probe, self.centroid_batch_size,

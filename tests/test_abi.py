@@ -162,3 +162,19 @@ def test_bad_rccl_override_is_an_error_code_not_a_crash():
     assert rc in (0, 6), r.stdout          # NP_OK (a later candidate loaded) or NP_ERR_DEVICE_UNAVAILABLE
     if rc == 6:
         assert "librccl is not available" in r.stdout or "ncclGetUniqueId" in r.stdout
+
+
+def test_search_parameters_serde_shape():
+    """search.rs:26-48: four required counts, serde defaults for the two newer fields, null threshold = None."""
+    P = npa.SearchParameters
+    p = P.from_json('{"batch_size": 2000, "n_full_scores": 8192, "top_k": 20, "n_ivf_probe": 16}')
+    assert (p.n_full_scores, p.top_k, p.n_ivf_probe, p.centroid_batch_size, p.centroid_score_threshold) == (8192, 20, 16, 100_000, 0.4)
+    p = P.from_json('{"batch_size": 1, "n_full_scores": 4, "top_k": 1, "n_ivf_probe": 1, "centroid_score_threshold": null, '
+                    '"centroid_batch_size": 0, "unknown": 5}')
+    assert p.centroid_score_threshold is None and p.centroid_batch_size == 0
+    with pytest.raises(ValueError, match="missing field `top_k`"):
+        P.from_json('{"batch_size": 1, "n_full_scores": 4, "n_ivf_probe": 1}')
+    with pytest.raises(ValueError, match="usize"):
+        P.from_json('{"batch_size": 1, "n_full_scores": -4, "top_k": 1, "n_ivf_probe": 1}')
+    q = P.from_json(P().to_json())
+    assert q == P() and "precision" not in P().to_json()      # the extra knob never leaks into the crate's JSON
