@@ -184,7 +184,8 @@ def main():
     def qbatch(i):   # replica groups walk the query batches at different offsets: different batches at the same time
         return (i + repl) % a.query_batches
 
-    if use_shards and a.dist_impl == "c":
+    dist_impl, dist_note = a.dist_impl, ""
+    if use_shards and dist_impl == "c":
         # the whole protocol below the C ABI (np_hip_search_batch_sharded, RCCL all-gathers issued by the library on
         # the call's stream): one communicator per stream so the collectives of batch i overlap the kernels of batch
         # i+1; rank 0's ncclUniqueId reaches the other ranks through a torch.distributed broadcast
@@ -199,7 +200,40 @@ def main():
             obj = [b]
             dist.broadcast_object_list(obj, src=repl * n_shards, group=grp)
             return obj[0]
-        comms = [ShardComm(ix, shard, n_shards, exchange=exchange if n_shards > 1 else None) for _ in range(nstr)]
+
+        # np_hip_comm_create is collective (ncclCommInitRank): if it fails anywhere (librccl missing, an id that could not
+        # be drawn) EVERY rank falls back to the torch.distributed harness of the same protocol, and the line says so.
+        comms, err = [], ""
+        try:
+            try:
+                if shard == 0 and n_shards > 1:
+                    buf = C.create_string_buffer(128)
+                    api._check(L.np_hip_comm_unique_id(buf))   # librccl loads here, before any collective is entered
+            except Exception as ex:   # noqa: BLE001
+                err = f"{type(ex).__name__}: {ex}"
+            if use_dist:
+                flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()) and not err:
+                    err = "np_hip_comm_unique_id failed on another rank"
+            if not err:
+                comms = [ShardComm(ix, shard, n_shards, exchange=exchange if n_shards > 1 else None) for _ in range(nstr)]
+        except Exception as ex:       # noqa: BLE001 -- a failure inside ncclCommInitRank itself
+            err = err or f"{type(ex).__name__}: {ex}"
+        if use_dist:
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and not err:
+                err = "np_hip_comm_create failed on another rank"
+        if err and n_repl == 1 and use_dist:
+            for cm in comms:
+                cm.close()
+            dist_impl = "torch"
+            dist_note = f" [np_hip_comm_create failed ({err[:160]}): fell back to the torch.distributed harness]"
+            print("bench.py:" + dist_note, file=sys.stderr)
+        elif err:
+            raise SystemExit(f"bench.py: the RCCL communicator could not be created: {err}")
+    if use_shards and dist_impl == "c":
         sss = [CShardedSearcher(ix, comms[s], stream=streams[s]) for s in range(nstr)]
         ss = sss[0]
 
@@ -246,6 +280,11 @@ def main():
         step(i)
     barrier()
     dt = time.perf_counter() - t0
+    if use_shards and dist_impl == "c":
+        for cm in comms:   # a rank that failed locally empties the batch everywhere and leaves its status here (np_dist.hip)
+            fr, code = cm.status()
+            if code:
+                raise SystemExit(f"bench.py: shard {fr} failed with np_status {code} inside the timed region")
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -384,7 +423,7 @@ def main():
                                f"n_full_scores={a.n_full_scores}, t_cs={thr}, top_k={a.top_k}; one fixed corpus sharded "
                                f"{n_shards} way(s) x {n_repl} replica group(s): {docs_local} docs on rank 0's GPU",
                    "docs_total": a.docs, "docs_per_gpu": docs_local, "batch": a.batch, "shards": n_shards, "replicas": n_repl,
-                   "parallelism": ((f"doc-shard x{n_shards} + RCCL all-gather ({'np_hip_search_batch_sharded' if a.dist_impl == 'c' else 'torch.distributed harness'})"
+                   "parallelism": ((f"doc-shard x{n_shards} + RCCL all-gather ({'np_hip_search_batch_sharded' if dist_impl == 'c' else 'torch.distributed harness'}){dist_note}"
                                     if use_shards else "whole index per GPU")
                                    + (f", x{n_repl} replica groups on different batches" if n_repl > 1 else ""))
                                   if use_dist else "single GPU"},

@@ -194,9 +194,10 @@ int np_hip_index_write_dir(const char* index_dir, const np_index_arrays* arrays,
  * NP_<UPPER-CASE NAME>, and can be changed on a live handle with this call (sweep tools, kernel-variant parity tests);
  * both paths clamp through one table.  Knobs: "s4_mode" 0..8, "s4_minb" >= 1, "s4_nbx" 8..512, "s4_swz" 0/1,
  * "s4_filter" 0/1, "s4_hot" 0..500 (per-mille of hot centroids in the first filter level; 0 = single-level filter),
- * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "ub_direct" 0..16, "ub_static" 0/1, "hot_static" 0/1, "s4_probe" 0..7 (diagnostic: results invalid when != 0), "s6_xcd" 0/1, "s6_tiles" 0/1, "s6_lds" 0..2, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
+ * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "ub_direct" 0..16, "ub_static" 0/1, "hot_static" 0/1, "s6_xcd" 0/1, "s6_tiles" 0/1, "s6_lds" 0..2, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
  * Results are identical for every setting; not synchronised with concurrent searches.  Unknown name:
- * NP_ERR_INVALID_ARGUMENT. */
+ * NP_ERR_INVALID_ARGUMENT.  (A library built with -DNP_DIAGNOSTICS also accepts "s4_probe" 0..7, a phase-skipping timing
+ * probe whose results are invalid; production builds reject the name and never read it from the environment.) */
 int np_hip_index_tune(np_index* index, const char* name, int32_t value);
 
 void np_hip_index_close(np_index* index);               /* Drop for MmapIndex */
@@ -289,11 +290,32 @@ int np_hip_merge_packed(const np_index* index, const void* d_records, int64_t re
  * top-k (identical to the unsharded search, subsets included) in the output buffers of EVERY rank.  All ranks must
  * call it with the same queries / params / subset in the same order.  librccl is loaded at first use
  * (dlopen "librccl.so.1"; NEXTPLAID_RCCL_LIB overrides); nranks == 1 with id128 == NULL needs no RCCL at all.
- * A communicator serialises its calls; use one per concurrent stream. */
+ * A communicator serialises its calls; use one per concurrent stream.
+ *
+ * Failure of ONE rank never blocks the others: every exchange record carries a status word, a rank whose local work
+ * fails (its workspace does not fit, a launch error) still takes part in both all-gathers with empty data and returns its
+ * own error at once; on the other ranks the batch comes back EMPTY (every out_counts[i] = 0) and np_hip_comm_status
+ * -- valid once `stream` is synchronised -- names the failed rank and its np_status.  With the hosted transport below the
+ * gathered bytes pass through the host, so every rank returns NP_ERR_SEARCH from the call itself (after gather 1). */
 typedef struct np_comm np_comm;
 int np_hip_comm_unique_id(void* id128);
 int np_hip_comm_create(const np_index* index, const void* id128, int32_t rank, int32_t nranks, np_comm** out);
 void np_hip_comm_destroy(np_comm* comm);
+/* Reads and clears the failure word of the communicator's last batches: *failed_rank = -1 and *code = 0 if every batch
+ * since the last call was healthy, else the first failed rank and its np_status.  Call after synchronising the stream. */
+int np_hip_comm_status(np_comm* comm, int32_t* failed_rank, int32_t* code);
+/* The same protocol over a transport the HOST brings (MPI, gloo, shared memory, the crate's own RPC) instead of RCCL:
+ * for hosts without librccl, for ranks that share one GPU (RCCL refuses two ranks on a device), and for the tests that
+ * run the shipped multi-rank code path on a one-GPU box.  `all_gather(ctx, send, recv, bytes)` is called on the calling
+ * thread with HOST pointers: it must place rank r's `bytes` bytes at recv + r * bytes for every rank and return 0.  The
+ * library stages the (<= 0.6 MB) records through pinned memory and synchronises the stream around the callback, so a
+ * hosted communicator costs two stream synchronisations per batch; results are identical to the RCCL transport.
+ * flags: NP_COMM_DEFERRED_STATUS = do not inspect the gathered status words on the host (propagate a failure on the
+ * device like the RCCL transport does; np_hip_comm_status reports it). */
+typedef int (*np_all_gather_host_fn)(void* ctx, const void* send, void* recv, int64_t bytes);
+#define NP_COMM_DEFERRED_STATUS 1
+int np_hip_comm_create_hosted(const np_index* index, int32_t rank, int32_t nranks, np_all_gather_host_fn all_gather,
+                              void* ctx, int32_t flags, np_comm** out);
 int np_hip_search_batch_sharded(const np_index* index, np_comm* comm, const float* d_queries,
                                 const int32_t* d_q_tok_offsets, const int32_t* h_q_tok_offsets, int32_t B, int32_t dim,
                                 const np_search_params* params, const int64_t* d_subset, int64_t subset_len,

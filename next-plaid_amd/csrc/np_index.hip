@@ -76,7 +76,9 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "ub_steal") t->ub_steal = value < 1 ? 1 : value;
   else if (n == "ub_nbx") t->ub_nbx = clamp(value, 8, 256);
   else if (n == "ub_direct") t->ub_direct = clamp(value, 0, 16);
+#ifdef NP_DIAGNOSTICS   // phase-skipping timing probe of the hot kernel: results are INVALID when != 0, so a production build has no way to set it
   else if (n == "s4_probe") t->s4_probe = clamp(value, 0, 7);
+#endif
   else if (n == "ub_static") t->ub_static = value != 0;
   else if (n == "hot_static") t->hot_static = value != 0;
   else if (n == "s6_xcd") t->s6_xcd = value != 0;
@@ -92,7 +94,7 @@ void read_tuning_env(Tuning* t) {
   static const char* const knobs[][2] = {
       {"NP_S4_MODE", "s4_mode"}, {"NP_S4_MINB", "s4_minb"}, {"NP_S4_NBX", "s4_nbx"}, {"NP_S4_SWZ", "s4_swz"},
       {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
-      {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_S4_PROBE", "s4_probe"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"},
+      {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"},
       {"NP_EXACT_ROWMAX", "exact_rowmax"}};
   for (const auto& k : knobs) {
     const char* e = getenv(k[0]);
@@ -105,7 +107,9 @@ void read_tuning_env(Tuning* t) {
 // (B x n_docs entries / pool) and the empty ones cost ~45 us of launches each: 16 GiB is 3 rounds at 10 M documents where
 // 8 GiB was 6.  A 12.5 M x 300-token shard (268 GB) leaves 12 GiB per context with three contexts.
 static void default_workspace(DeviceIndex* ix) {
-  if (ix->opts.workspace_bytes > 0) return;
+  ix->ws_auto = ix->opts.workspace_bytes <= 0;
+  ix->ws_budget = ix->opts.workspace_bytes;
+  if (!ix->ws_auto) return;
   size_t free_b = 0, total_b = 0;
   int64_t ws = (int64_t)8 << 30;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -113,6 +117,7 @@ static void default_workspace(DeviceIndex* ix) {
     ws = std::min<int64_t>((int64_t)16 << 30, std::max<int64_t>((int64_t)2 << 30, share));
   }
   ix->opts.workspace_bytes = ws;
+  ix->ws_budget = ws;
 }
 
 static int check_device(int dev) {
@@ -618,6 +623,11 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
   if (total >= ((int64_t)1 << 40)) {   // candidate records carry a 40-bit list offset
     set_error("Index load failed: %lld distinct-code list entries exceed the 40-bit list offset; use more shards",
               (long long)total);
+    return NP_ERR_INDEX_LOAD;
+  }
+  if (ovf_total / NP_ULIST_ALIGN >= ((int64_t)1 << 32)) {   // a block header carries the overflow index in 32 bits
+    set_error("Index load failed: %lld overflow list entries exceed the 32-bit overflow index of the list blocks; use more shards",
+              (long long)ovf_total);
     return NP_ERR_INDEX_LOAD;
   }
   ix->n_ucodes = total;

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <condition_variable>
 #include <string>
@@ -182,6 +183,12 @@ struct DeviceIndex {
   int64_t ivf_size = 0;
   size_t device_bytes = 0;
   np_open_opts opts{};
+  // per-context scratch budget the planner uses.  A caller-given workspace_bytes is kept as it is; the default (what the device
+  // had free at open, np_index.hip default_workspace) is re-clamped against what is free NOW whenever a candidate pool has to
+  // grow, and halved when a reservation still fails: a second index opened on the device (the "swap handles" reload pattern),
+  // or an encoder allocating later, shrinks the pool (more rounds) instead of failing the search with OutOfMemory.
+  mutable std::atomic<int64_t> ws_budget{0};
+  bool ws_auto = false;
   Tuning tune;
   CodeArr codes() const { return CodeArr{d_codes, code_wide}; }
   CodeArr ucodes() const { return CodeArr{d_ucodes, code_wide}; }
@@ -211,6 +218,15 @@ void shard_range(int64_t n_total, int rank, int count, int64_t* b, int64_t* e);
 
 // np_search.hip
 void destroy_context(Context* c);
+// document-sharded exchange on records with a per-rank status trailer (np_dist.hip); the C ABI's np_hip_select_cut /
+// np_hip_merge_packed are the status-free cases
+int select_cut_strided(const DeviceIndex* ix, const uint64_t* d_all_keys, int64_t rank_stride, int64_t status_off, int G,
+                       int B, int n_sel, uint64_t* d_cut, hipStream_t st);
+bool select_cut_fits(int G, int n_sel);
+int merge_packed_status(const DeviceIndex* ix, const void* d_records, int64_t record_bytes, int64_t off_keys,
+                        int64_t off_scores, int64_t off_counts, int64_t off_status, uint64_t* h_status, int G, int B,
+                        int top_k, int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts, hipStream_t st);
+int set_status_word(const DeviceIndex* ix, uint64_t* d_word, uint64_t value, hipStream_t st);
 
 struct DeviceGuard {
   int prev = -1;

@@ -3940,9 +3940,13 @@ __global__ void __launch_bounds__(1024) topk_kernel(TopkP p) {
 // ---------------------------------------------------------------------------------------------
 // document-sharded exchange
 // ---------------------------------------------------------------------------------------------
-// cut[b] = the n_sel-th largest key over the G shards' lists (1 if fewer exist: keep everything)
-__global__ void __launch_bounds__(1024) select_cut_kernel(const uint64_t* __restrict__ all_keys, int G, int B,
-                                                          int n_sel, int NP2, uint64_t* __restrict__ cut) {
+// cut[b] = the n_sel-th largest key over the G shards' lists (1 if fewer exist: keep everything).  Rank g's list starts
+// rs u64 words after rank g-1's (rs = B * n_sel for contiguous [G][B][n_sel] lists; np_dist.hip appends a status trailer to
+// every rank's record: status_off >= 0 is its word offset inside a record, and a non-zero status of ANY rank makes the
+// cut ~0 -- no local candidate survives, the batch comes back empty on every rank instead of silently missing a shard).
+__global__ void __launch_bounds__(1024) select_cut_kernel(const uint64_t* __restrict__ all_keys, int64_t rs,
+                                                          int64_t status_off, int G, int B, int n_sel, int NP2,
+                                                          uint64_t* __restrict__ cut) {
   extern __shared__ uint64_t s_sel[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = G * n_sel;
@@ -3950,16 +3954,22 @@ __global__ void __launch_bounds__(1024) select_cut_kernel(const uint64_t* __rest
     uint64_t v = 0;
     if (i < n) {
       const int g = i / n_sel, j = i - g * n_sel;
-      v = all_keys[((int64_t)g * B + b) * n_sel + j];
+      v = all_keys[(int64_t)g * rs + (int64_t)b * n_sel + j];
     }
     s_sel[i] = v;
   }
   bitonic_sort_desc(s_sel, NP2, tid, 1024);
   if (tid == 0) {
     const uint64_t c = (n_sel > 0) ? s_sel[n_sel - 1] : 0ull;
-    cut[b] = c ? c : 1ull;
+    uint64_t failed = 0;
+    if (status_off >= 0)
+      for (int g = 0; g < G; ++g) failed |= all_keys[(int64_t)g * rs + status_off];
+    cut[b] = failed ? ~0ull : (c ? c : 1ull);
   }
 }
+
+// one u64 status word of a rank's exchange record: 0 = healthy, else np_status | (rank + 1) << 32
+__global__ void set_status_kernel(uint64_t* __restrict__ word, uint64_t value) { *word = value; }
 
 // out[w] = OR over the G gathered bitmaps (eligible centroids of a subset, search.rs:350-364, across document shards)
 __global__ void or_reduce_kernel(const uint32_t* __restrict__ all, int G, int64_t words, uint32_t* __restrict__ out) {
@@ -3971,14 +3981,29 @@ __global__ void or_reduce_kernel(const uint32_t* __restrict__ all, int G, int64_
 }
 
 // merge G x top_k triples by (exact desc [finite first], approx key desc); rank by counting.  Rank g's arrays start
-// rs_* elements after rank g-1's (contiguous [G][B][top_k] arrays, or one packed record per rank).
+// rs_* elements after rank g-1's (contiguous [G][B][top_k] arrays, or one packed record per rank).  status (nullable):
+// one u64 per rank, rs_status words apart; a non-zero word of any rank empties every query of the batch and the first such
+// word is left in *host_status (pinned host memory the caller reads after synchronising the stream).
 __global__ void __launch_bounds__(256) merge_topk_kernel(const int64_t* __restrict__ ids, const float* __restrict__ scores,
                                                          const uint64_t* __restrict__ keys,
                                                          const int32_t* __restrict__ counts, int64_t rs_ids,
                                                          int64_t rs_scores, int64_t rs_keys, int64_t rs_counts, int G,
                                                          int B, int top_k, int64_t* __restrict__ out_ids,
-                                                         float* __restrict__ out_scores, int32_t* __restrict__ out_counts) {
+                                                         float* __restrict__ out_scores, int32_t* __restrict__ out_counts,
+                                                         const uint64_t* __restrict__ status = nullptr, int64_t rs_status = 0,
+                                                         uint64_t* __restrict__ host_status = nullptr) {
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (status) {
+    uint64_t failed = 0;
+    for (int g = 0; g < G && !failed; ++g) failed = status[(int64_t)g * rs_status];
+    if (failed) {   // wave-uniform: every thread read the same words
+      if (tid == 0) {
+        out_counts[b] = 0;
+        if (b == 0 && host_status) *host_status = failed;
+      }
+      return;
+    }
+  }
   const int n = G * top_k;
   int total = 0;
   for (int g = 0; g < G; ++g) total += counts[g * rs_counts + b];

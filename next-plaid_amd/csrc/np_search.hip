@@ -33,6 +33,13 @@ struct Workspace {
     if (done) (void)hipEventDestroy(done);
     done = nullptr;
   }
+  size_t pool_bytes() const {   // the candidate pool and its companions (sized by the budget)
+    return cand.cap + cand_meta.cap + approx.cap + ub.cap + surv_meta.cap + ub2.cap + list_meta.cap;
+  }
+  void release_pool() {
+    DevBuf* pool[] = {&cand, &cand_meta, &approx, &ub, &surv_meta, &ub2, &list_meta};
+    for (DevBuf* b : pool) b->release();
+  }
   int pin(size_t bytes) {
     if (bytes <= h_pin_cap) return NP_OK;
     if (h_pin) (void)hipHostFree(h_pin);
@@ -198,7 +205,7 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int to
 
 static WsPlan plan_workspace(const DeviceIndex* ix, int B, int LQP, const np_search_params* prm) {
   WsPlan w;
-  const int64_t budget = ix->opts.workspace_bytes;
+  const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
   const int64_t pq = std::max<int64_t>(per_query_bytes(ix, LQP, n_sel_of(prm), prm->top_k), 1);
   const int64_t nd = std::max<int64_t>(ix->n_docs, 1);
   const int cap = (int)std::min<int64_t>(std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB), std::max(B, 1));
@@ -388,8 +395,28 @@ static void launch_matvec(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
 }
 
 // S1..S5 for queries [0,B) whose rows live in d_q (absolute offsets d_qoff/h_qoff).
+static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
+                        const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len);
+
+// A reservation that fails under the DEFAULT budget (another index or an encoder took the memory since open) is retried
+// with the pool released and the budget halved -- more candidate-pool rounds instead of OutOfMemory.  Every reservation of
+// a pass happens before its first launch touches the buffer concerned, so a failed pass leaves nothing half-done.
 static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
                    const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len) {
+  for (int attempt = 0;; ++attempt) {
+    const int rc = phase_a_once(ix, cs, d_q, d_qoff, h_qoff, d_subset, subset_len);
+    if (rc != NP_ERR_OUT_OF_MEMORY || !ix->ws_auto || attempt >= 4) return rc;
+    const int64_t b = ix->ws_budget.load(std::memory_order_relaxed);
+    if (b <= ((int64_t)256 << 20)) return rc;
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(cs->stream);   // the pool may still be read by work queued before the failure
+    cs->ctx->ws->release_pool();
+    ix->ws_budget.store(std::max<int64_t>(b / 2, (int64_t)256 << 20), std::memory_order_relaxed);
+  }
+}
+
+static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
+                        const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len) {
   Workspace& w = *cs->ctx->ws;
   hipStream_t st = cs->stream;
   const int B = cs->B;
@@ -427,7 +454,23 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
   const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
   const int nchunks = (int)((NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS);
   const int nsel1 = std::max(cs->n_sel, 1), topk1 = std::max(prm.top_k, 1);
-  const WsPlan plan = plan_workspace(ix, B, LQP, &prm);
+  WsPlan plan = plan_workspace(ix, B, LQP, &prm);
+  if (ix->ws_auto) {
+    // the default budget was what the device had free at open: before a pool GROWS, look at what is free now
+    const int64_t want = std::min<int64_t>(plan.pool, (int64_t)std::max(B, 1) * std::max<int64_t>(ix->n_docs, 1));
+    if ((int64_t)w.cand.cap < want * 4) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const int64_t held = (int64_t)w.pool_bytes();
+        const int64_t avail = (int64_t)free_b + held - ((int64_t)1 << 30);   // keep 1 GiB for the per-query scratch to come
+        const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
+        if (want * NP_POOL_ENTRY > avail && avail < budget) {
+          ix->ws_budget.store(std::max<int64_t>(avail, (int64_t)256 << 20), std::memory_order_relaxed);
+          plan = plan_workspace(ix, B, LQP, &prm);
+        }
+      }
+    }
+  }
   const int64_t pool = std::min<int64_t>(plan.pool, (int64_t)std::max(B, 1) * std::max<int64_t>(ix->n_docs, 1));
   const int max_rounds = std::max(1, std::min(plan.max_rounds, std::max(B, 1)));
 
@@ -966,6 +1009,58 @@ static int run_device(const DeviceIndex* ix, CallState* cs, const float* d_q, co
   return NP_OK;
 }
 
+// ---- document-sharded exchange: the strided forms np_dist.hip uses (one record per rank with a status trailer) -----
+int select_cut_strided(const DeviceIndex* ix, const uint64_t* d_all_keys, int64_t rank_stride, int64_t status_off, int G,
+                       int B, int n_sel, uint64_t* d_cut, hipStream_t st) {
+  if (!ix || !d_all_keys || !d_cut || G < 1 || B < 0 || n_sel < 0 || rank_stride < (int64_t)B * n_sel) {
+    set_error("select_cut: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return NP_OK;
+  DeviceGuard g(ix->device);
+  const int NP2 = next_pow2(std::max(G * n_sel, 1));
+  const size_t lds = (size_t)NP2 * 8;
+  if (lds > 128 * 1024) {
+    set_error("select_cut: G*n_sel = %d exceeds the 16384-key merge window", G * n_sel);
+    return NP_ERR_SEARCH;
+  }
+  if (lds > 48 * 1024)
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_cut_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  select_cut_kernel<<<B, 1024, lds, st>>>(d_all_keys, rank_stride, status_off, G, B, n_sel, NP2, d_cut);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+bool select_cut_fits(int G, int n_sel) { return (size_t)next_pow2(std::max(G * n_sel, 1)) * 8 <= 128 * 1024; }
+
+int merge_packed_status(const DeviceIndex* ix, const void* d_records, int64_t record_bytes, int64_t off_keys,
+                        int64_t off_scores, int64_t off_counts, int64_t off_status, uint64_t* h_status, int G, int B,
+                        int top_k, int64_t* d_out_ids, float* d_out_scores, int32_t* d_out_counts, hipStream_t st) {
+  if (!ix || !d_records || !d_out_counts || G < 1 || B < 0 || top_k < 0 || (record_bytes & 7) || (off_keys & 7) ||
+      (off_scores & 3) || (off_counts & 3) || (off_status >= 0 && (off_status & 7))) {
+    set_error("merge_packed: invalid argument");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  if (B == 0) return NP_OK;
+  DeviceGuard g(ix->device);
+  const char* r = (const char*)d_records;
+  merge_topk_kernel<<<B, 256, 0, st>>>((const int64_t*)r, (const float*)(r + off_scores), (const uint64_t*)(r + off_keys),
+                                       (const int32_t*)(r + off_counts), record_bytes / 8, record_bytes / 4,
+                                       record_bytes / 8, record_bytes / 4, G, B, top_k, d_out_ids, d_out_scores,
+                                       d_out_counts, off_status >= 0 ? (const uint64_t*)(r + off_status) : nullptr,
+                                       record_bytes / 8, h_status);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
+int set_status_word(const DeviceIndex* ix, uint64_t* d_word, uint64_t value, hipStream_t st) {
+  DeviceGuard g(ix->device);
+  set_status_kernel<<<1, 1, 0, st>>>(d_word, value);
+  NP_HIP(hipGetLastError());
+  return NP_OK;
+}
+
 }  // namespace np
 
 using namespace np;
@@ -1243,24 +1338,7 @@ int np_hip_or_bitmaps(const np_index* ix, const uint32_t* d_all, int32_t G, int6
 int np_hip_select_cut(const np_index* ix, const uint64_t* d_all_keys, int32_t G, int32_t B, int32_t n_sel,
                       uint64_t* d_cut, void* stream) {
   clear_error();
-  if (!ix || !d_all_keys || !d_cut || G < 1 || B < 0 || n_sel < 0) {
-    set_error("select_cut: invalid argument");
-    return NP_ERR_INVALID_ARGUMENT;
-  }
-  if (B == 0) return NP_OK;
-  DeviceGuard g(ix->device);
-  const int NP2 = next_pow2(std::max(G * n_sel, 1));
-  const size_t lds = (size_t)NP2 * 8;
-  if (lds > 128 * 1024) {
-    set_error("select_cut: G*n_sel = %d exceeds the 16384-key merge window", G * n_sel);
-    return NP_ERR_SEARCH;
-  }
-  if (lds > 48 * 1024)
-    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_cut_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  select_cut_kernel<<<B, 1024, lds, (hipStream_t)stream>>>(d_all_keys, G, B, n_sel, NP2, d_cut);
-  NP_HIP(hipGetLastError());
-  return NP_OK;
+  return np::select_cut_strided(ix, d_all_keys, (int64_t)B * n_sel, -1, G, B, n_sel, d_cut, (hipStream_t)stream);
 }
 
 int np_hip_merge_topk(const np_index* ix, const int64_t* d_ids, const float* d_scores, const uint64_t* d_keys,
@@ -1286,21 +1364,8 @@ int np_hip_merge_packed(const np_index* ix, const void* d_records, int64_t recor
                         int64_t off_scores, int64_t off_counts, int32_t G, int32_t B, int32_t top_k, int64_t* d_out_ids,
                         float* d_out_scores, int32_t* d_out_counts, void* stream) {
   clear_error();
-  if (!ix || !d_records || !d_out_counts || G < 1 || B < 0 || top_k < 0 || (record_bytes & 7) || (off_keys & 7) ||
-      (off_scores & 3) || (off_counts & 3)) {
-    set_error("merge_packed: invalid argument");
-    return NP_ERR_INVALID_ARGUMENT;
-  }
-  if (B == 0) return NP_OK;
-  DeviceGuard g(ix->device);
-  const char* r = (const char*)d_records;
-  merge_topk_kernel<<<B, 256, 0, (hipStream_t)stream>>>((const int64_t*)r, (const float*)(r + off_scores),
-                                                        (const uint64_t*)(r + off_keys), (const int32_t*)(r + off_counts),
-                                                        record_bytes / 8, record_bytes / 4, record_bytes / 8,
-                                                        record_bytes / 4, G, B, top_k, d_out_ids, d_out_scores,
-                                                        d_out_counts);
-  NP_HIP(hipGetLastError());
-  return NP_OK;
+  return np::merge_packed_status(ix, d_records, record_bytes, off_keys, off_scores, off_counts, -1, nullptr, G, B, top_k,
+                                 d_out_ids, d_out_scores, d_out_counts, (hipStream_t)stream);
 }
 
 // ---- N2: decompress_documents (index.rs:1197-1245) ---------------------------------------------------------
@@ -1463,7 +1528,7 @@ int np_hip_encode_tokens(const np_index* ix, const float* embeddings, int64_t n_
   hipStream_t st = cs.stream;
   const int LQP = 32;
   const int64_t KP = ix->KP, G = KP >> 5;
-  int64_t S = ix->opts.workspace_bytes / std::max<int64_t>(per_query_bytes(ix, LQP, 1, 1), 1);
+  int64_t S = ix->ws_budget.load(std::memory_order_relaxed) / std::max<int64_t>(per_query_bytes(ix, LQP, 1, 1), 1);
   S = std::max<int64_t>(1, std::min<int64_t>(S, std::min<int64_t>(ix->opts.max_batch, NP_S4_MAXB)));
   S = std::min<int64_t>(S, (n_tokens + LQP - 1) / LQP);
   const int64_t TB = S * LQP;

@@ -184,6 +184,9 @@ extern "C" int np_hip_index_write_dir(const char* index_dir, const np_index_arra
   for (const char* stale : {"merged_codes.npy", "merged_codes.npy.manifest.json", "merged_residuals.npy",
                             "merged_residuals.npy.manifest.json"})
     unlink((dir + "/" + stale).c_str());
+  // The crate loads bucket_cutoffs.npy whenever it exists (codec.rs:491-500): a copy left by a previous index in this
+  // directory would pair the old cutoffs with the new weights / nbits on the update path.
+  if (!(o && o->bucket_cutoffs)) unlink((dir + "/bucket_cutoffs.npy").c_str());
 
   // codec files
   {
@@ -198,7 +201,7 @@ extern "C" int np_hip_index_write_dir(const char* index_dir, const np_index_arra
     const float thr = o ? o->cluster_threshold : 0.f;
     NP_TRY(write_npy(dir + "/cluster_threshold.npy", "<f4", &one, 1, &thr, 4));
   }
-  const int64_t n_chunks = std::max<int64_t>(1, (N + chunk_docs - 1) / chunk_docs);
+  const int64_t n_chunks = (N + chunk_docs - 1) / chunk_docs;   // chunks.len(): 0 for an empty corpus (index.rs:436-474)
   NP_TRY(write_text(dir + "/plan.json", "{\n  \"nbits\": " + std::to_string(nbits) + ",\n  \"num_chunks\": " +
                                             std::to_string((long long)n_chunks) + "\n}\n"));
   // chunks
@@ -223,6 +226,15 @@ extern "C" int np_hip_index_write_dir(const char* index_dir, const np_index_arra
     NP_TRY(write_npy(dir + "/" + ci + ".residuals.npy", "|u1", rs, 2, a->residuals ? a->residuals + tok * pd : nullptr,
                      (size_t)nt * pd));
     tok += nt;
+  }
+  // chunk files of a previous, longer index in the same directory (the loader walks num_chunks, an update appends to the
+  // last chunk it finds): remove {i}.* for i >= n_chunks until a gap
+  for (int64_t c = n_chunks;; ++c) {
+    const std::string ci = std::to_string((long long)c);
+    int gone = 0;
+    for (const std::string& f : {ci + ".codes.npy", ci + ".residuals.npy", ci + ".metadata.json", "doclens." + ci + ".json"})
+      gone += unlink((dir + "/" + f).c_str()) == 0;
+    if (!gone) break;
   }
   // IVF: the caller's (e.g. np_hip_index_export of a device handle), or counted here from the codes
   {
@@ -254,7 +266,30 @@ extern "C" int np_hip_index_write_dir(const char* index_dir, const np_index_arra
       ivf_len = own_len.data();
     }
     int64_t total = 0;
-    for (int64_t k = 0; k < K; ++k) total += ivf_len[k];
+    for (int64_t k = 0; k < K; ++k) {
+      if (ivf_len[k] < 0) {
+        set_error("Index write failed: negative posting-list length at centroid %lld", (long long)k);
+        return NP_ERR_INVALID_ARGUMENT;
+      }
+      total += ivf_len[k];
+    }
+    if (ivf == a->ivf && ivf) {   // caller-supplied lists: unique ascending document ids in [0, N) per centroid (index.rs:479-504)
+      int64_t i = 0;
+      for (int64_t k = 0; k < K; ++k) {
+        int64_t last = -1;
+        for (int32_t j = 0; j < ivf_len[k]; ++j, ++i) {
+          if (ivf[i] <= last || ivf[i] >= N) {
+            set_error("Index write failed: posting list of centroid %lld is not strictly ascending inside [0, %lld) at entry %d",
+                      (long long)k, (long long)N, j);
+            return NP_ERR_INVALID_ARGUMENT;
+          }
+          last = ivf[i];
+        }
+      }
+    } else if (total > 0 && !ivf) {
+      set_error("np_hip_index_write_dir: ivf_lengths without ivf");
+      return NP_ERR_INVALID_ARGUMENT;
+    }
     NP_TRY(write_npy(dir + "/ivf.npy", "<i8", &total, 1, ivf, (size_t)total * 8));
     NP_TRY(write_npy(dir + "/ivf_lengths.npy", "<i4", &K, 1, ivf_len, (size_t)K * 4));
   }

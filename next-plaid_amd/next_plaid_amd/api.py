@@ -111,13 +111,18 @@ class np_synth_spec(C.Structure):
                 ("bucket_weights", C.c_void_p), ("len_table", C.c_void_p), ("len_table_size", C.c_int32)]
 
 
+# np_all_gather_host_fn: int (*)(void* ctx, const void* send, void* recv, int64_t bytes)
+ALL_GATHER_HOST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+NP_COMM_DEFERRED_STATUS = 1
+
 EXPORTS = [
     "np_hip_device_count", "np_hip_last_error", "np_hip_index_open", "np_hip_index_from_arrays",
     "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_tune", "np_hip_index_close",
     "np_hip_index_info", "np_hip_index_probe_dir", "np_hip_index_write_dir", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
     "np_hip_search_phase_b", "np_hip_search_end", "np_hip_n_sel", "np_hip_select_cut", "np_hip_merge_topk",
     "np_hip_merge_packed", "np_hip_elig_words", "np_hip_subset_eligible", "np_hip_or_bitmaps",
-    "np_hip_comm_unique_id", "np_hip_comm_create", "np_hip_comm_destroy", "np_hip_search_batch_sharded",
+    "np_hip_comm_unique_id", "np_hip_comm_create", "np_hip_comm_create_hosted", "np_hip_comm_status", "np_hip_comm_destroy",
+    "np_hip_search_batch_sharded",
     "np_hip_decompress_documents", "np_hip_encode_tokens", "np_hip_rerank_maxsim", "np_hip_debug_trace",
 ]
 
@@ -188,6 +193,8 @@ def lib():
     L.np_hip_merge_packed.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp]
     L.np_hip_comm_unique_id.argtypes = [vp]
     L.np_hip_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.np_hip_comm_create_hosted.argtypes = [vp, i32, i32, ALL_GATHER_HOST_FN, vp, i32, C.POINTER(vp)]
+    L.np_hip_comm_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.np_hip_comm_destroy.argtypes = [vp]
     L.np_hip_comm_destroy.restype = None
     L.np_hip_search_batch_sharded.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,

@@ -212,12 +212,38 @@ class ShardedSearcher:
 
 
 class ShardComm:
-    """np_comm: the RCCL communicator of the C-level sharded entry point (np_hip_comm_*, np_dist.hip).  The 128-byte
-    id is drawn on rank 0 and handed to the other ranks by `exchange` (a callable bytes -> bytes that broadcasts rank
-    0's value; bench.py uses a torch.distributed broadcast).  world 1 with rccl=False needs no RCCL at all."""
+    """np_comm: the communicator of the C-level sharded entry point (np_hip_comm_*, np_dist.hip).
 
-    def __init__(self, index: "api.MmapIndex", rank: int = 0, world: int = 1, exchange=None, rccl: bool = True):
+    RCCL transport (default): the 128-byte id is drawn on rank 0 and handed to the other ranks by `exchange` (a callable
+    bytes -> bytes that broadcasts rank 0's value; bench.py uses a torch.distributed broadcast).  world 1 with rccl=False
+    needs no RCCL at all.
+
+    Hosted transport (`all_gather=`): a callable (send: np.ndarray[uint8], recv: np.ndarray[uint8] of world * len(send))
+    that fills recv with every rank's bytes in rank order -- MPI, gloo, shared memory, anything; `gloo_all_gather(group)`
+    below is one over torch.distributed.  This is how ranks that share one GPU run the shipped protocol (RCCL refuses two
+    ranks on a device).  deferred_status=True keeps failure propagation on the device, as the RCCL transport does."""
+
+    def __init__(self, index: "api.MmapIndex", rank: int = 0, world: int = 1, exchange=None, rccl: bool = True,
+                 all_gather=None, deferred_status: bool = False):
         L = api.lib()
+        self._h = C.c_void_p()
+        self.index = index
+        self._cb = None
+        if all_gather is not None:
+            def _cb(_ctx, send, recv, nbytes):
+                try:
+                    s = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
+                    r = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(int(nbytes) * world,))
+                    all_gather(s, r)
+                    return 0
+                except Exception:   # never unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = api.ALL_GATHER_HOST_FN(_cb)   # keep the trampoline alive as long as the communicator
+            api._check(L.np_hip_comm_create_hosted(index._h, rank, world, self._cb, None,
+                                                   api.NP_COMM_DEFERRED_STATUS if deferred_status else 0, C.byref(self._h)))
+            return
         idbuf = None
         if rccl:
             idbuf = C.create_string_buffer(128)
@@ -225,9 +251,13 @@ class ShardComm:
                 api._check(L.np_hip_comm_unique_id(idbuf))
             if exchange is not None:
                 idbuf = C.create_string_buffer(exchange(bytes(idbuf.raw)), 128)
-        self._h = C.c_void_p()
-        self.index = index
         api._check(L.np_hip_comm_create(index._h, idbuf, rank, world, C.byref(self._h)))
+
+    def status(self):
+        """(failed_rank, np_status) of the batches since the last call, (-1, 0) if all were healthy.  Synchronise first."""
+        r, c = C.c_int32(), C.c_int32()
+        api._check(api.lib().np_hip_comm_status(self._h, C.byref(r), C.byref(c)))
+        return int(r.value), int(c.value)
 
     def close(self):
         h, self._h = self._h, None
@@ -239,6 +269,20 @@ class ShardComm:
             self.close()
         except Exception:
             pass
+
+
+def gloo_all_gather(group=None):
+    """A hosted-transport all-gather over a torch.distributed (gloo) process group, for ShardComm(all_gather=...)."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(send, recv):
+        ws = dist.get_world_size(group)
+        out = [torch.empty(send.size, dtype=torch.uint8) for _ in range(ws)]
+        dist.all_gather(out, torch.from_numpy(send.copy()), group=group)
+        for r, o in enumerate(out):
+            recv[r * send.size:(r + 1) * send.size] = o.numpy()
+    return fn
 
 
 class CShardedSearcher:
@@ -280,4 +324,8 @@ class CShardedSearcher:
             ds = None if subset is None else t.from_numpy(np.ascontiguousarray(subset, np.int64)).to(self.device)
             ids, sc, cnt = self.search_batch_device(dq, do, off, params, ds)
             ids, sc, cnt = ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        self.stream.synchronize()
+        rank, code = self.comm.status()   # a peer's failure empties the batch on every rank (np_dist.hip)
+        if code:
+            raise api.SearchError(f"Search failed: shard {rank} failed with status {code}; the batch was abandoned on every rank")
         return [api.QueryResult(i, ids[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(len(qs))]

@@ -67,13 +67,25 @@ def test_overwrite_clears_derived_caches_and_empty_index(tmp_path):
     write_native(tmp_path, a)
     assert not any(n.startswith("merged_") for n in os.listdir(tmp_path))   # mmap.rs:1714-1743: derived, rebuilt on load
     assert not any(".tmp." in n for n in os.listdir(tmp_path))
-    # zero documents: one empty chunk, avg_doclen 0.0 (index.rs:387-391)
+    # zero documents: no chunk at all (chunks.len() / ceil(0 / batch_size) = 0, index.rs:420, 702), avg_doclen 0.0 (:387-391)
     e = tmp_path / "empty"
     npa.write_index_dir(str(e / "nested" / "dir"), a["centroids"], a["bucket_weights"], np.zeros(0, np.int64),
                         np.zeros(0, np.int64), np.zeros((0, 8), np.uint8), 2)
     m = json.load(open(e / "nested" / "dir" / "metadata.json"))
-    assert m["num_documents"] == 0 and m["avg_doclen"] == 0.0 and m["num_chunks"] == 1
-    assert np.load(e / "nested" / "dir" / "0.residuals.npy").shape == (0, 8)
+    assert m["num_documents"] == 0 and m["avg_doclen"] == 0.0 and m["num_chunks"] == 0
+    assert not (e / "nested" / "dir" / "0.residuals.npy").exists()
+    assert npa.probe_index_dir(str(e / "nested" / "dir")).num_documents == 0      # the loader takes it
+    # a SHORTER index written over a longer one leaves no chunk of the old one behind, and no stale cutoffs
+    d = tmp_path / "shrink"
+    spec2, big = make_arrays(num_docs=30, num_centroids=8, dim=32, nbits=2, doc_len_min=1, doc_len_max=5, seed=4)
+    npa.write_index_dir(str(d), big["centroids"], big["bucket_weights"], big["doc_lengths"], big["codes"], big["residuals"], 2,
+                        bucket_cutoffs=np.zeros(3, np.float32), chunk_docs=10)
+    assert (d / "2.codes.npy").exists() and (d / "bucket_cutoffs.npy").exists()
+    n10 = int(big["doc_lengths"][:10].sum())
+    npa.write_index_dir(str(d), big["centroids"], big["bucket_weights"], big["doc_lengths"][:10], big["codes"][:n10],
+                        big["residuals"][:n10], 2, chunk_docs=10)
+    assert not (d / "1.codes.npy").exists() and not (d / "doclens.2.json").exists() and not (d / "bucket_cutoffs.npy").exists()
+    assert npa.probe_index_dir(str(d)).num_documents == 10
 
 
 def test_writer_errors(tmp_path):
@@ -89,6 +101,17 @@ def test_writer_errors(tmp_path):
     with pytest.raises(npa.CodecError):
         npa.write_index_dir(str(tmp_path / "z"), a["centroids"], a["bucket_weights"][:3], a["doc_lengths"], a["codes"],
                             a["residuals"], 4)
+    ivf_bad = a["ivf"].copy()
+    ivf_bad[0], ivf_bad[1] = ivf_bad[1], ivf_bad[0]                # not ascending inside the first non-trivial list
+    if int(a["ivf_lengths"][0]) >= 2:
+        with pytest.raises(ValueError, match="ascending"):
+            npa.write_index_dir(str(tmp_path / "v"), a["centroids"], a["bucket_weights"], a["doc_lengths"], a["codes"],
+                                a["residuals"], 4, ivf=ivf_bad, ivf_lengths=a["ivf_lengths"])
+    neg = a["ivf_lengths"].copy()
+    neg[0] = -1
+    with pytest.raises(ValueError, match="negative"):
+        npa.write_index_dir(str(tmp_path / "w"), a["centroids"], a["bucket_weights"], a["doc_lengths"], a["codes"],
+                            a["residuals"], 4, ivf=a["ivf"], ivf_lengths=neg)
     blocker = tmp_path / "file"
     blocker.write_text("x")
     with pytest.raises(npa.NextPlaidError):        # a file where the directory should go: Io, nothing half-written elsewhere
