@@ -348,8 +348,14 @@ def main():
                 traffic_src = {"commit": tj.get("commit"), "kernels_sha": tj.get("kernels_sha")}
         except Exception:
             traffic = None
+    # `frac` prices the contract's ALGORITHMIC bytes (Tc*4 + C*8 for S4) against the stage's duration; the filter
+    # never reads most of them, so the bytes the stage really moved (PMC `traffic`) give the PHYSICAL fraction beside it
+    frac_phys = None
+    if traffic and ms > 0 and bound == "hbm":
+        frac_phys = round(traffic / 1e9 / (ms * 1e-3) / peak, 5)
     roofline = dict(kernel=dom, bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
-                    frac=round(achieved / peak, 5), traffic=traffic, traffic_source=traffic_src, ms_per_launch=round(ms, 4),
+                    frac=round(achieved / peak, 5), frac_physical=frac_phys, traffic=traffic, traffic_source=traffic_src,
+                    ms_per_launch=round(ms, 4),
                     all={k: dict(ms=round(v[0], 4), bound=v[1], achieved=round(v[2] / (v[0] * 1e-3), 2) if v[0] > 0 else None,
                                  unit=v[3], frac=round(v[2] / (v[0] * 1e-3) / v[4], 4) if v[0] > 0 else None)
                          for k, v in per_stage.items()},
@@ -422,6 +428,9 @@ def main():
                                f"(nbits={a.nbits}), 2^{k2} centroids, nprobe={a.nprobe}, batch={a.batch}x{a.query_tokens} tok, "
                                f"n_full_scores={a.n_full_scores}, t_cs={thr}, top_k={a.top_k}; one fixed corpus sharded "
                                f"{n_shards} way(s) x {n_repl} replica group(s): {docs_local} docs on rank 0's GPU",
+                   "centroids_note": (f"K = 2^{k2} is an explicit choice (BASELINE config 2's K carried to this corpus; the metric "
+                                      f"names no K).  The crate's k-means heuristic (kmeans.rs:303-309) would pick 2^19 at 10 M x 300 "
+                                      f"tokens, the batched-probe regime: run --centroids 524288 for that line") if a.centroids == 65536 and a.docs >= 5_000_000 else None,
                    "docs_total": a.docs, "docs_per_gpu": docs_local, "batch": a.batch, "shards": n_shards, "replicas": n_repl,
                    "parallelism": ((f"doc-shard x{n_shards} + RCCL all-gather ({'np_hip_search_batch_sharded' if dist_impl == 'c' else 'torch.distributed harness'}){dist_note}"
                                     if use_shards else "whole index per GPU")
