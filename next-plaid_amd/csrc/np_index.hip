@@ -71,6 +71,8 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "s4_swz") t->s4_swz = value != 0;
   else if (n == "s4_filter") t->s4_filter = value != 0;
   else if (n == "s4_hot") t->s4_hot = clamp(value, 0, 500);
+  else if (n == "s4_planes") t->s4_planes = value != 0;
+  else if (n == "s4_pexp") t->s4_pexp = clamp(value, 5, 40);
   else if (n == "s3_slices") t->s3_slices = value != 0;
   else if (n == "ub_nt") t->ub_nt = value < 0 || value > 2 ? 0 : value;
   else if (n == "ub_steal") t->ub_steal = value < 1 ? 1 : value;
@@ -93,7 +95,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
 void read_tuning_env(Tuning* t) {
   static const char* const knobs[][2] = {
       {"NP_S4_MODE", "s4_mode"}, {"NP_S4_MINB", "s4_minb"}, {"NP_S4_NBX", "s4_nbx"}, {"NP_S4_SWZ", "s4_swz"},
-      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
+      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
       {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"},
       {"NP_EXACT_ROWMAX", "exact_rowmax"}};
   for (const auto& k : knobs) {
@@ -323,15 +325,21 @@ __global__ void __launch_bounds__(256) unique_codes_kernel(const int64_t* __rest
 // with the list.  Every other consumer keeps addressing lists through the 40-bit offset of doc_meta / the records.
 #define NP_UBLOCK_MAX_U16 128   // entries (256 B: one 8-byte load per lane of half a wave): 8 header + 120 codes
 #define NP_UBLOCK_MAX_U32 64    // entries (256 B): 4 header + 60 codes
+// with the bit-plane hot level (approx_hotp_kernel, LPD = 4: a whole wave stages a block) blocks go up to 512 bytes, so that a
+// corpus with 150-250 distinct codes per document (0.5-0.8 per token at 300 tokens) keeps its lists in the blocks
+#define NP_UBLOCK_BIG_U16 256   // 8 header + 248 codes
+#define NP_UBLOCK_BIG_U32 128   // 4 header + 124 codes
+#define NP_ULEN_BINS 258        // list lengths 0..256, > 256
 
-__global__ void ulen_hist_kernel(const int32_t* __restrict__ ulen, int64_t n, uint32_t* __restrict__ hist /* [130]: 0..128, >128 */) {
-  __shared__ uint32_t s_h[130];
-  if (threadIdx.x < 130) s_h[threadIdx.x] = 0;
+__global__ void ulen_hist_kernel(const int32_t* __restrict__ ulen, int64_t n, uint32_t* __restrict__ hist /* [NP_ULEN_BINS] */) {
+  __shared__ uint32_t s_h[NP_ULEN_BINS];
+  for (int i = threadIdx.x; i < NP_ULEN_BINS; i += blockDim.x) s_h[i] = 0;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    atomicAdd(&s_h[min(ulen[i], 129)], 1u);
+    atomicAdd(&s_h[min(ulen[i], NP_ULEN_BINS - 1)], 1u);
   __syncthreads();
-  if (threadIdx.x < 130 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+  for (int i = threadIdx.x; i < NP_ULEN_BINS; i += blockDim.x)
+    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
 }
 
 // overflow entries of document i (its whole list, 4-entry aligned) or 0 when the list fits its block
@@ -566,11 +574,12 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
   NP_HIP(hipGetLastError());
   // block stride: the smallest multiple of 16 bytes that holds the header and 99.9 % of the lists (at most the staging row)
   const int hdr = (int)(16 / ix->code_bytes());
-  const int smax = ix->code_wide ? NP_UBLOCK_MAX_U32 : NP_UBLOCK_MAX_U16;
+  const int smax = ix->tune.s4_planes ? (ix->code_wide ? NP_UBLOCK_BIG_U32 : NP_UBLOCK_BIG_U16)
+                                      : (ix->code_wide ? NP_UBLOCK_MAX_U32 : NP_UBLOCK_MAX_U16);
   int fit = smax - hdr;
   if (N > 0) {
     uint32_t* d_hist = nullptr;
-    uint32_t h_hist[130];
+    uint32_t h_hist[NP_ULEN_BINS];
     NP_HIP(hipMalloc(&d_hist, sizeof h_hist));
     hipError_t e = hipMemset(d_hist, 0, sizeof h_hist);
     if (e == hipSuccess) {
@@ -581,7 +590,7 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
     NP_HIP(e);
     const int64_t allow = N / 100;    // lists allowed to overflow (1 %: the filter re-reads only those)
     int64_t over = 0;
-    int q = 129;
+    int q = NP_ULEN_BINS - 1;
     while (q > 0 && over + h_hist[q] <= allow) over += h_hist[q--];   // q = the smallest capacity leaving <= 0.1 % outside
     fit = std::min(fit, std::max(q, 1));
   }

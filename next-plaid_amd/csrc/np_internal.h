@@ -128,6 +128,10 @@ struct Tuning {
                          // filter).  More hot centroids: fewer documents left to the exact bound (S1 + S2: 2.66 M / 1.19 M of 11.9 M
                          // at 100 / 200) but more table rows and walk steps per document in the hot kernel, which is VALU-bound:
                          // 40 / 100 / 200 / 300 -> S4 4.02 / 2.73 / 2.92 / 3.00 ms at 10 M documents
+  int s4_planes = 1;     // first filter level in bit-plane form (approx_hotp_kernel: 8 planes per hot centroid, OR + weighted popcount
+                         // instead of 32 byte maxima per table row); 0 = approx_hot_kernel.  Read at OPEN too: with it the list blocks
+                         // may be up to 512 bytes (corpora with long distinct-code lists), which approx_hot_kernel cannot stage
+  int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim
                          // on a line all XCDs share costs ~50 ns, serialised): 2.06 -> 1.68 ms at 10 M documents

@@ -2600,6 +2600,413 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
 }
 
 // ---------------------------------------------------------------------------------------------
+// S4, first filter level in BIT-PLANE form (round 4).
+// approx_hot_kernel is VALU-bound (50 wave instructions per document at 10 M documents: scan 16, walk 12-24, staging 7):
+// the walk folds 32 byte maxima per table row and pads every document of a claim to the longest hot list.  Rounding the
+// values above Lambda UP to one of P = 8 levels  Lambda = t_0 < t_1 < ... < t_8  turns a hot centroid's row into 8 bit
+// planes -- plane j = the query tokens with u[q, c] > t_j -- the max over a document's hot codes into a bitwise OR and
+// the bound into a weighted popcount:
+//     U''(d) = Lq * Lambda + sum_j (t_{j+1} - t_j) * popcount( OR_{c in codes(d), c hot} plane_j[c] )  >=  U'(d)  >=  U(d).
+// Any upper bound keeps the three-step cut of np_search.hip selection-preserving (S1 = the n_sel largest bounds, tau from
+// their exact U, S2 = the rest with bound >= tau); what the rounding costs is a larger S2.  CPU simulation on the metric
+// corpus (tools/sim/s4_planes_sim.py, profiles/r04_sim_s4_planes_10m.txt): uniform levels up to the table's maximum keep
+// |S2| within ~10 % of the exact hot bound's (16 planes: within 1 %; levels crowded next to Lambda are much worse -- the
+// documents near the cut are told apart by their STRONG matches).
+// Kernel structure (one XCD per query, claims round-robin as in approx_hot_kernel), per claim of DPW = 64 / LPD documents:
+//   stage  the claim's list blocks -> LDS rows, 16 aligned 8-byte loads per lane in one burst (LPD = 2: half a wave per
+//          block of <= 256 B; LPD = 4: a whole wave per block of <= 512 B, for corpora with long distinct-code lists);
+//   scan   the LPD lanes of a document each test one share of its codes (<= 64) against the hot bitmap, 4 codes per step,
+//          and keep the hot POSITIONS as a 64-bit mask in registers: no compaction, no LDS write;
+//   walk   every lane pops its own hot positions (G per step), fetches the code from the staged row and the 8 planes of
+//          that centroid through a bounds-checked buffer (an exhausted lane issues no request) and ORs them in: 8 v_or per
+//          row instead of 32 byte maxima, and all 64 lanes walk lists of their own (lockstep over <= 4 positions per lane);
+//   bound  OR across the document's lanes (DPP), weighted popcount, u16 bound + LDS histogram.
+// ---------------------------------------------------------------------------------------------
+#define NP_PLANES 8
+
+// Per query: the plane thresholds and the hot bitmap.  lev[b][0..7] = t_0..t_7 (t_0 = Lambda, hot_lam_kernel), lev[b][8..15] =
+// the weights t_{j+1} - t_j, with t_8 = the largest per-centroid maximum of the query's table and the levels spaced by a
+// power law, t_j = Lambda + span * (j / 8)^e: e = 1 is uniform, the default e = 1.5 is finer next to Lambda -- on the metric
+// corpus 8 planes at e = 1.5 keep |S2| within ~10 % of the exact hot bound's, uniform ones within ~35 %, and levels crowded
+// next to Lambda (geometric, quantiles of the values) are far worse (profiles/r04_sim_s4_planes*_10m.txt).
+// hotbits[b][w] bit i = (M[32 w + i] > Lambda): the filter's workgroups copy it into LDS instead of each rebuilding it from
+// the 64 KB of per-centroid maxima.  One block per query.
+__global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restrict__ chist, const uint32_t* __restrict__ lam_b,
+                                                         const uint8_t* __restrict__ cmaxu, int64_t KP, int pexp10,
+                                                         uint32_t* __restrict__ lev, uint32_t* __restrict__ hotbits) {
+  __shared__ int s_top;
+  __shared__ int s_t[NP_PLANES + 1];
+  const int b = blockIdx.x, v = threadIdx.x;
+  if (v == 0) s_top = 0;
+  __syncthreads();
+  if (chist[(int64_t)b * 256 + v]) atomicMax(&s_top, v);
+  __syncthreads();
+  const int lam = (int)lam_b[b];
+  if (v <= NP_PLANES) {
+    const int top = max(s_top, lam + 1), span = top - lam;
+    const float w = __powf((float)v / (float)NP_PLANES, 0.1f * (float)pexp10);
+    int t = v == 0 ? lam : (v == NP_PLANES ? top : lam + (int)ceilf((float)span * w));
+    t = min(max(t, min(lam + v, top)), top);          // strictly increasing while there is room, never past the top
+    s_t[v] = t;
+  }
+  __syncthreads();
+  if (v < NP_PLANES) {
+    const int t0 = s_t[v], t1 = max(s_t[v + 1], t0);
+    lev[b * 16 + v] = (uint32_t)t0;
+    lev[b * 16 + 8 + v] = (uint32_t)(t1 - t0);
+  }
+  const uint8_t* cm = cmaxu + (int64_t)b * KP;
+  for (int64_t w = v; w < (KP >> 5); w += 256) {
+    const uint4 v0 = *reinterpret_cast<const uint4*>(cm + w * 32), v1 = *reinterpret_cast<const uint4*>(cm + w * 32 + 16);
+    const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bits |= (((w8[e] >> (8 * k)) & 0xFFu) > (uint32_t)lam ? 1u : 0u) << (4 * e + k);
+    hotbits[(int64_t)b * (KP >> 5) + w] = bits;
+  }
+}
+
+// planes[b][c][j] for every hot centroid c of query b: bit q of plane j = (u[q, c] > t_j).  RB = bytes of a u8 table row =
+// bits of a plane x 8 planes / 8: plane rows have the u8 rows' size and addressing.  A wave takes 64 centroids and builds
+// the rows of the hot ones one after the other: lane q holds u[q, c], a plane is one ballot.  Rows of cold centroids are
+// never read and stay unwritten.
+template <int RB>
+__global__ void __launch_bounds__(256) hot_planes_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
+                                                         const uint8_t* __restrict__ cmaxu, const uint32_t* __restrict__ lam_b,
+                                                         const uint32_t* __restrict__ lev, uint32_t* __restrict__ planes) {
+  static_assert(RB == 32 || RB == 64, "plane rows of 32 or 64 query tokens");
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lam = lam_b[b];
+  uint32_t t[NP_PLANES];
+#pragma unroll
+  for (int j = 0; j < NP_PLANES; ++j) t[j] = lev[b * 16 + j];
+  const uint8_t* cm = cmaxu + (int64_t)b * KP;
+  for (int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 64; c0 < KP; c0 += (int64_t)gridDim.x * 256) {
+    const bool hot = (uint32_t)cm[c0 + lane] > lam;   // KP is a multiple of 64
+    unsigned long long hm = __ballot(hot);
+    while (hm) {
+      const int l = __builtin_ctzll(hm);
+      hm &= hm - 1;
+      const int64_t row = (int64_t)b * KP + c0 + l;
+      const uint32_t u = lane < RB ? (uint32_t)QCU[row * RB + lane] : 0u;
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int j = 0; j < NP_PLANES; ++j) {
+        const unsigned long long pm = __ballot(u > t[j]);
+        if (lane == j) {
+          lo = (uint32_t)pm;
+          hi = (uint32_t)(pm >> 32);
+        }
+      }
+      if (lane < NP_PLANES) {
+        if constexpr (RB == 32) planes[row * 8 + lane] = lo;
+        else *reinterpret_cast<uint2*>(planes + row * 16 + 2 * lane) = make_uint2(lo, hi);
+      }
+    }
+  }
+}
+
+template <int RB, typename CT, int LPD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) approx_hotp_kernel(
+    const uint32_t* __restrict__ planes /* [B][KP][RB / 4] */, int64_t K, int64_t KP, const uint32_t* __restrict__ hotbits /* [B][KP / 32] */,
+    const uint32_t* __restrict__ lam_b, const uint32_t* __restrict__ lev /* [B][16] */,
+    const uint32_t* __restrict__ cand_ids /* [pool] shard-local document ids (compact_kernel) */,
+    uint4* __restrict__ cand_meta /* [pool] OUT: the candidates' 16-B records, for the cuts and the exact level */,
+    int ublock_stride /* entries per document block of `codes` */, int64_t ovf_base /* first entry of the overflow region */,
+    const int32_t* __restrict__ n_cand, RoundPlan rp, int round, int max_rounds, const CT* __restrict__ codes,
+    const uint32_t* __restrict__ qflag, const int32_t* __restrict__ qoff, int n_sel, uint16_t* __restrict__ U,
+    uint32_t* __restrict__ hist, int hshift, int32_t* __restrict__ slots, int32_t* __restrict__ ticket, int B, Counters* ctr) {
+  static_assert(RB == 32 || RB == 64, "plane rows of 32 or 64 query tokens");
+  static_assert(LPD == 2 || LPD == 4, "lanes per document");
+  constexpr int DPW = 64 / LPD;                      // documents per claim
+  constexpr int HDR = 16 / (int)sizeof(CT);          // entries of a block's 16-byte header {#distinct, doc length, overflow index, 0}
+  constexpr int NLD = LPD / 2;                       // 256-byte pieces of a block: load instructions per document
+  constexpr int NS = RB / 4;                         // dwords of plane state (and of a plane row)
+  constexpr int PW = RB / 32;                        // dwords per plane
+  constexpr int G = 128 / RB;                        // hot positions popped per walk step (32 dwords of rows in flight)
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // LDS: the hot bitmap -- STATIC (8 KB) with u16 codes (K <= 65536), so that its address folds into the ds_read offset
+  // field of the scan's four lookups per step, else the first KP / 32 words of the dynamic region -- and [4][DPW] rows
+  constexpr bool SBM = sizeof(CT) == 2;
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits_static[SBM ? 2048 : 4];
+  // histogram of the bounds at HALF the global resolution (4 KB instead of 8: a fourth workgroup per CU).  A document of bin
+  // t is counted at bin t & ~1; ub_thr_kernel's threshold can only come out lower (more documents in S1), which any cut on
+  // an upper bound tolerates, and ub_cut_kernel tests the true bins.
+  __shared__ uint32_t s_hist[NP_UB_BINS / 2];
+  __shared__ int s_q;
+#define BITS(i) (SBM ? s_bits_static[(i)] : s_dyn[(i)])
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jl = lane & (LPD - 1), grp = lane / LPD;
+  const int x = blockIdx.x & 7;
+  if (round >= rp.round_tab[2 * max_rounds]) return;
+  const int rb = rp.round_tab[2 * round], re = rp.round_tab[2 * round + 1];
+  const int bmw = SBM ? 0 : (int)(((KP >> 5) + 3) & ~3ll);   // dynamic bitmap words; the rows behind stay 16-byte aligned
+  const int stride_b = ublock_stride * (int)sizeof(CT);              // block bytes (a multiple of 64)
+  const int row_b = stride_b + 16;                   // LDS row: the block + 16 bytes (rows off each other's banks)
+  char* s_rows = reinterpret_cast<char*>(s_dyn + bmw) + (size_t)wave * DPW * row_b;
+  const int fit = ublock_stride - HDR;               // codes a block holds = codes staged per window
+  uint32_t toks32 = 0, ucnt32 = 0, rows32 = 0;
+  // the scan looks every staged position up in the bitmap, also past a list's end: the rows must never hold anything but
+  // codes (< K) behind the header, so they start zeroed (afterwards they only ever receive list entries or zeros)
+  for (int i = tid; i < 4 * DPW * row_b / 4; i += 256) (s_dyn + bmw)[i] = 0u;
+  for (int step = 0;; ++step) {
+    __syncthreads();
+    if (tid == 0) s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() { return -3; });
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(s_q);
+    if (b < 0) break;
+    const int64_t n = n_cand[b];
+    const int64_t pbase = rp.cand_base[b];
+    const uint32_t* idb = cand_ids + pbase;
+    uint4* metab = cand_meta + pbase;
+    if (qflag[b] || n <= (int64_t)n_sel) {
+      // the cuts keep every candidate of this query: no bound to compute, but the later stages still want the records
+      for (int64_t i = ((int64_t)(blockIdx.x >> 3) * 256 + tid); i < n; i += (int64_t)(gridDim.x >> 3) * 256) {
+        const uint32_t d = idb[i];
+        const uint4 hd = *reinterpret_cast<const uint4*>(codes + (int64_t)d * ublock_stride);
+        const int64_t cl = (int)hd.x > fit ? ovf_base + (int64_t)hd.z * 4 : (int64_t)d * ublock_stride + HDR;
+        metab[i] = make_uint4(d, hd.x, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
+      }
+      continue;
+    }
+    const int Lq = qoff[b + 1] - qoff[b];
+    const uint32_t lam = lam_b[b];
+    uint32_t wj[NP_PLANES];                          // plane weights (wave-uniform: scalar registers)
+#pragma unroll
+    for (int j = 0; j < NP_PLANES; ++j) wj[j] = lev[b * 16 + 8 + j];
+    // ---- hot bitmap (hot_levels_kernel): bit c = M[c] > Lambda
+    {
+      const uint32_t* hbits = hotbits + (int64_t)b * (KP >> 5);
+      for (int w = tid; w < (int)(KP >> 5); w += 256) BITS(w) = hbits[w];
+      for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t tb64 = reinterpret_cast<uint64_t>(planes + (int64_t)b * KP * NS);
+    const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tb64);
+    const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tb64 >> 32));
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((uint64_t)thi << 32) | tlo), 0, (int)(KP * RB), 0x00020000);
+    uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+    // claims round-robin: wave g of the NW waves of this XCD takes claims g, g + NW, ... (approx_hot_kernel: a cursor
+    // atomic per claim costs more than the imbalance it removes)
+    const int64_t NW = (int64_t)(gridDim.x >> 3) * 4;
+    int64_t i0 = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW, i1 = i0 + NW * DPW;
+    const uint32_t id_last = idb[n - 1];
+    uint32_t did = idb[min(i0 + grp, n - 1)];
+    char* row = s_rows + (size_t)grp * row_b;        // this lane's document
+    const CT* rowc = reinterpret_cast<const CT*>(row) + HDR;   // its codes (behind the block header)
+    for (;;) {
+      if (i0 >= n) break;
+      const uint32_t did_next = idb[min(i1 + grp, n - 1)];   // prefetch (clamped: a claim past the end is never used)
+      const int64_t i = i0 + grp;
+      const bool valid = i < n;
+      if (!valid) did = id_last;
+      // ---- stage: the claim's list BLOCKS -> LDS rows, header included.  One buffer_load_dword ... lds per 256 bytes of a
+      // block: the block's address is wave-uniform (document id by v_readlane, 64-bit address on the scalar unit), the
+      // data goes from memory straight into the LDS row (M0 = its address) -- no address or staging VGPRs, one VALU
+      // instruction per document.  Lanes past the block are masked off (their dwords belong to the next row).
+      __builtin_amdgcn_wave_barrier();       // the previous claim's rows are consumed
+#pragma unroll
+      for (int h = 0; h < NLD; ++h) {
+        if (256 * h + 4 * lane < stride_b) {
+#pragma unroll
+          for (int j = 0; j < DPW; ++j) {
+            const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)did, LPD * j);
+            const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<CT*>(codes) + (int64_t)dj * ublock_stride, 0, stride_b, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(s_rows + (size_t)j * row_b + 256 * h), 4, 256 * h + 4 * lane, 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): the rows are in LDS
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint4 hd = *reinterpret_cast<const uint4*>(row);   // {#distinct, doc length, overflow index, 0}
+      const int nd = valid ? (int)hd.x : 0;
+      const bool ovf = nd > fit;
+      const int64_t cl = ovf ? ovf_base + (int64_t)hd.z * 4 : (int64_t)did * ublock_stride + HDR;
+      if (jl == 0 && valid) {
+        toks32 += hd.y;
+        ucnt32 += (uint32_t)nd;
+        metab[i] = make_uint4(did, (uint32_t)nd, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
+      }
+      const int nmax = wave_max_nonneg(nd);
+      uint32_t st[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) st[k] = 0;
+      for (int p0 = 0; p0 < nmax; p0 += fit) {
+        // lists that fit their block are already staged; only a claim with an overflow list or a further window of a long
+        // list goes back to memory: the same LDS-direct loads, document by document, from the list's own address (reads
+        // past the list's end return zeros: the buffer ends with the list)
+        if (p0 > 0 || nmax > fit) {                  // wave-uniform
+          __builtin_amdgcn_wave_barrier();           // the previous window is consumed
+#pragma unroll 1
+          for (int j = 0; j < DPW; ++j) {
+            const int ndj = __builtin_amdgcn_readlane(nd, LPD * j);
+            if (ndj <= (p0 > 0 ? p0 : fit)) continue;   // staged with its block / already finished
+            const uint32_t clo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cl, LPD * j);
+            const uint32_t chi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cl >> 32), LPD * j);
+            const int64_t clj = (int64_t)(((uint64_t)chi << 32) | clo) + p0;
+            const int left_b = (min(ndj - p0, fit) * (int)sizeof(CT) + 3) & ~3;   // whole dwords: an odd u16 count reads one entry of the list's padding
+            const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT*>(codes) + clj, 0, left_b, 0x00020000);
+#pragma unroll
+            for (int h = 0; h < NLD; ++h)
+              if (256 * h + 4 * lane < fit * (int)sizeof(CT))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(s_rows + (size_t)j * row_b + 16 + 256 * h), 4, 256 * h + 4 * lane, 0, 0, 0);
+          }
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        // ---- scan: lane jl of the document's LPD lanes tests codes [start, start + len) of the window, CPI per step (one
+        // 16-byte LDS read: 8 u16 / 4 u32 codes), the next step's codes already on their way while this step's bitmap
+        // words are looked up.  The hot flags enter the mask from the top (v_alignbit: acc = acc >> 1 | flag << 31, one
+        // instruction per code, and only bit 0 of `flag` counts, so the bitmap word is just shifted right by the code --
+        // shifts use the low 5 bits of their operand, which for the low code of a u16 pair is the packed dword itself);
+        // after n codes the first one sits at bit 32 - n.
+        constexpr int CPI = 16 / (int)sizeof(CT);
+        const int cnt = min(max(nd - p0, 0), fit);
+        const int share = (((cnt + LPD - 1) / LPD) + CPI - 1) & ~(CPI - 1);
+        const int start = jl * share;
+        const int len = max(min(share, cnt - start), 0);
+        const int itmax = (((min(nmax - p0, fit) + LPD - 1) / LPD) + CPI - 1) & ~(CPI - 1);   // wave-uniform, >= every share, <= 64
+        auto rd = [&](int it) { return *reinterpret_cast<const uint4*>(rowc + min(start + it, fit - CPI)); };
+        auto look = [&](const uint4& w, uint32_t& acc) {
+          const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+          if constexpr (sizeof(CT) == 2) {
+            uint32_t bl[4], bh[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              bl[k] = BITS((ww[k] >> 5) & 0x7FFu);
+              bh[k] = BITS(ww[k] >> 21);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              acc = __builtin_amdgcn_alignbit(bl[k] >> (ww[k] & 31u), acc, 1);
+              acc = __builtin_amdgcn_alignbit(bh[k] >> ((ww[k] >> 16) & 31u), acc, 1);
+            }
+          } else {
+            uint32_t bw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bw[k] = BITS(ww[k] >> 5);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_alignbit(bw[k] >> (ww[k] & 31u), acc, 1);
+          }
+        };
+        uint32_t mlo = 0, mhi = 0;
+        const int n_lo = min(itmax, 32), n_hi = itmax - n_lo;   // codes per lane scanned into each half (multiples of CPI)
+        uint4 cur = rd(0);
+        for (int it = 0; it < n_lo; it += CPI) {
+          const uint4 nxt = rd(it + CPI);
+          look(cur, mlo);
+          cur = nxt;
+        }
+        for (int it = 32; it < itmax; it += CPI) {
+          const uint4 nxt = rd(it + CPI);
+          look(cur, mhi);
+          cur = nxt;
+        }
+        mlo = n_lo ? mlo >> (32 - n_lo) : 0u;
+        mhi = n_hi ? mhi >> (32 - n_hi) : 0u;
+        unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
+        rows32 += (uint32_t)__popcll(m);
+        // ---- walk: G hot positions per lane and step; a lane without one issues out-of-range offsets (no request).  The
+        // positions of step s + 1 are popped and their codes read from LDS while the rows of step s are in flight.
+        bool has[G];
+        uint32_t c[G];
+        auto pop = [&]() {
+#pragma unroll
+          for (int g = 0; g < G; ++g) {   // straight-line: the LDS reads are unconditional (position 0 for an exhausted lane)
+            has[g] = m != 0ull;
+            const int p = max(__ffsll((long long)m) - 1, 0);
+            m &= m - 1ull;
+            c[g] = (uint32_t)rowc[start + p];
+          }
+        };
+        pop();
+        while (__ballot(has[0]) != 0ull) {
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 v[G][RB / 16];
+          uint32_t off[G];
+          // the fence keeps the compiler from sinking each LDS read into a branch of its own (dependent round trips)
+          if constexpr (G == 4) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+          else asm volatile("" : "+v"(c[0]), "+v"(c[1]));
+#pragma unroll
+          for (int g = 0; g < G; ++g) off[g] = has[g] ? c[g] * (uint32_t)RB : 0x7FFFFF00u;
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < RB / 16; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)(off[g] + 16u * k), 0, 0);
+          pop();
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < RB / 16; ++k) {
+              st[4 * k + 0] |= v[g][k].x;
+              st[4 * k + 1] |= v[g][k].y;
+              st[4 * k + 2] |= v[g][k].z;
+              st[4 * k + 3] |= v[g][k].w;
+            }
+        }
+      }
+      // ---- bound: OR across the document's lanes, weighted popcount
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        st[k] |= (uint32_t)__builtin_amdgcn_mov_dpp((int)st[k], 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+        if constexpr (LPD == 4) st[k] |= (uint32_t)__builtin_amdgcn_mov_dpp((int)st[k], 0x4E, 0xf, 0xf, true);   // [2,3,0,1]
+      }
+      uint32_t sum = (uint32_t)Lq * lam;
+#pragma unroll
+      for (int j = 0; j < NP_PLANES; ++j) {
+        uint32_t pc = (uint32_t)__popc(st[j * PW]);
+        if constexpr (PW == 2) pc += (uint32_t)__popc(st[j * PW + 1]);
+        sum += __umul24(wj[j], pc);
+      }
+      if (valid && jl == 0) {
+        U[pbase + i] = (uint16_t)sum;
+        atomicAdd(&s_hist[min(sum >> (hshift + 1), (uint32_t)(NP_UB_BINS / 2 - 1))], 1u);
+      }
+      i0 = i1;
+      did = did_next;
+      i1 += NW * DPW;
+    }
+    __syncthreads();
+    for (int i = tid; i < NP_UB_BINS / 2; i += 256) {
+      const uint32_t v = s_hist[i];
+      if (v) atomicAdd(&hb[2 * i], v);
+    }
+  }
+  unsigned long long toks = toks32, ucnt = ucnt32, rows = rows32;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    toks += __shfl_xor(toks, o);
+    ucnt += __shfl_xor(ucnt, o);
+    rows += __shfl_xor(rows, o);
+  }
+  __shared__ unsigned long long s_cnt[3];
+  __syncthreads();
+  if (tid == 0) s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+  __syncthreads();
+  if (lane == 0 && toks) {
+    atomicAdd(&s_cnt[0], toks);
+    atomicAdd(&s_cnt[1], ucnt);
+    atomicAdd(&s_cnt[2], rows);
+  }
+  __syncthreads();
+  if (tid == 0 && s_cnt[0]) {
+    atomicAdd(&ctr->n_cand_tokens, s_cnt[0]);
+    atomicAdd(&ctr->n_cand_dcodes, s_cnt[1]);
+    atomicAdd(&ctr->n_cand_codes, s_cnt[2]);     // table rows gathered
+  }
+}
+
+#undef BITS
+
+// ---------------------------------------------------------------------------------------------
 // Batched path (K > centroid_batch_size): approximate scores in the reference's arithmetic.
 // search.rs:259-272 does not reuse the probe's GEMM: it recomputes Q.c for every distinct centroid of the candidates
 // as an ndarray mat-vec, i.e. per (q, c) numeric_util::unrolled_dot -- eight partial sums p_j += x[8i+j] * y[8i+j]

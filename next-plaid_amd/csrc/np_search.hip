@@ -16,7 +16,7 @@ namespace np {
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, n_list2, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
-      subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2, qpad;
+      subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2, qpad, planes, levels, hotbits;
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
@@ -25,7 +25,7 @@ struct Workspace {
     DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
                      &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
                      &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
-                     &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad};
+                     &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits};
     for (DevBuf* b : all) b->release();
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
@@ -502,8 +502,12 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   NP_TRY(w.qinv.reserve((size_t)B * 4));
   NP_TRY(w.qflag.reserve((size_t)B * 4));
   // two-level filter (np_kernels.h, "S4, first filter level"): the hot bitmap of a query lives in LDS (K / 8 bytes)
+  // bit-plane form of the first level (approx_hotp_kernel): rows of 32 / 64 query tokens; list blocks of up to 512 bytes
+  // (staged by a whole wave, LPD = 4) exist only with it -- approx_hot_kernel stages at most 256-byte blocks
+  const int old_cap = ix->code_wide ? 64 : 128;
+  const bool use_planes = ix->tune.s4_planes && RB <= 64;
   const bool two_level = use_filter && ix->tune.s4_hot > 0 && KP / 8 <= 64 * 1024 && KP * RB < ((int64_t)1 << 31) &&
-                         ix->ublock_stride > 0;
+                         ix->ublock_stride > 0 && (use_planes || ix->ublock_stride <= old_cap);
   const size_t slot_words = (size_t)(8 * (B + 1) + 1);   // hand-out slots + ticket of one filter launch
   if (use_filter) {
     NP_TRY(w.QCU.reserve((size_t)B * KP * RB));
@@ -524,6 +528,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     NP_TRY(w.list_meta.reserve((size_t)pool * 16));
     NP_TRY(w.n_l1.reserve((size_t)B * 4));
     NP_TRY(w.n_l2.reserve((size_t)B * 4));
+    if (use_planes) {
+      NP_TRY(w.planes.reserve((size_t)B * KP * RB));
+      NP_TRY(w.levels.reserve((size_t)B * 16 * 4));
+      NP_TRY(w.hotbits.reserve((size_t)B * (KP / 32) * 4));
+    }
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -591,6 +600,17 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     hot_prep_kernel<<<dim3((unsigned)std::min<int64_t>((KP + 255) / 256, 64), B), 256, 0, st>>>(
         w.QCU.as<uint8_t>(), ix->K, KP, RB, w.cmaxu.as<uint8_t>(), w.chist.as<uint32_t>());
     hot_lam_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.ub_thr2.as<uint32_t>() + B);
+    if (use_planes) {   // thresholds of the 8 planes, then the plane rows of the hot centroids
+      hot_levels_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.cmaxu.as<uint8_t>(), KP,
+                                           ix->tune.s4_pexp, w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>());
+      const dim3 pg((unsigned)std::min<int64_t>((KP + 255) / 256, 64), B);
+      if (RB == 32)
+        hot_planes_kernel<32><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
+                                                  w.levels.as<uint32_t>(), w.planes.as<uint32_t>());
+      else
+        hot_planes_kernel<64><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
+                                                  w.levels.as<uint32_t>(), w.planes.as<uint32_t>());
+    }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[1], st));
 
@@ -801,8 +821,36 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     else if (RB == 128) NP_LAUNCH_HOT(128, CT); \
     else NP_LAUNCH_HOT(256, CT);                \
   } while (0)
-          if (!ix->code_wide) NP_LAUNCH_HOT_RB(uint16_t);
+#define NP_LAUNCH_HOTP(ROWB, CT, LPDV)                                                                                     \
+  do {                                                                                                                   \
+    const size_t bm = sizeof(CT) == 2 ? 0 : (size_t)(((KP >> 5) + 3) & ~(int64_t)3) * 4;   /* u16 codes: static bitmap */   \
+    const size_t dynp = bm + (size_t)4 * (64 / LPDV) * ((size_t)ix->ublock_stride * sizeof(CT) + 16);                         \
+    if (dynp > 16 * 1024)                                                                                                \
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV>),                      \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynp));                                \
+    approx_hotp_kernel<ROWB, CT, LPDV><<<8 * nbx, 256, dynp, st>>>(                                                       \
+        w.planes.as<uint32_t>(), ix->K, KP, w.hotbits.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.levels.as<uint32_t>(), \
+        w.cand.as<uint32_t>(), w.cand_meta.as<uint4>(), ix->ublock_stride, (int64_t)ix->n_docs * ix->ublock_stride,        \
+        w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), d_qoff, cs->n_sel,     \
+        w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift, sl, sl + 8 * (B + 1), B, w.ctr.as<Counters>());             \
+  } while (0)
+#define NP_LAUNCH_HOTP_L(ROWB, CT)                                   \
+  do {                                                               \
+    if (ix->ublock_stride <= old_cap) NP_LAUNCH_HOTP(ROWB, CT, 2);   \
+    else NP_LAUNCH_HOTP(ROWB, CT, 4);                                \
+  } while (0)
+          if (use_planes) {
+            if (!ix->code_wide) {
+              if (RB == 32) NP_LAUNCH_HOTP_L(32, uint16_t);
+              else NP_LAUNCH_HOTP_L(64, uint16_t);
+            } else {
+              if (RB == 32) NP_LAUNCH_HOTP_L(32, uint32_t);
+              else NP_LAUNCH_HOTP_L(64, uint32_t);
+            }
+          } else if (!ix->code_wide) NP_LAUNCH_HOT_RB(uint16_t);
           else NP_LAUNCH_HOT_RB(uint32_t);
+#undef NP_LAUNCH_HOTP_L
+#undef NP_LAUNCH_HOTP
 #undef NP_LAUNCH_HOT_RB
 #undef NP_LAUNCH_HOT
         }

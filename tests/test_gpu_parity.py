@@ -310,8 +310,10 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         ref = hx.search_batch(batch, p)
         hx.tune("s4_filter", 1)
         rows = {}
-        for hot in (0, 10, 100, 300, 500):
+        # (hot share, first level in bit-plane form (round 4: approx_hotp_kernel) or as byte maxima (approx_hot_kernel))
+        for hot, planes in ((0, 1), (10, 1), (100, 1), (300, 1), (500, 1), (10, 0), (100, 0), (300, 0)):
             hx.tune("s4_hot", hot)
+            hx.tune("s4_planes", planes)
             hx.tune("ub_direct", 0 if hot == 300 else 8)   # short-list launch: per-XCD hand-out or one group of workgroups per query
             hx.tune("ub_static", 1 if hot in (10, 500) else 0)   # claims from a cursor (with stealing) or round-robin
             hx.tune("hot_static", 0 if hot in (10, 300) else 1)
@@ -322,13 +324,15 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
                 assert np.array_equal(g.scores, r.scores), f"nfs={nfs} hot={hot} q{i}"
             assert 0 < st["n_survivors"] <= st["n_candidates"]
             assert st["n_cand_dcodes"] > 0 and st["n_cand_tokens"] >= st["n_cand_dcodes"]
-            rows[hot] = st["n_cand_codes"]
+            if planes:
+                rows[hot] = st["n_cand_codes"]
             if hot == 0:
                 assert st["n_level2"] == 0 and st["n_cand_codes"] <= st["n_cand_dcodes"]
             elif nfs == 512:
                 assert 0 < st["n_level2"] < st["n_candidates"], st
         if nfs == 512:
             assert rows[100] < rows[0], rows        # the hot level gathers fewer table rows than the exact bound alone
+    hx.tune("s4_planes", 1)
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got[:8], orc):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
@@ -341,24 +345,37 @@ def test_long_documents_overflow_blocks_and_windows():
     unfiltered searches must still agree bit for bit, and with the oracle."""
     spec, a = make_arrays(num_docs=3000, num_centroids=2048, dim=128, nbits=4, doc_len_min=150, doc_len_max=700, n_topics=40,
                           rand256=160, seed=97)
-    ox, hx = oracle_index(a), hip_index(a)
+    ox = oracle_index(a)
     qs, src = synth.make_queries(spec, 12, n_tokens=32, cen=a["centroids"])
     qs = list(qs) + [qs[0][:9]]
     p = P(n_full_scores=256, top_k=64, n_ivf_probe=4, centroid_score_threshold=None)
-    hx.tune("s4_filter", 0)
-    ref = hx.search_batch(qs, p)
-    hx.tune("s4_filter", 1)
-    for hot in (100, 0, 400):
-        hx.tune("s4_hot", hot)
-        got = hx.search_batch(qs, p)
-        st = dict(hx.last_stats)
-        for i, (g, r) in enumerate(zip(got, ref)):
-            assert np.array_equal(g.passage_ids, r.passage_ids) and np.array_equal(g.scores, r.scores), f"hot={hot} q{i}"
-        assert st["n_cand_dcodes"] / max(st["n_candidates"], 1) > 128, st      # the lists really are longer than one window
-        assert 0 < st["n_survivors"] < st["n_candidates"]
-    for g, o in zip(got, ox.search_batch(qs, to_oracle_params(p))):
-        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
-    check_trace(hx, ox, qs[1], P(n_full_scores=128, top_k=10, n_ivf_probe=4), what="long documents")
+    # Round 4: the block size is chosen at OPEN from s4_planes -- with the bit-plane first level (default) blocks go up to
+    # 512 bytes (a whole wave stages one: LPD = 4), without it 256 bytes.  Both layouts, and on the 256-byte one both
+    # first-level kernels (the plane kernel then runs LPD = 2 with every list in the overflow region).
+    for open_planes in ("1", "0"):
+        os.environ["NP_S4_PLANES"] = open_planes
+        try:
+            hx = hip_index(a)
+        finally:
+            del os.environ["NP_S4_PLANES"]
+        hx.tune("s4_filter", 0)
+        ref = hx.search_batch(qs, p)
+        hx.tune("s4_filter", 1)
+        for hot, planes in ((100, 1), (0, 1), (400, 1)) + (((100, 0), (400, 0)) if open_planes == "0" else ()):
+            hx.tune("s4_hot", hot)
+            hx.tune("s4_planes", planes)
+            got = hx.search_batch(qs, p)
+            st = dict(hx.last_stats)
+            for i, (g, r) in enumerate(zip(got, ref)):
+                assert np.array_equal(g.passage_ids, r.passage_ids) and np.array_equal(g.scores, r.scores), \
+                    f"open={open_planes} hot={hot} planes={planes} q{i}"
+            assert st["n_cand_dcodes"] / max(st["n_candidates"], 1) > 128, st      # the lists really are longer than one window
+            assert 0 < st["n_survivors"] < st["n_candidates"]
+            if hot:
+                assert 0 < st["n_level2"] < st["n_candidates"], (open_planes, hot, planes, st)   # the two-level filter really ran
+        for g, o in zip(got, ox.search_batch(qs, to_oracle_params(p))):
+            assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
+        check_trace(hx, ox, qs[1], P(n_full_scores=128, top_k=10, n_ivf_probe=4), what="long documents")
 
 
 def test_candidate_pool_rounds(mid):
