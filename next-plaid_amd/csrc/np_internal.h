@@ -131,6 +131,9 @@ struct Tuning {
   int s4_planes = 1;     // first filter level in bit-plane form (approx_hotp_kernel: 8 planes per hot centroid, OR + weighted popcount
                          // instead of 32 byte maxima per table row); 0 = approx_hot_kernel.  Read at OPEN too: with it the list blocks
                          // may be up to 512 bytes (corpora with long distinct-code lists), which approx_hot_kernel cannot stage
+  int s4_lpd = 2;        // approx_hotp_kernel: lanes per document -- 4: claims of 16 documents (half the LDS rows per wave: more waves per
+                         // CU hide the latency of the block loads), 2: claims of 32.  512-byte blocks always take 4
+  int s4_pnbx = 96;      // ... workgroups per XCD (3 per CU at 42 KB of LDS each with 2 lanes per document; 160 = 5 per CU with 4)
   int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim

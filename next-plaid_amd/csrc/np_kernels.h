@@ -2623,6 +2623,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
 //   bound  OR across the document's lanes (DPP), weighted popcount, u16 bound + LDS histogram.
 // ---------------------------------------------------------------------------------------------
 #define NP_PLANES 8
+#define NP_HOTP_SLACK 768   // spare LDS bytes behind a wave's staging rows (approx_hotp_kernel, stage: idle lanes of the last instruction)
 
 // Per query: the plane thresholds and the hot bitmap.  lev[b][0..7] = t_0..t_7 (t_0 = Lambda, hot_lam_kernel), lev[b][8..15] =
 // the weights t_{j+1} - t_j, with t_8 = the largest per-centroid maximum of the query's table and the levels spaced by a
@@ -2708,8 +2709,9 @@ __global__ void __launch_bounds__(256) hot_planes_kernel(const uint8_t* __restri
   }
 }
 
-template <int RB, typename CT, int LPD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) approx_hotp_kernel(
+template <int RB, typename CT, int LPD, int PF /* walk steps in flight ahead of the prefetch: 1 or 2 */,
+          int DPI /* documents per staging instruction: 4 (blocks <= 240 B), 2 (<= 496 B), 1 */>
+__global__ void __launch_bounds__(256) approx_hotp_kernel(
     const uint32_t* __restrict__ planes /* [B][KP][RB / 4] */, int64_t K, int64_t KP, const uint32_t* __restrict__ hotbits /* [B][KP / 32] */,
     const uint32_t* __restrict__ lam_b, const uint32_t* __restrict__ lev /* [B][16] */,
     const uint32_t* __restrict__ cand_ids /* [pool] shard-local document ids (compact_kernel) */,
@@ -2717,12 +2719,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) a
     int ublock_stride /* entries per document block of `codes` */, int64_t ovf_base /* first entry of the overflow region */,
     const int32_t* __restrict__ n_cand, RoundPlan rp, int round, int max_rounds, const CT* __restrict__ codes,
     const uint32_t* __restrict__ qflag, const int32_t* __restrict__ qoff, int n_sel, uint16_t* __restrict__ U,
-    uint32_t* __restrict__ hist, int hshift, int32_t* __restrict__ slots, int32_t* __restrict__ ticket, int B, Counters* ctr) {
+    uint32_t* __restrict__ hist, int hshift, int32_t* __restrict__ slots, int32_t* __restrict__ ticket, int B, Counters* ctr,
+    int probe_arg /* NP_DIAGNOSTICS builds only (results invalid when != 0): 1 no row loads in the walk, 2 no scan, 4 no staging */) {
   static_assert(RB == 32 || RB == 64, "plane rows of 32 or 64 query tokens");
   static_assert(LPD == 2 || LPD == 4, "lanes per document");
+#ifdef NP_DIAGNOSTICS
+  const int probe = probe_arg;
+#else
+  constexpr int probe = 0;
+#endif
   constexpr int DPW = 64 / LPD;                      // documents per claim
   constexpr int HDR = 16 / (int)sizeof(CT);          // entries of a block's 16-byte header {#distinct, doc length, overflow index, 0}
-  constexpr int NLD = LPD / 2;                       // 256-byte pieces of a block: load instructions per document
   constexpr int NS = RB / 4;                         // dwords of plane state (and of a plane row)
   constexpr int PW = RB / 32;                        // dwords per plane
   constexpr int G = 128 / RB;                        // hot positions popped per walk step (32 dwords of rows in flight)
@@ -2747,12 +2754,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) a
   const int bmw = SBM ? 0 : (int)(((KP >> 5) + 3) & ~3ll);   // dynamic bitmap words; the rows behind stay 16-byte aligned
   const int stride_b = ublock_stride * (int)sizeof(CT);              // block bytes (a multiple of 64)
   const int row_b = stride_b + 16;                   // LDS row: the block + 16 bytes (rows off each other's banks)
-  char* s_rows = reinterpret_cast<char*>(s_dyn + bmw) + (size_t)wave * DPW * row_b;
+  char* s_rows = reinterpret_cast<char*>(s_dyn + bmw) + (size_t)wave * (DPW * row_b + NP_HOTP_SLACK);
   const int fit = ublock_stride - HDR;               // codes a block holds = codes staged per window
   uint32_t toks32 = 0, ucnt32 = 0, rows32 = 0;
   // the scan looks every staged position up in the bitmap, also past a list's end: the rows must never hold anything but
   // codes (< K) behind the header, so they start zeroed (afterwards they only ever receive list entries or zeros)
-  for (int i = tid; i < 4 * DPW * row_b / 4; i += 256) (s_dyn + bmw)[i] = 0u;
+  for (int i = tid; i < 4 * (DPW * row_b + NP_HOTP_SLACK) / 4; i += 256) (s_dyn + bmw)[i] = 0u;
   for (int step = 0;; ++step) {
     __syncthreads();
     if (tid == 0) s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() { return -3; });
@@ -2796,33 +2803,54 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) a
     const int64_t NW = (int64_t)(gridDim.x >> 3) * 4;
     int64_t i0 = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW, i1 = i0 + NW * DPW;
     const uint32_t id_last = idb[n - 1];
-    uint32_t did = idb[min(i0 + grp, n - 1)];
     char* row = s_rows + (size_t)grp * row_b;        // this lane's document
     const CT* rowc = reinterpret_cast<const CT*>(row) + HDR;   // its codes (behind the block header)
-    for (;;) {
-      if (i0 >= n) break;
-      const uint32_t did_next = idb[min(i1 + grp, n - 1)];   // prefetch (clamped: a claim past the end is never used)
-      const int64_t i = i0 + grp;
-      const bool valid = i < n;
-      if (!valid) did = id_last;
-      // ---- stage: the claim's list BLOCKS -> LDS rows, header included.  One buffer_load_dword ... lds per 256 bytes of a
-      // block: the block's address is wave-uniform (document id by v_readlane, 64-bit address on the scalar unit), the
-      // data goes from memory straight into the LDS row (M0 = its address) -- no address or staging VGPRs, one VALU
-      // instruction per document.  Lanes past the block are masked off (their dwords belong to the next row).
-      __builtin_amdgcn_wave_barrier();       // the previous claim's rows are consumed
+    // ---- stage: a claim's list BLOCKS -> LDS rows, header included, by LDS-direct loads (buffer_load ... lds: the data goes
+    // from memory straight into the rows at M0 + lane x size, no staging VGPRs).  The stage is bound by the CU's vector-memory
+    // pipe, which charges a 64-lane instruction by the lanes and cache lines it touches, not by its bytes (a dword per lane
+    // moved 256 bytes per instruction: 675 pipe cycles per claim of 32 documents, more than scan and walk together).  So
+    // the blocks travel PACKED, 16 bytes per lane: a row = the block + 16 bytes of padding = LPR lanes, DPI documents per
+    // instruction (a power of two, DPI x LPR <= 64), per-lane offsets from the claim's FIRST block (candidate ids ascend,
+    // so the offsets are non-negative; a claim whose ids span 2 GiB of blocks takes the one-block-per-instruction path).
+    // NO lane is masked off: idle lanes are out of the buffer's range, get zero, and their 16 bytes land on the head of
+    // the rows the NEXT instruction fills, issued later (loads return in order; NP_HOTP_SLACK spare bytes follow a wave's
+    // last row).  Masking would put the loads behind an EXEC branch, and the compiler would then have to assume at every
+    // later wait that they may not have been issued: the wait for a walk step's rows would wait for these blocks too.
+    const int LPR = stride_b / 16 + 1;
+    const int sslot = lane / LPR, spiece = lane - sslot * LPR;
+    auto stage = [&](uint32_t dv) {
+      if (probe & 4) return;
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 63);
+      if ((uint64_t)(d1 - d0) * (uint64_t)stride_b < 0x7FFF0000ull && d1 >= d0) {
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<CT*>(codes) + (int64_t)d0 * ublock_stride, 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
-      for (int h = 0; h < NLD; ++h) {
-        if (256 * h + 4 * lane < stride_b) {
-#pragma unroll
-          for (int j = 0; j < DPW; ++j) {
-            const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)did, LPD * j);
-            const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<CT*>(codes) + (int64_t)dj * ublock_stride, 0, stride_b, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(s_rows + (size_t)j * row_b + 256 * h), 4, 256 * h + 4 * lane, 0, 0, 0);
-          }
+        for (int k = 0; k < DPW / DPI; ++k) {
+          const uint32_t dj = (uint32_t)__shfl((int)dv, LPD * (k * DPI + sslot));   // the id of this lane's document (any lane of its group)
+          const uint32_t voff = sslot < DPI ? (dj - d0) * (uint32_t)stride_b + 16u * (uint32_t)spiece : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(s_rows + (size_t)k * DPI * row_b), 16, (int)voff, 0, 0, 0);
+        }
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < DPW; ++j) {
+          const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dv, LPD * j);
+          const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<CT*>(codes) + (int64_t)dj * ublock_stride, 0, stride_b, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(s_rows + (size_t)j * row_b), 4, 4 * lane, 0, 0, 0);
+          if (stride_b > 256)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(s_rows + (size_t)j * row_b + 256), 4, 256 + 4 * lane, 0, 0, 0);
         }
       }
-      __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): the rows are in LDS
+    };
+    uint32_t did = i0 + grp < n ? idb[i0 + grp] : id_last;
+    if (i0 < n) stage(did);
+    for (;;) {
+      if (i0 >= n) break;
+      const int64_t i = i0 + grp;
+      const bool valid = i < n;
+      const bool more = i1 < n;                      // wave-uniform: this wave has another claim
+      const uint32_t did_next = more && i1 + grp < n ? idb[i1 + grp] : id_last;
+      __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): the claim's rows are in LDS
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const uint4 hd = *reinterpret_cast<const uint4*>(row);   // {#distinct, doc length, overflow index, 0}
@@ -2838,6 +2866,69 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) a
       uint32_t st[NS];
 #pragma unroll
       for (int k = 0; k < NS; ++k) st[k] = 0;
+      int hq = 0;                                    // entries in this lane's hot queue
+      // ---- walk: G queue entries per lane and step; a lane without one issues out-of-range offsets (no request).  With
+      // `prefetch` the next claim's blocks are requested right behind the first step's rows: the rest of the walk and the
+      // bound overlap their way from memory (vmcnt waits are in order, so the first step's rows arrive first).
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const char* hotq = nullptr;                    // the lane's hot queue (set by the scan of each window)
+      auto issue = [&](int t, u32x4 (&v)[G][RB / 16]) {
+        uint32_t c[G];
+        if constexpr (sizeof(CT) == 2 && G == 4) {
+          const uint2 q2 = *reinterpret_cast<const uint2*>(hotq + 2 * t);
+          c[0] = q2.x & 0xFFFFu; c[1] = q2.x >> 16; c[2] = q2.y & 0xFFFFu; c[3] = q2.y >> 16;
+        } else if constexpr (sizeof(CT) == 2) {
+          const uint32_t q1 = *reinterpret_cast<const uint32_t*>(hotq + 2 * t);
+          c[0] = q1 & 0xFFFFu; c[1] = q1 >> 16;
+        } else {
+#pragma unroll
+          for (int g = 0; g < G; g += 2) {
+            const uint2 q2 = *reinterpret_cast<const uint2*>(hotq + 4 * (t + g));
+            c[g] = q2.x; c[g + 1] = q2.y;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const uint32_t off = (t + g < hq && !(probe & 1)) ? c[g] * (uint32_t)RB : 0x7FFFFF00u;
+#pragma unroll
+          for (int k = 0; k < RB / 16; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)(off + 16u * k), 0, 0);
+        }
+      };
+      auto fold = [&](const u32x4 (&v)[G][RB / 16]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int k = 0; k < RB / 16; ++k) {
+            st[4 * k + 0] |= v[g][k].x;
+            st[4 * k + 1] |= v[g][k].y;
+            st[4 * k + 2] |= v[g][k].z;
+            st[4 * k + 3] |= v[g][k].w;
+          }
+      };
+      // The queue lives IN the row: a lane writes its hot codes back over the start of its own share (the write position
+      // never passes the codes already read).  `prefetch`: the queue's first PF steps are read and their rows requested,
+      // then the next claim's blocks right behind them (they overwrite the rows: every later queue entry must have been
+      // read before, so steps beyond PF run first), and only then are the rows folded -- straight-line code, so that the
+      // wait before the fold is vmcnt(#block loads): the rows arrive first (vmcnt is in order) and the blocks travel during
+      // the fold, the bound and the claim bookkeeping.
+      auto walk = [&](bool prefetch) {
+        const int hmax = wave_max_nonneg(hq);
+        for (int t = prefetch ? PF * G : 0; t < hmax; t += G) {
+          u32x4 v[G][RB / 16];
+          issue(t, v);
+          fold(v);
+        }
+        if (prefetch) {
+          u32x4 v0[G][RB / 16], v1[PF == 2 ? G : 1][RB / 16];
+          issue(0, v0);
+          if constexpr (PF == 2) issue(G, v1);
+          stage(did_next);
+          fold(v0);
+          if constexpr (PF == 2) fold(v1);
+        }
+        rows32 += (uint32_t)hq;
+        hq = 0;
+      };
       for (int p0 = 0; p0 < nmax; p0 += fit) {
         // lists that fit their block are already staged; only a claim with an overflow list or a further window of a long
         // list goes back to memory: the same LDS-direct loads, document by document, from the list's own address (reads
@@ -2853,8 +2944,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) a
             const int64_t clj = (int64_t)(((uint64_t)chi << 32) | clo) + p0;
             const int left_b = (min(ndj - p0, fit) * (int)sizeof(CT) + 3) & ~3;   // whole dwords: an odd u16 count reads one entry of the list's padding
             const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<CT*>(codes) + clj, 0, left_b, 0x00020000);
-#pragma unroll
-            for (int h = 0; h < NLD; ++h)
+            for (int h = 0; 256 * h < fit * (int)sizeof(CT); ++h)
               if (256 * h + 4 * lane < fit * (int)sizeof(CT))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr)(s_rows + (size_t)j * row_b + 16 + 256 * h), 4, 256 * h + 4 * lane, 0, 0, 0);
           }
@@ -2863,96 +2953,56 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) a
           __builtin_amdgcn_wave_barrier();
         }
         // ---- scan: lane jl of the document's LPD lanes tests codes [start, start + len) of the window, CPI per step (one
-        // 16-byte LDS read: 8 u16 / 4 u32 codes), the next step's codes already on their way while this step's bitmap
-        // words are looked up.  The hot flags enter the mask from the top (v_alignbit: acc = acc >> 1 | flag << 31, one
-        // instruction per code, and only bit 0 of `flag` counts, so the bitmap word is just shifted right by the code --
-        // shifts use the low 5 bits of their operand, which for the low code of a u16 pair is the packed dword itself);
-        // after n codes the first one sits at bit 32 - n.
+        // 16-byte LDS read: 8 u16 / 4 u32 codes).  Every code is WRITTEN to the lane's hot queue at the queue's current
+        // length and the length grows by the code's hot flag (one v_bfe_u32 on the bitmap word: the bit offset is the
+        // code's low 5 bits): a cold code is overwritten by the next one -- no branch, no compaction pass, no mask.  A
+        // lane's last step may run up to CPI - 1 positions past its list: those hold ZEROS (block padding / out-of-range
+        // reads), i.e. code 0, which at worst ORs centroid 0's planes into the bound -- still an upper bound.  The queue is
+        // all the walk reads, so after the last window's scan the rows are free for the next claim's blocks.
         constexpr int CPI = 16 / (int)sizeof(CT);
         const int cnt = min(max(nd - p0, 0), fit);
         const int share = (((cnt + LPD - 1) / LPD) + CPI - 1) & ~(CPI - 1);
         const int start = jl * share;
-        const int len = max(min(share, cnt - start), 0);
-        const int itmax = (((min(nmax - p0, fit) + LPD - 1) / LPD) + CPI - 1) & ~(CPI - 1);   // wave-uniform, >= every share, <= 64
-        auto rd = [&](int it) { return *reinterpret_cast<const uint4*>(rowc + min(start + it, fit - CPI)); };
-        auto look = [&](const uint4& w, uint32_t& acc) {
-          const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-          if constexpr (sizeof(CT) == 2) {
-            uint32_t bl[4], bh[4];
+        const int len8 = (max(min(share, cnt - start), 0) + CPI - 1) & ~(CPI - 1);      // this lane's positions, whole steps
+        const int itmax = (((min(nmax - p0, fit) + LPD - 1) / LPD) + CPI - 1) & ~(CPI - 1);   // wave-uniform, >= every len8, <= 64
+        CT* mine = const_cast<CT*>(rowc) + start;    // the lane's share: read CPI codes ahead, written back as the hot queue
+        hotq = reinterpret_cast<const char*>(mine);
+        uint4 w = *reinterpret_cast<const uint4*>(mine);
+        for (int it = 0; it < ((probe & 2) ? 0 : itmax); it += CPI) {
+          const uint4 wn = *reinterpret_cast<const uint4*>(mine + min(it + CPI, fit - CPI - start));   // next step's codes, on their way
+          if (it < len8) {
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            if constexpr (sizeof(CT) == 2) {
+              uint32_t bl[4], bh[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              bl[k] = BITS((ww[k] >> 5) & 0x7FFu);
-              bh[k] = BITS(ww[k] >> 21);
+              for (int k = 0; k < 4; ++k) {
+                bl[k] = BITS((ww[k] >> 5) & 0x7FFu);
+                bh[k] = BITS(ww[k] >> 21);
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                mine[hq] = (CT)ww[k];
+                hq += (int)__builtin_amdgcn_ubfe(bl[k], ww[k], 1u);
+                mine[hq] = (CT)(ww[k] >> 16);
+                hq += (int)__builtin_amdgcn_ubfe(bh[k], ww[k] >> 16, 1u);
+              }
+            } else {
+              uint32_t bw[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) bw[k] = BITS(ww[k] >> 5);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                mine[hq] = (CT)ww[k];
+                hq += (int)__builtin_amdgcn_ubfe(bw[k], ww[k], 1u);
+              }
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              acc = __builtin_amdgcn_alignbit(bl[k] >> (ww[k] & 31u), acc, 1);
-              acc = __builtin_amdgcn_alignbit(bh[k] >> ((ww[k] >> 16) & 31u), acc, 1);
-            }
-          } else {
-            uint32_t bw[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bw[k] = BITS(ww[k] >> 5);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_alignbit(bw[k] >> (ww[k] & 31u), acc, 1);
           }
-        };
-        uint32_t mlo = 0, mhi = 0;
-        const int n_lo = min(itmax, 32), n_hi = itmax - n_lo;   // codes per lane scanned into each half (multiples of CPI)
-        uint4 cur = rd(0);
-        for (int it = 0; it < n_lo; it += CPI) {
-          const uint4 nxt = rd(it + CPI);
-          look(cur, mlo);
-          cur = nxt;
+          w = wn;
         }
-        for (int it = 32; it < itmax; it += CPI) {
-          const uint4 nxt = rd(it + CPI);
-          look(cur, mhi);
-          cur = nxt;
-        }
-        mlo = n_lo ? mlo >> (32 - n_lo) : 0u;
-        mhi = n_hi ? mhi >> (32 - n_hi) : 0u;
-        unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
-        rows32 += (uint32_t)__popcll(m);
-        // ---- walk: G hot positions per lane and step; a lane without one issues out-of-range offsets (no request).  The
-        // positions of step s + 1 are popped and their codes read from LDS while the rows of step s are in flight.
-        bool has[G];
-        uint32_t c[G];
-        auto pop = [&]() {
-#pragma unroll
-          for (int g = 0; g < G; ++g) {   // straight-line: the LDS reads are unconditional (position 0 for an exhausted lane)
-            has[g] = m != 0ull;
-            const int p = max(__ffsll((long long)m) - 1, 0);
-            m &= m - 1ull;
-            c[g] = (uint32_t)rowc[start + p];
-          }
-        };
-        pop();
-        while (__ballot(has[0]) != 0ull) {
-          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-          u32x4 v[G][RB / 16];
-          uint32_t off[G];
-          // the fence keeps the compiler from sinking each LDS read into a branch of its own (dependent round trips)
-          if constexpr (G == 4) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
-          else asm volatile("" : "+v"(c[0]), "+v"(c[1]));
-#pragma unroll
-          for (int g = 0; g < G; ++g) off[g] = has[g] ? c[g] * (uint32_t)RB : 0x7FFFFF00u;
-#pragma unroll
-          for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int k = 0; k < RB / 16; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)(off[g] + 16u * k), 0, 0);
-          pop();
-#pragma unroll
-          for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int k = 0; k < RB / 16; ++k) {
-              st[4 * k + 0] |= v[g][k].x;
-              st[4 * k + 1] |= v[g][k].y;
-              st[4 * k + 2] |= v[g][k].z;
-              st[4 * k + 3] |= v[g][k].w;
-            }
-        }
+        const bool last_window = p0 + fit >= nmax;   // wave-uniform
+        if (!last_window) walk(false);
       }
+      walk(more);                                    // the last window's queue; the next claim's blocks ride behind its first step
       // ---- bound: OR across the document's lanes, weighted popcount
 #pragma unroll
       for (int k = 0; k < NS; ++k) {

@@ -314,6 +314,7 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         for hot, planes in ((0, 1), (10, 1), (100, 1), (300, 1), (500, 1), (10, 0), (100, 0), (300, 0)):
             hx.tune("s4_hot", hot)
             hx.tune("s4_planes", planes)
+            hx.tune("s4_lpd", 2 if hot in (10, 500) else 4)      # plane kernel: claims of 32 documents (2 lanes each) or 16 (4 lanes)
             hx.tune("ub_direct", 0 if hot == 300 else 8)   # short-list launch: per-XCD hand-out or one group of workgroups per query
             hx.tune("ub_static", 1 if hot in (10, 500) else 0)   # claims from a cursor (with stealing) or round-robin
             hx.tune("hot_static", 0 if hot in (10, 300) else 1)
@@ -364,6 +365,7 @@ def test_long_documents_overflow_blocks_and_windows():
         for hot, planes in ((100, 1), (0, 1), (400, 1)) + (((100, 0), (400, 0)) if open_planes == "0" else ()):
             hx.tune("s4_hot", hot)
             hx.tune("s4_planes", planes)
+            hx.tune("s4_lpd", 2 if hot == 400 else 4)            # (512-byte blocks take 4 lanes per document whatever the knob)
             got = hx.search_batch(qs, p)
             st = dict(hx.last_stats)
             for i, (g, r) in enumerate(zip(got, ref)):
