@@ -84,6 +84,11 @@ def parse():
                     help="HIP streams the steps are issued on round-robin (each step = one full batch pass; the "
                          "small launch-bound kernels of one batch overlap the memory-bound ones of the next)")
     ap.add_argument("--workspace-gib", type=float, default=0.0, help="per-context scratch budget (0 = library default)")
+    ap.add_argument("--from-disk", default="",
+                    help="directory: the generated corpus is exported, WRITTEN there as an index directory in the crate's on-disk "
+                         "format (np_hip_index_write_dir), the HBM copy dropped, and the bench runs on np_hip_index_open of that "
+                         "directory (= MmapIndex::load).  The line gains `disk_open` (seconds, bytes, GB/s: warm page cache and, "
+                         "when the box lets us drop caches, cold)")
     return ap.parse_args()
 
 
@@ -157,6 +162,41 @@ def main():
     t0 = time.time()
     ix = npa.MmapIndex.synth(spec, centroids=cen, **opts)
     t_build = time.time() - t0
+    disk_open = None
+    if a.from_disk:
+        if world > 1:
+            raise SystemExit("--from-disk is a one-GPU regime line")
+        import shutil
+        e = ix.export()
+        t_exp = time.time() - t0 - t_build
+        ix.close()
+        shutil.rmtree(a.from_disk, ignore_errors=True)
+        t1 = time.time()
+        npa.write_index_dir(a.from_disk, cen, synth.bucket_tables(spec)[1], e["doc_lengths"], e["codes"], e["residuals"], a.nbits,
+                            ivf=e["ivf"], ivf_lengths=e["ivf_lengths"])
+        t_write = time.time() - t1
+        nbytes = sum(os.path.getsize(os.path.join(a.from_disk, f)) for f in os.listdir(a.from_disk))
+        del e
+        t1 = time.time()
+        ix = npa.MmapIndex.load(a.from_disk, **opts)
+        t_warm = time.time() - t1
+        t_cold = None
+        try:   # cold: needs root and a writable /proc/sys (the GPU box's container usually has both)
+            ix.close()
+            os.sync()
+            with open("/proc/sys/vm/drop_caches", "w") as f:
+                f.write("3\n")
+            t1 = time.time()
+            ix = npa.MmapIndex.load(a.from_disk, **opts)
+            t_cold = time.time() - t1
+        except OSError:
+            ix = npa.MmapIndex.load(a.from_disk, **opts)
+        disk_open = dict(dir=a.from_disk, bytes=nbytes, files=len(os.listdir(a.from_disk)), export_s=round(t_exp, 2),
+                         write_s=round(t_write, 2), open_warm_s=round(t_warm, 2), open_warm_gbs=round(nbytes / 1e9 / t_warm, 2),
+                         open_cold_s=None if t_cold is None else round(t_cold, 2),
+                         open_cold_gbs=None if t_cold is None else round(nbytes / 1e9 / t_cold, 2),
+                         note="np_hip_index_open = MmapIndex::load of the crate's own file set (chunked i64 codes, packed residuals, "
+                              "JSON doclens, ivf.npy): seconds until the handle is searchable, derived structures included")
     if a.hot >= 0:
         ix.tune("s4_hot", a.hot)
     docs_local = int(ix.info.shard_doc_end - ix.info.shard_doc_begin)
@@ -438,6 +478,7 @@ def main():
                                   if use_dist else "single GPU"},
         "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
         "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stages.items()},
+        "disk_open": disk_open,
         "index_build_s": round(t_build, 2), "hbm_index_bytes": int(ix.info.device_bytes),
         "hbm_bytes_per_token": round(ix.info.device_bytes / max(int(ix.info.shard_embeddings), 1), 2),
     }

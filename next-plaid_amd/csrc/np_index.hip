@@ -9,7 +9,10 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <thread>
 #include <math.h>
+#include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -729,6 +732,100 @@ __global__ void __launch_bounds__(256) unpack_rows_kernel(const uint8_t* __restr
   dst[i] = (uint8_t)out;
 }
 
+// NP_OPEN_TRACE=1: seconds of each phase of an open to stderr (parse, token upload, posting lists, derived structures)
+struct OpenTrace {
+  bool on = getenv("NP_OPEN_TRACE") != nullptr;
+  double t0 = now();
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+  }
+  void mark(const char* what) {
+    if (!on) return;
+    (void)hipDeviceSynchronize();
+    const double t = now();
+    fprintf(stderr, "[np open] %-28s %8.3f s\n", what, t - t0);
+    t0 = t;
+  }
+};
+
+// ---- host -> HBM at the link's rate ----------------------------------------------------------------------------------
+// MmapIndex::load maps the chunk files and touches them lazily (index.rs:1096-1124); here the whole index has to cross
+// PCIe once.  A plain hipMemcpy from the mapping is a single-threaded copy out of the page cache into the runtime's own
+// staging buffer (3-6 GB/s: a 216 GB index would open in a minute).  Uploader keeps NP_UP_SLOTS pinned pieces in flight:
+// NP_UP_THREADS host threads copy a piece out of the mapping in parallel (page faults and all), the DMA engine moves the
+// previous piece meanwhile, and whatever the data needs (codes i64 -> u16 / u32 with the range check, residual rows to
+// storage geometry) is done by a kernel on the staged bytes in HBM -- no scalar loop on the host touches a token.
+#define NP_UP_SLOTS 3
+#define NP_UP_PIECE ((size_t)128 << 20)
+#define NP_UP_THREADS 12
+struct Uploader {
+  hipStream_t st = nullptr;
+  char* pin[NP_UP_SLOTS] = {};
+  hipEvent_t done[NP_UP_SLOTS] = {};
+  int next = 0;
+  int init() {
+    NP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int i = 0; i < NP_UP_SLOTS; ++i) {
+      NP_HIP(hipHostMalloc((void**)&pin[i], NP_UP_PIECE, hipHostMallocDefault));
+      NP_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    return NP_OK;
+  }
+  ~Uploader() {
+    if (st) (void)hipStreamSynchronize(st);
+    for (int i = 0; i < NP_UP_SLOTS; ++i) {
+      if (pin[i]) (void)hipHostFree(pin[i]);
+      if (done[i]) (void)hipEventDestroy(done[i]);
+    }
+    if (st) (void)hipStreamDestroy(st);
+  }
+  // parallel copy of [src, src + bytes) into a pinned slot (bytes <= NP_UP_PIECE); returns the slot
+  int fill(const void* src, size_t bytes, int* slot) {
+    const int s = next;
+    next = (next + 1) % NP_UP_SLOTS;
+    NP_HIP(hipEventSynchronize(done[s]));   // the slot's previous piece has left (a fresh event is complete)
+    const size_t per = ((bytes + NP_UP_THREADS - 1) / NP_UP_THREADS + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (int t = 1; t < NP_UP_THREADS; ++t) {
+      const size_t a = (size_t)t * per;
+      if (a >= bytes) break;
+      th.emplace_back([=] { memcpy(pin[s] + a, (const char*)src + a, std::min(per, bytes - a)); });
+    }
+    memcpy(pin[s], src, std::min(per, bytes));
+    for (auto& t : th) t.join();
+    *slot = s;
+    return NP_OK;
+  }
+  // the staged piece -> dst (device) ; `after` runs on the stream once the bytes are there
+  template <class F>
+  int send(int slot, size_t bytes, void* dst, F&& after) {
+    NP_HIP(hipMemcpyAsync(dst, pin[slot], bytes, hipMemcpyHostToDevice, st));
+    NP_TRY(after(st));
+    NP_HIP(hipEventRecord(done[slot], st));
+    return NP_OK;
+  }
+  int finish() {
+    NP_HIP(hipStreamSynchronize(st));
+    return NP_OK;
+  }
+};
+
+// codes as stored (i64, N.codes.npy) -> u16 / u32 with the loader's range check (first offending value to *bad, -1 = none)
+__global__ void __launch_bounds__(256) narrow_codes_kernel(const int64_t* __restrict__ src, int64_t n, int64_t K, void* __restrict__ dst,
+                                                           int wide, long long* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = src[i];
+  if (v < 0 || v >= K) {
+    atomicCAS((unsigned long long*)bad, (unsigned long long)-1ll, (unsigned long long)v);
+    return;
+  }
+  if (wide) static_cast<uint32_t*>(dst)[i] = (uint32_t)v;
+  else static_cast<uint16_t*>(dst)[i] = (uint16_t)v;
+}
+
 static int upload_repacked(DeviceIndex* ix, const uint8_t* rows, int64_t first_tok, int64_t n_tok) {
   const int64_t PIECE = (int64_t)1 << 20;   // tokens per staging piece
   uint8_t* d_stage = nullptr;
@@ -800,7 +897,9 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
   ix->dim = storage_dim(h.dim);
   ix->nbits = storage_nbits(h.dim, h.nbits);
   ix->pd = ix->dim * ix->nbits / 8;
+  OpenTrace trace;
   NP_TRY(upload_codec(ix, h.centroids, h.bucket_weights));
+  trace.mark("codec");
 
   // doc offsets of the shard + its token range inside the host arrays
   int64_t tb = 0;
@@ -831,75 +930,147 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
   }
   NP_TRY(dev_alloc(&ix->d_residuals, (size_t)ix->T * ix->pd, &ix->device_bytes));
   {
-    const int64_t PIECE = (int64_t)8 << 20;
-    std::vector<uint32_t> tmp((size_t)std::min<int64_t>(PIECE, std::max<int64_t>(ix->T, 1)));
-    std::vector<uint16_t> tmp16(ix->code_wide ? 0 : tmp.size());
+    Uploader up;
+    NP_TRY(up.init());
+    // device-side staging of raw pieces that need a kernel (i64 codes; residual rows in file geometry)
+    char* d_stage[NP_UP_SLOTS] = {};
+    long long* d_bad = nullptr;
+    struct FreeStage {
+      char** p;
+      long long** b;
+      ~FreeStage() {
+        for (int i = 0; i < NP_UP_SLOTS; ++i) (void)hipFree(p[i]);
+        (void)hipFree(*b);
+      }
+    } free_stage{d_stage, &d_bad};
+    for (int i = 0; i < NP_UP_SLOTS; ++i) NP_HIP(hipMalloc(&d_stage[i], NP_UP_PIECE));
+    NP_HIP(hipMalloc(&d_bad, 8));
+    NP_HIP(hipMemset(d_bad, 0xFF, 8));
+    const bool repack = ix->pd != ix->lpd;
+    const int widen = ix->lnbits != ix->nbits;
     int64_t pos = 0;  // token position of the current chunk's first token in the host arrays
     for (const HostChunk& c : h.chunks) {
-      int64_t a = std::max(pos, tb), b = std::min(pos + c.n_tokens, te);
-      for (int64_t s = a; s < b; s += PIECE) {
-        int64_t n = std::min(PIECE, b - s);
-        const char* src = (const char*)(c.codes) + (s - pos) * 8;
-        for (int64_t i = 0; i < n; ++i) {
-          int64_t v;
-          memcpy(&v, src + i * 8, 8);  // unaligned-safe, like mmap.rs:841-845
-          if (v < 0 || v >= ix->K) {
-            set_error("Index load failed: code %lld out of range [0,%lld)", (long long)v, (long long)ix->K);
-            return NP_ERR_INDEX_LOAD;
-          }
-          tmp[i] = (uint32_t)v;
-        }
-        if (ix->code_wide) {
-          NP_HIP(hipMemcpy((uint32_t*)ix->d_codes + (s - tb), tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-        } else {
-          for (int64_t i = 0; i < n; ++i) tmp16[i] = (uint16_t)tmp[i];
-          NP_HIP(hipMemcpy((uint16_t*)ix->d_codes + (s - tb), tmp16.data(), (size_t)n * 2, hipMemcpyHostToDevice));
-        }
+      const int64_t a = std::max(pos, tb), b = std::min(pos + c.n_tokens, te);
+      // codes: raw i64 pieces, narrowed and range-checked on the device
+      const int64_t CP = (int64_t)(NP_UP_PIECE / 8);
+      for (int64_t t0 = a; t0 < b; t0 += CP) {
+        const int64_t n = std::min(CP, b - t0);
+        int slot;
+        NP_TRY(up.fill((const char*)c.codes + (t0 - pos) * 8, (size_t)n * 8, &slot));
+        NP_TRY(up.send(slot, (size_t)n * 8, d_stage[slot], [&](hipStream_t st) -> int {
+          narrow_codes_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(
+              (const int64_t*)d_stage[slot], n, ix->K, (char*)ix->d_codes + (t0 - tb) * (int64_t)ix->code_bytes(), ix->code_wide, d_bad);
+          NP_HIP(hipGetLastError());
+          return (int)NP_OK;
+        }));
       }
-      if (b > a && ix->pd == ix->lpd) {
-        NP_HIP(hipMemcpy(ix->d_residuals + (a - tb) * ix->pd, c.residuals + (a - pos) * ix->pd,
-                         (size_t)(b - a) * ix->pd, hipMemcpyHostToDevice));
-      } else if (b > a) {   // file rows -> storage rows (zero-padded, 1-bit buckets widened to 2-bit segments)
-        NP_TRY(upload_repacked(ix, c.residuals + (a - pos) * ix->lpd, a - tb, b - a));
+      // residuals: straight into place, or through the staging area + repack (file rows -> storage rows: zero-padded,
+      // 1-bit buckets widened to 2-bit segments)
+      const int64_t RP = (int64_t)(NP_UP_PIECE / std::max(ix->lpd, 1));
+      for (int64_t t0 = a; t0 < b; t0 += RP) {
+        const int64_t n = std::min(RP, b - t0);
+        int slot;
+        NP_TRY(up.fill(c.residuals + (t0 - pos) * ix->lpd, (size_t)n * ix->lpd, &slot));
+        if (!repack) {
+          NP_TRY(up.send(slot, (size_t)n * ix->lpd, ix->d_residuals + (t0 - tb) * ix->pd, [](hipStream_t) -> int { return NP_OK; }));
+        } else {
+          NP_TRY(up.send(slot, (size_t)n * ix->lpd, d_stage[slot], [&](hipStream_t st) -> int {
+            repack_rows_kernel<<<(unsigned)((n * ix->pd + 255) / 256), 256, 0, st>>>((const uint8_t*)d_stage[slot], n, ix->lpd, ix->pd,
+                                                                                    widen, ix->d_residuals + (t0 - tb) * ix->pd);
+            NP_HIP(hipGetLastError());
+            return (int)NP_OK;
+          }));
+        }
       }
       pos += c.n_tokens;
     }
+    NP_TRY(up.finish());
     if (pos < te) {
       set_error("Index load failed: chunks hold %lld tokens, doclens need %lld", (long long)pos, (long long)te);
       return NP_ERR_INDEX_LOAD;
     }
+    long long bad = -1;
+    NP_HIP(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+    if (bad != -1) {
+      set_error("Index load failed: code %lld out of range [0,%lld)", bad, (long long)ix->K);
+      return NP_ERR_INDEX_LOAD;
+    }
   }
 
-  // IVF restricted to the shard, re-based to shard-local u32 ids
+  trace.mark("codes + residuals -> HBM");
+  // IVF restricted to the shard, re-based to shard-local u32 ids: two passes over the posting lists (count, then fill), the
+  // centroid range split over host threads (680 M i64 entries at 10 M x 300-token documents)
   {
-    std::vector<int64_t> ioff((size_t)ix->K + 1, 0);
-    std::vector<uint32_t> ivf;
-    ivf.reserve((size_t)std::min<int64_t>(h.ivf_size, ix->T));
-    int64_t p = 0;
+    std::vector<int64_t> ioff((size_t)ix->K + 1, 0), lstart((size_t)ix->K + 1, 0);
     for (int64_t c = 0; c < ix->K; ++c) {
-      int64_t l = h.ivf_lengths[c];
-      if (l < 0 || p + l > h.ivf_size) {
+      const int64_t l = h.ivf_lengths[c];
+      if (l < 0 || lstart[c] + l > h.ivf_size) {
         set_error("Index load failed: ivf_lengths inconsistent with ivf.npy at centroid %lld", (long long)c);
         return NP_ERR_INDEX_LOAD;
       }
-      for (int64_t i = 0; i < l; ++i) {
-        int64_t id;
-        memcpy(&id, (const char*)h.ivf + (p + i) * 8, 8);
-        if (id < 0 || id >= h.num_documents_total) {
-          set_error("Index load failed: ivf doc id %lld out of range", (long long)id);
-          return NP_ERR_INDEX_LOAD;
-        }
-        if (id >= sb && id < se) ivf.push_back((uint32_t)(id - sb));
-      }
-      p += l;
-      ioff[c + 1] = (int64_t)ivf.size();
+      lstart[c + 1] = lstart[c] + l;
     }
+    const int NT = (int)std::max<int64_t>(1, std::min<int64_t>(NP_UP_THREADS, ix->K / 1024));
+    const bool whole = sb == 0 && se == h.num_documents_total;
+    std::vector<int64_t> bad_id((size_t)NT, -1);
+    auto run = [&](auto&& body) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < NT; ++t) th.emplace_back([&, t] { body(t); });
+      body(0);
+      for (auto& x : th) x.join();
+    };
+    auto range = [&](int t, int64_t* c0, int64_t* c1) {   // centroid ranges of about equal posting volume
+      const int64_t tot = lstart[ix->K];
+      *c0 = std::lower_bound(lstart.begin(), lstart.end(), tot * t / NT) - lstart.begin();
+      *c1 = t + 1 == NT ? ix->K : std::lower_bound(lstart.begin(), lstart.end(), tot * (t + 1) / NT) - lstart.begin();
+      *c0 = std::min<int64_t>(*c0, ix->K);
+      *c1 = std::min<int64_t>(std::max(*c1, *c0), ix->K);
+    };
+    run([&](int t) {   // pass 1: entries of every list that fall into the shard, ids range-checked
+      int64_t c0, c1;
+      range(t, &c0, &c1);
+      for (int64_t c = c0; c < c1; ++c) {
+        int64_t cnt = 0;
+        const char* src = (const char*)h.ivf + lstart[c] * 8;
+        for (int64_t i = 0, l = lstart[c + 1] - lstart[c]; i < l; ++i) {
+          int64_t id;
+          memcpy(&id, src + i * 8, 8);
+          if (id < 0 || id >= h.num_documents_total) {
+            bad_id[t] = id;
+            return;
+          }
+          cnt += whole || (id >= sb && id < se);
+        }
+        ioff[c + 1] = cnt;
+      }
+    });
+    for (int t = 0; t < NT; ++t)
+      if (bad_id[t] != -1) {
+        set_error("Index load failed: ivf doc id %lld out of range", (long long)bad_id[t]);
+        return NP_ERR_INDEX_LOAD;
+      }
+    for (int64_t c = 0; c < ix->K; ++c) ioff[c + 1] += ioff[c];
+    std::vector<uint32_t> ivf((size_t)ioff[ix->K]);
+    run([&](int t) {   // pass 2
+      int64_t c0, c1;
+      range(t, &c0, &c1);
+      for (int64_t c = c0; c < c1; ++c) {
+        uint32_t* out = ivf.data() + ioff[c];
+        const char* src = (const char*)h.ivf + lstart[c] * 8;
+        for (int64_t i = 0, l = lstart[c + 1] - lstart[c]; i < l; ++i) {
+          int64_t id;
+          memcpy(&id, src + i * 8, 8);
+          if (whole || (id >= sb && id < se)) *out++ = (uint32_t)(id - sb);
+        }
+      }
+    });
     ix->ivf_size = (int64_t)ivf.size();
     NP_TRY(dev_alloc(&ix->d_ivf, ivf.size(), &ix->device_bytes));
     if (!ivf.empty()) NP_HIP(hipMemcpy(ix->d_ivf, ivf.data(), ivf.size() * 4, hipMemcpyHostToDevice));
     NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
     NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
   }
+  trace.mark("posting lists");
   NP_TRY(sort_tokens(ix));
   {
     int64_t* d_uoff = nullptr;
@@ -907,7 +1078,9 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     (void)hipFree(d_uoff);
     NP_TRY(rc);
   }
+  trace.mark("distinct-code blocks");
   NP_TRY(build_inv_norm(ix));
+  trace.mark("inverse norms");
   default_workspace(ix);
   cleanup.p = nullptr;
   *out = ix;
@@ -1315,7 +1488,9 @@ int np_hip_index_open(const char* index_dir, const np_open_opts* opts, np_index*
   }
   *out = nullptr;
   HostIndex h;
+  OpenTrace trace;
   NP_TRY(load_index_dir(index_dir, &h));
+  trace.mark("parse + map the directory");
   DeviceIndex* ix = nullptr;
   NP_TRY(build_device_index(h, opts, &ix));
   *out = static_cast<np_index*>(ix);
