@@ -92,6 +92,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "s6_tiles") t->s6_tiles = value != 0;
   else if (n == "s6_lds") t->s6_lds = clamp(value, 0, 2);
   else if (n == "gemm_cpw") t->gemm_cpw = value == 2 ? 2 : 1;
+  else if (n == "s1_split") t->s1_split = value != 0;
   else if (n == "exact_rowmax") t->exact_rowmax = value != 0;
   else return false;
   return true;
@@ -101,7 +102,7 @@ void read_tuning_env(Tuning* t) {
   static const char* const knobs[][2] = {
       {"NP_S4_MODE", "s4_mode"}, {"NP_S4_MINB", "s4_minb"}, {"NP_S4_NBX", "s4_nbx"}, {"NP_S4_SWZ", "s4_swz"},
       {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S4_LPD", "s4_lpd"}, {"NP_S4_PNBX", "s4_pnbx"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
-      {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"},
+      {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"}, {"NP_S1_SPLIT", "s1_split"},
       {"NP_EXACT_ROWMAX", "exact_rowmax"}};
   for (const auto& k : knobs) {
     const char* e = getenv(k[0]);

@@ -148,6 +148,8 @@ struct Tuning {
   int s6_xcd = 1;        // one XCD per query in S6
   int s6_lds = 1;        // QC-reuse S6: query fragments in LDS + C-in rows prefetched one tile ahead (exact_qcl_kernel); 0 = exact_qct_kernel
   int s6_tiles = 1;      // QC-reuse S6: one launch of the one-tile kernel per 32-token query tile (0: the multi-tile kernels)
+  int s1_split = 0;      // OPT-IN (np_hip_index_tune / NP_S1_SPLIT): split-bf16 S1 (qc_gemm_b3_kernel) when precision >= 1 and K >
+                         // centroid_batch_size -- S1-S5 are then no longer bit-equal to the f32 chain (near-ties < ~1e-5 can reorder)
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };

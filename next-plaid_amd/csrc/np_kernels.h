@@ -307,6 +307,145 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// S1, split-bf16 form (round 4; OPT-IN: precision >= 1 and K > centroid_batch_size, the crate's large-K regime).
+// At K = 2^19 (what kmeans.rs:303-309 picks for 10 M x 300-token documents) Q.C^T is 275 GFLOP per batch of 64 queries:
+// 1.75 ms at the exact-f32 MFMA peak, 3.5 ms measured -- the largest stage of that regime.  Here both operands are split
+// into bf16 hi + lo (x = hi + lo to ~2^-17 relative) and the product is hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_bf16,
+// f32 accumulation: three MFMAs at 16x the f32 rate, |error| <~ 2^-16 |q||c| per score (the dropped lo.lo term and the
+// bf16 rounding of lo) -- the arithmetic of the precision-2 MaxSim.  The values are NOT the k-ordered f32 FMA chain any
+// more, so S1-S5 are no longer bit-equal to the oracle in this mode: probed cells / candidates can differ at near-ties
+// closer than ~1e-5, rankings are checked with assert_ranking_close like the exact stage (tests/test_gpu_large_k.py).
+// precision 0 never takes this path.  Structure as qc_gemm_kernel: a wave keeps one 32-centroid A fragment (hi and lo, 64
+// VGPRs) for the whole kernel and walks every 32-token query tile; tiles arrive by global_load_lds into a double buffer,
+// laid out [hi | lo][k-step][k-half][token] in 16-byte pieces so that the B operand reads are conflict-free.
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(256) qc_gemm_b3_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
+                                                         const __bf16* __restrict__ Qb, const __bf16* __restrict__ Qbl, int B,
+                                                         int LQP, float* __restrict__ QCT, uint32_t* __restrict__ gmax,
+                                                         uint8_t* __restrict__ QCU, int RB, const float* __restrict__ qinv,
+                                                         const int32_t* __restrict__ qoff) {
+  constexpr int NS = DIM / 16;                 // k-steps of 16
+  constexpr int TILE_B = DIM * 32 * 2;         // bytes of one bf16 tile (hi or lo)
+  constexpr int NV = 2 * TILE_B / (256 * 16);  // 16-byte DMA pieces per thread per tile
+  __shared__ __attribute__((aligned(16))) char sQ[2][2 * TILE_B];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, kk = lane >> 5, wave = tid >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const bool active = c0 < KP;
+  bf16x8 ah[NS], al[NS];
+  {
+    const int64_t r0 = c0 + li;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float v[8];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 < K) f = *reinterpret_cast<const float4*>(C + r0 * DIM + 16 * s + 8 * kk + 4 * m);
+        v[4 * m] = f.x; v[4 * m + 1] = f.y; v[4 * m + 2] = f.z; v[4 * m + 3] = f.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        ah[s][e] = h;
+        al[s][e] = (__bf16)(v[e] - (float)h);
+      }
+    }
+  }
+  const int nqt = LQP >> 5;
+  const int ntiles = B * nqt;
+  const int64_t G = KP >> 5;
+  auto dma_tile = [&](int tile, int buf) {
+    const int b = tile / nqt, qt = tile - b * nqt;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int p = j * 256 + tid;                    // 16-byte piece of the buffer: [half][s][kk][token]
+      const int half = p / (TILE_B / 16), pp = p - half * (TILE_B / 16);
+      const int s = pp >> 6, k2 = (pp >> 5) & 1, tok = pp & 31;
+      const __bf16* src = (half ? Qbl : Qb) + ((int64_t)b * LQP + qt * 32 + tok) * DIM + 16 * s + 8 * k2;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(&sQ[buf][(j * 256 + wave * 64) * 16]), 16, 0, 0);
+    }
+  };
+  constexpr int TS = 36;   // f32 tile row stride in words (see qc_gemm_kernel)
+  __shared__ __attribute__((aligned(16))) float sT[4][32 * TS];
+  __shared__ __attribute__((aligned(16))) uint8_t sU[4][32 * 32];
+  auto epilogue = [&](const f32x16& acc, int tile) {
+    const int b = nqt == 1 ? tile : tile / nqt, qt = tile - b * nqt;
+    const int h = lane >> 5, rr = (lane & 31) >> 3, c4 = lane & 7;
+    float vsum = 0.f, vmax = acc[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sT[wave][mfma_row(r, kk) * TS + li] = acc[r];
+      vsum += acc[r];
+      vmax = fmaxf(vmax, acc[r]);
+    }
+    uint32_t k0;
+    if (c0 + 32 <= K && __ballot(!finitef(vsum)) == 0ull) {
+      k0 = okey(vmax);
+    } else {
+      k0 = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) k0 = max(k0, (c0 + mfma_row(r, kk) < K) ? okey(acc[r]) : 0u);
+    }
+    k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
+    if (kk == 0) gmax[((int64_t)b * G + (c0 >> 5)) * LQP + qt * 32 + li] = k0;
+    if (QCU) {
+      const float inv = qinv[b];
+      const bool qv = qt * 32 + li < qoff[b + 1] - qoff[b];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // the split product can exceed the Cauchy-Schwarz bound of the f32 chain by its own error: clamp to the table's range
+        const float hh = fminf(fmaxf(fmaf(acc[r] * inv, 127.5f, 127.5f), 0.f), 254.5f);
+        const uint32_t u = qv ? (uint32_t)hh + 1u : 0u;
+        sU[wave][mfma_row(r, kk) * 32 + li] = (uint8_t)u;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* outb = QCT + ((int64_t)b * KP + c0) * LQP + qt * 32 + 4 * c4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 8 * g + 4 * h + rr;
+      const float4 v = *reinterpret_cast<const float4*>(&sT[wave][row * TS + 4 * c4]);
+      *reinterpret_cast<float4*>(outb + (int64_t)row * LQP) = v;
+    }
+    if (QCU) {
+      const int row = lane >> 1, half = lane & 1;
+      const uint4 v = *reinterpret_cast<const uint4*>(&sU[wave][row * 32 + 16 * half]);
+      *reinterpret_cast<uint4*>(QCU + ((int64_t)b * KP + c0 + row) * RB + qt * 32 + 16 * half) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (ntiles > 0) dma_tile(0, 0);
+  __syncthreads();
+  f32x16 prev;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) dma_tile(tile + 1, (tile + 1) & 1);
+    if (active) {
+      if (tile > 0) epilogue(prev, tile - 1);
+      const char* qb = &sQ[tile & 1][0];
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(qb + 16 * ((s * 2 + kk) * 32 + li));
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(qb + TILE_B + 16 * ((s * 2 + kk) * 32 + li));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl, acc, 0, 0, 0);
+      }
+      prev = acc;
+    }
+    __syncthreads();
+  }
+  if (active && ntiles > 0) epilogue(prev, ntiles - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // S2 helpers: block-level radix select for QW query tokens at once.
 // Thread (r = tid / QW, q = tid % QW); `enumerate(cb)` calls cb(key) for this thread's items of
 // token q.  On return s_prefix[q] = key of the want-th largest item, s_rem[q] = how many items
@@ -2678,32 +2817,64 @@ __global__ void __launch_bounds__(256) hot_planes_kernel(const uint8_t* __restri
                                                          const uint8_t* __restrict__ cmaxu, const uint32_t* __restrict__ lam_b,
                                                          const uint32_t* __restrict__ lev, uint32_t* __restrict__ planes) {
   static_assert(RB == 32 || RB == 64, "plane rows of 32 or 64 query tokens");
-  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // A block takes 2048 centroids at a time: their hot ones are compacted into LDS (one ballot per wave and 64 centroids),
+  // then every LANE builds the row of one hot centroid -- its RB bytes against the 8 thresholds, two instructions per
+  // (byte, threshold) -- so the work is spread over all lanes whatever the hot share (a wave building one row at a time
+  // by ballots took 0.33 ms per batch at K = 2^19).
+  constexpr int CH = 2048;
+  __shared__ uint32_t s_list[CH];
+  __shared__ int s_n;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const uint32_t lam = lam_b[b];
   uint32_t t[NP_PLANES];
 #pragma unroll
   for (int j = 0; j < NP_PLANES; ++j) t[j] = lev[b * 16 + j];
   const uint8_t* cm = cmaxu + (int64_t)b * KP;
-  for (int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 64; c0 < KP; c0 += (int64_t)gridDim.x * 256) {
-    const bool hot = (uint32_t)cm[c0 + lane] > lam;   // KP is a multiple of 64
-    unsigned long long hm = __ballot(hot);
-    while (hm) {
-      const int l = __builtin_ctzll(hm);
-      hm &= hm - 1;
-      const int64_t row = (int64_t)b * KP + c0 + l;
-      const uint32_t u = lane < RB ? (uint32_t)QCU[row * RB + lane] : 0u;
-      uint32_t lo = 0, hi = 0;
+  for (int64_t c0 = (int64_t)blockIdx.x * CH; c0 < KP; c0 += (int64_t)gridDim.x * CH) {
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = tid; i < CH; i += 256) {   // CH is a multiple of 256: whole waves
+      const int64_t c = c0 + i;
+      const bool hot = c < KP && (uint32_t)cm[c] > lam;
+      const unsigned long long bal = __ballot(hot);
+      int base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&s_n, (int)__popcll(bal));
+      base = __shfl(base, 0);
+      if (hot) s_list[base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int i = tid; i < n; i += 256) {
+      const int64_t row = (int64_t)b * KP + c0 + s_list[i];
+      const uint4* src = reinterpret_cast<const uint4*>(QCU + row * RB);
+      uint32_t pl[NP_PLANES][RB / 32];
 #pragma unroll
-      for (int j = 0; j < NP_PLANES; ++j) {
-        const unsigned long long pm = __ballot(u > t[j]);
-        if (lane == j) {
-          lo = (uint32_t)pm;
-          hi = (uint32_t)(pm >> 32);
-        }
+      for (int j = 0; j < NP_PLANES; ++j)
+#pragma unroll
+        for (int h = 0; h < RB / 32; ++h) pl[j][h] = 0;
+#pragma unroll
+      for (int q4 = 0; q4 < RB / 16; ++q4) {
+        const uint4 v = src[q4];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (w4[e] >> (8 * k)) & 0xFFu;
+            const int q = 16 * q4 + 4 * e + k;
+#pragma unroll
+            for (int j = 0; j < NP_PLANES; ++j) pl[j][q >> 5] |= (u > t[j] ? 1u : 0u) << (q & 31);
+          }
       }
-      if (lane < NP_PLANES) {
-        if constexpr (RB == 32) planes[row * 8 + lane] = lo;
-        else *reinterpret_cast<uint2*>(planes + row * 16 + 2 * lane) = make_uint2(lo, hi);
+      uint32_t* dst = planes + row * (RB / 4);
+      if constexpr (RB == 32) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pl[0][0], pl[1][0], pl[2][0], pl[3][0]);
+        *reinterpret_cast<uint4*>(dst + 4) = make_uint4(pl[4][0], pl[5][0], pl[6][0], pl[7][0]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NP_PLANES; j += 2)
+          *reinterpret_cast<uint4*>(dst + 2 * j) = make_uint4(pl[j][0], pl[j][1], pl[j + 1][0], pl[j + 1][1]);
       }
     }
   }

@@ -586,7 +586,27 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // ---- S1
   prep_queries_kernel<<<B, 256, 0, st>>>(d_q, d_qoff, ix->dim, LQP, w.Qt.as<float>(), w.Qb.as<__bf16>(),
                                          w.Qbl.as<__bf16>(), ix->cmax, w.qinv.as<float>(), w.qflag.as<uint32_t>());
-  {
+  // split-bf16 S1 (qc_gemm_b3_kernel): opt-in, only where the crate itself leaves the dense path (K > centroid_batch_size)
+  // and the caller asked for a reduced-precision mode; precision 0 keeps the exact-f32 chain everywhere
+  // (with it the approximate scores stay the GEMM's: the batched path's mat-vec re-scoring -- there to reproduce the
+  // reference's non-FMA summation order bit for bit, 1.6 ms of packed-f32 VALU work per batch at K = 2^19 -- has nothing
+  // left to reproduce)
+  const bool s1_split = ix->tune.s1_split && prm.precision >= 1 && prm.centroid_batch_size > 0 &&
+                        ix->K > prm.centroid_batch_size && !cs->trace;
+  if (s1_split) {
+    uint8_t* qcu = use_filter ? w.QCU.as<uint8_t>() : nullptr;
+    const unsigned blocks = (unsigned)((ix->KP / 32 + 3) / 4);
+#define NP_GEMM_B3(D)                                                                                                     \
+  qc_gemm_b3_kernel<D><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, w.Qb.as<__bf16>(), w.Qbl.as<__bf16>(), B, LQP, \
+                                               w.QCT.as<float>(), w.gmax.as<uint32_t>(), qcu, RB, w.qinv.as<float>(), d_qoff)
+    switch (ix->dim) {
+      case 32: NP_GEMM_B3(32); break;
+      case 64: NP_GEMM_B3(64); break;
+      case 96: NP_GEMM_B3(96); break;
+      default: NP_GEMM_B3(128); break;
+    }
+#undef NP_GEMM_B3
+  } else {
     uint8_t* qcu = use_filter ? w.QCU.as<uint8_t>() : nullptr;
     const float* qinv = w.qinv.as<float>();
     switch (ix->dim) {
@@ -603,7 +623,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     if (use_planes) {   // thresholds of the 8 planes, then the plane rows of the hot centroids
       hot_levels_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.cmaxu.as<uint8_t>(), KP,
                                            ix->tune.s4_pexp, w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>());
-      const dim3 pg((unsigned)std::min<int64_t>((KP + 255) / 256, 64), B);
+      const dim3 pg((unsigned)std::min<int64_t>((KP + 2047) / 2048, 64), B);
       if (RB == 32)
         hot_planes_kernel<32><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
                                                   w.levels.as<uint32_t>(), w.planes.as<uint32_t>());
@@ -911,7 +931,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       sp.cand_step = 4;
       sp.n_cand = w.n_surv.as<int32_t>();
       sp.ctr = w.ctr.as<Counters>();
-      if (batched) {
+      if (batched && !s1_split) {
         // reference arithmetic of the batched path: G-valued cut with a rounding margin, then the mat-vec scores
         // of what is left (the candidate records of this round are consumed: their array takes the second list)
         gcut_kernel<<<B, 1024, 0, st>>>(w.approx.as<float>(), w.surv_meta.as<uint4>(), w.n_surv.as<int32_t>(), rp, r, cs->n_sel,
@@ -922,7 +942,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
         sp.n_cand = w.n_list2.as<int32_t>();
       }
     } else if (ix->T > 0) {
-      if (batched) {   // debug trace / filter off: the mat-vec score of every candidate
+      if (batched && !s1_split) {   // debug trace / filter off: the mat-vec score of every candidate
         launch_matvec(st, ix, w, d_q, d_qoff, B, w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r);
         count_work_kernel<<<dim3(32, (unsigned)B), 256, 0, st>>>(w.cand_meta.as<uint4>(), w.n_cand.as<int32_t>(), rp, r,
                                                                  w.ctr.as<Counters>());

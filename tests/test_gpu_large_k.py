@@ -109,6 +109,37 @@ def test_production_path_selects_the_oracles_set(big):
         assert g.passage_ids[0] == src[i]
 
 
+def test_split_bf16_centroid_scores_opt_in(big):
+    """Round 4: s1_split = 1 computes Q.C^T on the batched path as hi.hi + lo.hi + hi.lo in bf16 MFMAs (qc_gemm_b3_kernel,
+    ~5x the exact-f32 MFMA rate; the crate's heuristic K at 10 M documents is 2^19, where S1 is the largest stage).  The
+    values differ from the f32 chain by ~1e-6 relative, so cells / candidates may differ at near-ties: the contract is the
+    exact stage's -- rankings and scores within the stated tolerance of the oracle, the source document first -- and the
+    knob must do nothing on the dense path and under precision 0."""
+    name, spec, hx, ox, qs, src, cbs = big
+    batched = spec.num_centroids > cbs
+    p = P(n_full_scores=4096, top_k=10, n_ivf_probe=32, centroid_score_threshold=0.4, centroid_batch_size=cbs)
+    ref = ox.search_batch(qs, to_oracle_params(p))
+    base = hx.search_batch(qs, p)
+    hx.tune("s1_split", 1)
+    try:
+        got = hx.search_batch(qs, p)
+        n_same = 0
+        for i, (g, o, b0) in enumerate(zip(got, ref, base)):
+            assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, 5e-5, f"{name} split q{i}")
+            assert g.passage_ids[0] == src[i]
+            n_same += int(np.array_equal(g.passage_ids, b0.passage_ids))
+            if not batched:
+                assert np.array_equal(g.passage_ids, b0.passage_ids) and np.array_equal(g.scores, b0.scores)   # dense path: untouched
+        assert n_same >= len(qs) - 1, (name, n_same)
+        p0 = P(n_full_scores=1024, top_k=10, n_ivf_probe=8, centroid_batch_size=cbs, precision=0)
+        a = hx.search_batch(qs[:8], p0)
+        hx.tune("s1_split", 0)
+        for g, o in zip(a, hx.search_batch(qs[:8], p0)):      # precision 0 never takes the split path
+            assert np.array_equal(g.passage_ids, o.passage_ids) and np.array_equal(g.scores, o.scores)
+    finally:
+        hx.tune("s1_split", 0)
+
+
 def test_colgrep_window_and_encoder_query_length(big):
     """The two caller defaults the 32-token / 4096 headline does not exercise: ColGREP re-ranks n_full_scores = 8192
     candidates (colgrep/src/index/mod.rs:771-777: n_sel = 2048) and the ONNX encoder pads queries to 48 tokens
