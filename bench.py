@@ -54,6 +54,9 @@ def parse():
                     help="of 256: share of tokens with a uniformly random code (51 = 20 %%: ~68 distinct codes per 300-token "
                          "document = 0.23 per token; 121 -> 0.5; 200 -> 0.8)")
     ap.add_argument("--hot", type=int, default=-1, help="s4_hot per-mille (first filter level); -1 = library default")
+    ap.add_argument("--s1-split", action="store_true",
+                    help="opt into the split-bf16 S1 (qc_gemm_b3_kernel) where K > centroid_batch_size and precision >= 1: S1-S5 are "
+                         "then no longer bit-equal to the f32 chain (the crate-heuristic K = 2^19 line runs with it)")
     ap.add_argument("--centroids", type=int, default=65536)
     ap.add_argument("--nbits", type=int, default=4)
     ap.add_argument("--nprobe", type=int, default=32)
@@ -199,6 +202,10 @@ def main():
                               "JSON doclens, ivf.npy): seconds until the handle is searchable, derived structures included")
     if a.hot >= 0:
         ix.tune("s4_hot", a.hot)
+    if a.s1_split:
+        ix.tune("s1_split", 1)
+    s1_split = (a.s1_split or os.environ.get("NP_S1_SPLIT", "0") not in ("", "0")) and a.precision >= 1 and \
+        0 < a.centroid_batch_size < a.centroids
     docs_local = int(ix.info.shard_doc_end - ix.info.shard_doc_begin)
     thr = None if a.threshold < 0 else a.threshold
     prm = npa.SearchParameters(n_full_scores=a.n_full_scores, top_k=a.top_k, n_ivf_probe=a.nprobe,
@@ -367,7 +374,10 @@ def main():
     cand_tokens, exact_tokens = stages["n_cand_tokens"], stages["n_exact_tokens"]
     per_stage = {
         # name: (ms, bound, algorithmic units per launch, unit, peak)
-        "qc_gemm(S1)": (stages["ms_centroid"], "mfma", 2.0 * a.batch * Lq * d * a.centroids / 1e12, "TFLOP/s", MFMA_F32_PEAK_TF),
+        # split-bf16 S1: three bf16 MFMAs per product, priced against the dense bf16 peak
+        "qc_gemm(S1)": ((stages["ms_centroid"], "mfma", 3 * 2.0 * a.batch * Lq * d * a.centroids / 1e12, "TFLOP/s", MFMA_BF16_PEAK_TF)
+                        if s1_split else
+                        (stages["ms_centroid"], "mfma", 2.0 * a.batch * Lq * d * a.centroids / 1e12, "TFLOP/s", MFMA_F32_PEAK_TF)),
         "probe(S2)": (stages["ms_probe"], "hbm", (a.batch * (a.centroids / 32) * Lq * 4) / 1e9, "GB/s", HBM_PEAK_GBS),
         "candidates(S3)": (stages["ms_candidates"], "hbm", (stages["n_ivf_ids"] * 4 + stages["n_candidates"] * 4) / 1e9, "GB/s", HBM_PEAK_GBS),
         "approx(S4)": (stages["ms_approx"], "hbm", (cand_tokens * 4 + stages["n_candidates"] * 8) / 1e9, "GB/s", HBM_PEAK_GBS),
@@ -471,6 +481,7 @@ def main():
                    "centroids_note": (f"K = 2^{k2} is an explicit choice (BASELINE config 2's K carried to this corpus; the metric "
                                       f"names no K).  The crate's k-means heuristic (kmeans.rs:303-309) would pick 2^19 at 10 M x 300 "
                                       f"tokens, the batched-probe regime: run --centroids 524288 for that line") if a.centroids == 65536 and a.docs >= 5_000_000 else None,
+                   "s1_split": bool(s1_split),
                    "docs_total": a.docs, "docs_per_gpu": docs_local, "batch": a.batch, "shards": n_shards, "replicas": n_repl,
                    "parallelism": ((f"doc-shard x{n_shards} + RCCL all-gather ({'np_hip_search_batch_sharded' if dist_impl == 'c' else 'torch.distributed harness'}){dist_note}"
                                     if use_shards else "whole index per GPU")

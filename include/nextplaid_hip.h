@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 3
+#define NP_ABI_VERSION 4
 
 typedef enum np_status {
   NP_OK = 0,

@@ -134,6 +134,7 @@ struct Tuning {
   int s4_lpd = 2;        // approx_hotp_kernel: lanes per document -- 4: claims of 16 documents (half the LDS rows per wave: more waves per
                          // CU hide the latency of the block loads), 2: claims of 32.  512-byte blocks always take 4
   int s4_pnbx = 96;      // ... workgroups per XCD (3 per CU at 42 KB of LDS each with 2 lanes per document; 160 = 5 per CU with 4)
+  int s4_qm = 1;         // ... a lane's hot codes as a position mask in registers (1) or compacted in place by LDS writes (0)
   int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim

@@ -2762,7 +2762,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
 //   bound  OR across the document's lanes (DPP), weighted popcount, u16 bound + LDS histogram.
 // ---------------------------------------------------------------------------------------------
 #define NP_PLANES 8
-#define NP_HOTP_SLACK 768   // spare LDS bytes behind a wave's staging rows (approx_hotp_kernel, stage: idle lanes of the last instruction)
 
 // Per query: the plane thresholds and the hot bitmap.  lev[b][0..7] = t_0..t_7 (t_0 = Lambda, hot_lam_kernel), lev[b][8..15] =
 // the weights t_{j+1} - t_j, with t_8 = the largest per-centroid maximum of the query's table and the levels spaced by a
@@ -2881,7 +2880,8 @@ __global__ void __launch_bounds__(256) hot_planes_kernel(const uint8_t* __restri
 }
 
 template <int RB, typename CT, int LPD, int PF /* walk steps in flight ahead of the prefetch: 1 or 2 */,
-          int DPI /* documents per staging instruction: 4 (blocks <= 240 B), 2 (<= 496 B), 1 */>
+          int DPI /* documents per staging instruction: 4 (blocks <= 240 B), 2 (<= 496 B), 1 */,
+          int QM /* hot codes of a lane: 0 = compacted in place over its share (LDS writes), 1 = a 64-bit position mask in registers */>
 __global__ void __launch_bounds__(256) approx_hotp_kernel(
     const uint32_t* __restrict__ planes /* [B][KP][RB / 4] */, int64_t K, int64_t KP, const uint32_t* __restrict__ hotbits /* [B][KP / 32] */,
     const uint32_t* __restrict__ lam_b, const uint32_t* __restrict__ lev /* [B][16] */,
@@ -2891,6 +2891,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
     const int32_t* __restrict__ n_cand, RoundPlan rp, int round, int max_rounds, const CT* __restrict__ codes,
     const uint32_t* __restrict__ qflag, const int32_t* __restrict__ qoff, int n_sel, uint16_t* __restrict__ U,
     uint32_t* __restrict__ hist, int hshift, int32_t* __restrict__ slots, int32_t* __restrict__ ticket, int B, Counters* ctr,
+    int slack /* spare LDS bytes behind a wave's rows: what the idle lanes of the last staging instruction overrun */,
     int probe_arg /* NP_DIAGNOSTICS builds only (results invalid when != 0): 1 no row loads in the walk, 2 no scan, 4 no staging */) {
   static_assert(RB == 32 || RB == 64, "plane rows of 32 or 64 query tokens");
   static_assert(LPD == 2 || LPD == 4, "lanes per document");
@@ -2925,12 +2926,12 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
   const int bmw = SBM ? 0 : (int)(((KP >> 5) + 3) & ~3ll);   // dynamic bitmap words; the rows behind stay 16-byte aligned
   const int stride_b = ublock_stride * (int)sizeof(CT);              // block bytes (a multiple of 64)
   const int row_b = stride_b + 16;                   // LDS row: the block + 16 bytes (rows off each other's banks)
-  char* s_rows = reinterpret_cast<char*>(s_dyn + bmw) + (size_t)wave * (DPW * row_b + NP_HOTP_SLACK);
+  char* s_rows = reinterpret_cast<char*>(s_dyn + bmw) + (size_t)wave * (DPW * row_b + slack);
   const int fit = ublock_stride - HDR;               // codes a block holds = codes staged per window
   uint32_t toks32 = 0, ucnt32 = 0, rows32 = 0;
   // the scan looks every staged position up in the bitmap, also past a list's end: the rows must never hold anything but
   // codes (< K) behind the header, so they start zeroed (afterwards they only ever receive list entries or zeros)
-  for (int i = tid; i < 4 * (DPW * row_b + NP_HOTP_SLACK) / 4; i += 256) (s_dyn + bmw)[i] = 0u;
+  for (int i = tid; i < 4 * (DPW * row_b + slack) / 4; i += 256) (s_dyn + bmw)[i] = 0u;
   for (int step = 0;; ++step) {
     __syncthreads();
     if (tid == 0) s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() { return -3; });
@@ -2984,7 +2985,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
     // instruction (a power of two, DPI x LPR <= 64), per-lane offsets from the claim's FIRST block (candidate ids ascend,
     // so the offsets are non-negative; a claim whose ids span 2 GiB of blocks takes the one-block-per-instruction path).
     // NO lane is masked off: idle lanes are out of the buffer's range, get zero, and their 16 bytes land on the head of
-    // the rows the NEXT instruction fills, issued later (loads return in order; NP_HOTP_SLACK spare bytes follow a wave's
+    // the rows the NEXT instruction fills, issued later (loads return in order; slack spare bytes follow a wave's
     // last row).  Masking would put the loads behind an EXEC branch, and the compiler would then have to assume at every
     // later wait that they may not have been issued: the wait for a walk step's rows would wait for these blocks too.
     const int LPR = stride_b / 16 + 1;
@@ -3043,8 +3044,31 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
       // bound overlap their way from memory (vmcnt waits are in order, so the first step's rows arrive first).
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       const char* hotq = nullptr;                    // the lane's hot queue (set by the scan of each window)
+      unsigned long long hm = 0ull;                  // QM = 1: the lane's hot positions inside its share
       auto issue = [&](int t, u32x4 (&v)[G][RB / 16]) {
         uint32_t c[G];
+        if constexpr (QM == 1) {
+          // pop G positions from the bottom of the mask: straight-line, the LDS reads unconditional (position 0 for an
+          // exhausted lane) and fenced so that the compiler does not sink each into a branch of its own
+          const CT* mine_c = reinterpret_cast<const CT*>(hotq);
+          bool has[G];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            has[g] = hm != 0ull;
+            const int p = max(__ffsll((long long)hm) - 1, 0);
+            hm &= hm - 1ull;
+            c[g] = (uint32_t)mine_c[p];
+          }
+          if constexpr (G == 4) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+          else asm volatile("" : "+v"(c[0]), "+v"(c[1]));
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const uint32_t off = (has[g] && !(probe & 1)) ? c[g] * (uint32_t)RB : 0x7FFFFF00u;
+#pragma unroll
+            for (int k = 0; k < RB / 16; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)(off + 16u * k), 0, 0);
+          }
+          return;
+        }
         if constexpr (sizeof(CT) == 2 && G == 4) {
           const uint2 q2 = *reinterpret_cast<const uint2*>(hotq + 2 * t);
           c[0] = q2.x & 0xFFFFu; c[1] = q2.x >> 16; c[2] = q2.y & 0xFFFFu; c[3] = q2.y >> 16;
@@ -3083,6 +3107,45 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
       // wait before the fold is vmcnt(#block loads): the rows arrive first (vmcnt is in order) and the blocks travel during
       // the fold, the bound and the claim bookkeeping.
       auto walk = [&](bool prefetch) {
+        if constexpr (QM == 1) {
+          // positions beyond the PF * G the prefetch steps take are popped from the TOP of the mask first
+          const CT* mine_c = reinterpret_cast<const CT*>(hotq);
+          int cnt = (int)__popcll(hm);
+          rows32 += (uint32_t)cnt;
+          const int keep = prefetch ? PF * G : 0;
+          while (__ballot(cnt > keep) != 0ull) {
+            u32x4 v[G][RB / 16];
+            uint32_t c[G];
+            bool has[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              has[g] = cnt > keep;
+              const int p = has[g] ? 63 - (int)__builtin_clzll(hm | 1ull) : 0;
+              hm &= ~((has[g] ? 1ull : 0ull) << p);
+              cnt -= has[g] ? 1 : 0;
+              c[g] = (uint32_t)mine_c[p];
+            }
+            if constexpr (G == 4) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+            else asm volatile("" : "+v"(c[0]), "+v"(c[1]));
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const uint32_t off = (has[g] && !(probe & 1)) ? c[g] * (uint32_t)RB : 0x7FFFFF00u;
+#pragma unroll
+              for (int k = 0; k < RB / 16; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)(off + 16u * k), 0, 0);
+            }
+            fold(v);
+          }
+          if (prefetch) {
+            u32x4 v0[G][RB / 16], v1[PF == 2 ? G : 1][RB / 16];
+            issue(0, v0);
+            if constexpr (PF == 2) issue(G, v1);
+            stage(did_next);
+            fold(v0);
+            if constexpr (PF == 2) fold(v1);
+          }
+          hm = 0ull;
+          return;
+        }
         const int hmax = wave_max_nonneg(hq);
         for (int t = prefetch ? PF * G : 0; t < hmax; t += G) {
           u32x4 v[G][RB / 16];
@@ -3139,6 +3202,49 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
         CT* mine = const_cast<CT*>(rowc) + start;    // the lane's share: read CPI codes ahead, written back as the hot queue
         hotq = reinterpret_cast<const char*>(mine);
         uint4 w = *reinterpret_cast<const uint4*>(mine);
+        if constexpr (QM == 1) {
+          // position mask: the hot flags enter from the top (v_alignbit: acc = acc >> 1 | flag << 31, one instruction per
+          // code, only bit 0 of `flag` counts, so the bitmap word is just shifted right by the code); no LDS write at all
+          const int len = max(min(share, cnt - start), 0);
+          uint32_t mlo = 0, mhi = 0;
+          auto look = [&](const uint4& x, uint32_t& acc) {
+            const uint32_t ww[4] = {x.x, x.y, x.z, x.w};
+            if constexpr (sizeof(CT) == 2) {
+              uint32_t bl[4], bh[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                bl[k] = BITS((ww[k] >> 5) & 0x7FFu);
+                bh[k] = BITS(ww[k] >> 21);
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                acc = __builtin_amdgcn_alignbit(bl[k] >> (ww[k] & 31u), acc, 1);
+                acc = __builtin_amdgcn_alignbit(bh[k] >> ((ww[k] >> 16) & 31u), acc, 1);
+              }
+            } else {
+              uint32_t bw[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) bw[k] = BITS(ww[k] >> 5);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_alignbit(bw[k] >> (ww[k] & 31u), acc, 1);
+            }
+          };
+          const int n_lo = min(itmax, 32), n_hi = itmax - n_lo;
+          const int itm = (probe & 2) ? 0 : itmax;
+          for (int it = 0; it < min(itm, 32); it += CPI) {
+            const uint4 wn = *reinterpret_cast<const uint4*>(mine + min(it + CPI, fit - CPI - start));
+            look(w, mlo);
+            w = wn;
+          }
+          for (int it = 32; it < itm; it += CPI) {
+            const uint4 wn = *reinterpret_cast<const uint4*>(mine + min(it + CPI, fit - CPI - start));
+            look(w, mhi);
+            w = wn;
+          }
+          mlo = (n_lo && itm) ? mlo >> (32 - n_lo) : 0u;
+          mhi = (n_hi && itm) ? mhi >> (32 - n_hi) : 0u;
+          hm = (((unsigned long long)mhi << 32) | mlo) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
+        } else
         for (int it = 0; it < ((probe & 2) ? 0 : itmax); it += CPI) {
           const uint4 wn = *reinterpret_cast<const uint4*>(mine + min(it + CPI, fit - CPI - start));   // next step's codes, on their way
           if (it < len8) {

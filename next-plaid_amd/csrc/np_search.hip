@@ -841,18 +841,22 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     else if (RB == 128) NP_LAUNCH_HOT(128, CT); \
     else NP_LAUNCH_HOT(256, CT);                \
   } while (0)
-#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV)                                                                          \
+#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV, QMV)                                                                         \
   do {                                                                                                                   \
     const size_t bm = sizeof(CT) == 2 ? 0 : (size_t)(((KP >> 5) + 3) & ~(int64_t)3) * 4;   /* u16 codes: static bitmap */   \
-    const size_t dynp = bm + (size_t)4 * ((64 / LPDV) * ((size_t)ix->ublock_stride * sizeof(CT) + 16) + NP_HOTP_SLACK);      \
+    /* idle lanes of the last packed staging instruction write 16 B each past the rows it fills (1 KiB per instruction);     \
+       the one-block-per-instruction fallback overruns by at most 256 B */                                                  \
+    const size_t rowb = (size_t)ix->ublock_stride * sizeof(CT) + 16;                                                          \
+    const int slack = (int)std::max<int64_t>(256, 1024 - (int64_t)(DPIV) * (int64_t)rowb);                                   \
+    const size_t dynp = bm + (size_t)4 * ((64 / LPDV) * rowb + (size_t)slack);                                               \
     if (dynp > 16 * 1024)                                                                                                \
-      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV>),           \
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV>),           \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynp));                                \
-    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV><<<8 * pnbx, 256, dynp, st>>>(                                           \
+    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV><<<8 * pnbx, 256, dynp, st>>>(                                           \
         w.planes.as<uint32_t>(), ix->K, KP, w.hotbits.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.levels.as<uint32_t>(), \
         w.cand.as<uint32_t>(), w.cand_meta.as<uint4>(), ix->ublock_stride, (int64_t)ix->n_docs * ix->ublock_stride,        \
         w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), d_qoff, cs->n_sel,     \
-        w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift, sl, sl + 8 * (B + 1), B, w.ctr.as<Counters>(),              \
+        w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift, sl, sl + 8 * (B + 1), B, w.ctr.as<Counters>(), slack,       \
         ix->tune.s4_probe);                                                                                            \
   } while (0)
   // lanes per document: 2 (32 documents per claim; blocks of at most 256 bytes) or 4 (16 per claim: half the LDS rows per
@@ -862,11 +866,12 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   do {                                                                  \
     const int sb = ix->ublock_stride * (int)sizeof(CT);                 \
     if (plpd == 2) {                                                    \
-      if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4);                 \
-      else NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 2);                           \
-    } else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 4);            \
-    else if (sb <= 496) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 2);              \
-    else NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 1);                             \
+      if (sb <= 240 && ix->tune.s4_qm) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 1);   \
+      else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 0);         \
+      else NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 2, 0);                        \
+    } else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 4, 0);         \
+    else if (sb <= 496) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 2, 0);           \
+    else NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 1, 0);                          \
   } while (0)
           const int plpd = (ix->ublock_stride > old_cap || ix->tune.s4_lpd == 4) ? 4 : 2;
           const unsigned pnbx = (unsigned)ix->tune.s4_pnbx;   // workgroups per XCD of the plane kernel

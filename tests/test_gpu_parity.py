@@ -314,7 +314,8 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         for hot, planes in ((0, 1), (10, 1), (100, 1), (300, 1), (500, 1), (10, 0), (100, 0), (300, 0)):
             hx.tune("s4_hot", hot)
             hx.tune("s4_planes", planes)
-            hx.tune("s4_lpd", 2 if hot in (10, 500) else 4)      # plane kernel: claims of 32 documents (2 lanes each) or 16 (4 lanes)
+            hx.tune("s4_lpd", 2 if hot in (10, 100, 500) else 4) # plane kernel: claims of 32 documents (2 lanes each) or 16 (4 lanes)
+            hx.tune("s4_qm", 0 if hot == 500 else 1)             # ... hot codes as a position mask or compacted in place
             hx.tune("ub_direct", 0 if hot == 300 else 8)   # short-list launch: per-XCD hand-out or one group of workgroups per query
             hx.tune("ub_static", 1 if hot in (10, 500) else 0)   # claims from a cursor (with stealing) or round-robin
             hx.tune("hot_static", 0 if hot in (10, 300) else 1)
