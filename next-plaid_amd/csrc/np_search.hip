@@ -796,7 +796,9 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       };
       const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
       // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
-      const int slack = LQP + 2 + (batched ? 1 : 0);
+      // (per query the bracket is Lq + 2 with its OWN token count: padding tokens contribute exactly 0 to both sides, so the
+      // slice's longest query bounds it -- 48-token queries in 64-token rows keep 50, not 66)
+      const int slack = maxLq + 2 + (batched ? 1 : 0);
       CutP cp{};
       cp.hshift = hshift;
       cp.all_src = w.cand_meta.as<uint4>();
