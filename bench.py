@@ -393,7 +393,11 @@ def main():
         try:
             tj = json.load(open(tpath))
             # counters belong to one workload AND one build of the kernels: never carried over to another
-            if tj.get("docs_per_gpu") == docs_local and tj.get("kernels_sha") == kernels_sha():
+            default_workload = (a.rand256 == 51 and a.centroids == 65536 and a.nbits == 4 and a.nprobe == 32 and a.batch == 64 and
+                                a.query_tokens == 32 and a.n_full_scores == 4096 and a.threshold == 0.4 and a.precision == 2 and
+                                a.hot < 0 and a.doc_len == 300 and a.doc_len_min == 0 and a.len_dist == "uniform" and not s1_split and
+                                not any(k.startswith("NP_S") for k in os.environ))
+            if default_workload and tj.get("docs_per_gpu") == docs_local and tj.get("kernels_sha") == kernels_sha():
                 traffic = tj.get(dom)
                 traffic_src = {"commit": tj.get("commit"), "kernels_sha": tj.get("kernels_sha")}
         except Exception:

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Installs the evidence of a final GPU call under profiles/ and regenerates the measured tables of DESIGN.md
-(between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r03_*.
+(between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r04_*.
 
-  design_tables.py install <gpurun_out tag> [--merge]   copy gpurun_out/<tag>/... to profiles/r03_* (names below); --merge keeps
+  design_tables.py install <gpurun_out tag> [--merge]   copy gpurun_out/<tag>/... to profiles/r04_* (names below); --merge keeps
                                                 the committed lines the call did not re-measure
-  design_tables.py                              regenerate the tables from profiles/r03_*
+  design_tables.py                              regenerate the tables from profiles/r04_*
 """
 import json
 import os
@@ -14,14 +14,15 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 P = os.path.join(ROOT, "profiles") + "/"
-R = "r03"
+R = "r04"
 
 GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
-    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m", "hot50", "hot200", "hot300"],
-    f"{R}_bench_regimes.jsonl": ["dist05", "dist08", "dist08_single", "lq48_10m", "lq48_1m", "nfs8192_10m", "k19_10m", "c3_np32", "c3_np8"],
+    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m", "planes0_10m"],
+    f"{R}_bench_regimes.jsonl": ["dist05", "dist08", "lq48_10m", "lq48_1m", "nfs8192_10m", "k19_10m", "k19_split_10m", "c3_np32", "c3_np8"],
 }
-SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k"}
+SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k",
+           f"{R}_bench_disk_1m.json": "disk1m"}
 
 
 def install(tag, merge=False):
@@ -30,7 +31,11 @@ def install(tag, merge=False):
     for dst, name in SINGLES.items():
         if merge and not os.path.exists(os.path.join(src, f"b_{name}.json")):
             continue
-        shutil.copy(os.path.join(src, f"b_{name}.json"), P + dst)
+        d = json.load(open(os.path.join(src, f"b_{name}.json")))
+        if name != "default_10m" and d.get("roofline", {}).get("traffic") is not None:
+            d["roofline"]["traffic"] = d["roofline"]["traffic_source"] = d["roofline"]["frac_physical"] = None
+        json.dump(d, open(P + dst, "w"))
+        open(P + dst, "a").write("\n")
     for dst, names in GROUPS.items():
         old = {}
         if merge and os.path.exists(P + dst):
@@ -47,6 +52,9 @@ def install(tag, merge=False):
                 d = json.load(open(p))
                 d["name"] = n
                 d["evidence_call"] = tag
+                # the PMC traffic figure belongs to the DEFAULT workload only (bench.py now checks that itself)
+                if d.get("roofline", {}).get("traffic") is not None:
+                    d["roofline"]["traffic"] = d["roofline"]["traffic_source"] = d["roofline"]["frac_physical"] = None
                 f.write(json.dumps(d) + "\n")
     for a, b in (("stats_d10m.md", f"{R}_kernel_stats_10m.md"), ("stats_d10m.csv", f"{R}_kernel_stats_10m.csv"),
                  ("stats_d1m.md", f"{R}_kernel_stats_1m.md"), ("stats_d1m.csv", f"{R}_kernel_stats_1m.csv"),
@@ -97,9 +105,10 @@ def tables():
               f"{d1['index_build_s']:.2f} s (1 M); {d10['hbm_bytes_per_token']:.1f} B per token. CPU baseline (oracle C restatement, {cb10['cores']} threads, "
               f"{cb10['cpu_model']}): {cb10['value']:.1f} queries/s at 10 M, {cb1['value']:.1f} at 1 M. `roofline.traffic` (PMC, 10 M): "
               f"S4 {tr['approx(S4)']/1e9:.2f} GB, S6 {tr['exact(S6)']/1e9:.2f} GB, S3 {tr['candidates(S3)']/1e9:.2f} GB per batch.", "",
-          f"Round 2 → round 3: 10 M documents 10.9 k → {d10['value']/1e3:.1f} k queries/s (p50 6.21 → {d10['p50_batch_latency_ms']:.2f} ms, S4 4.54 → "
-          f"{s10['ms_approx']:.2f} ms, index 231 → {d10['hbm_index_bytes']/1e9:.0f} GB); 1 M documents 37.0 k → {d1['value']/1e3:.1f} k queries/s "
-          f"(S4 0.72 → {s1['ms_approx']:.2f} ms)."]
+          f"Round 3 → round 4: 10 M documents 17.3 k → {d10['value']/1e3:.1f} k queries/s (p50 4.16 → {d10['p50_batch_latency_ms']:.2f} ms, S4 2.64 → "
+          f"{s10['ms_approx']:.2f} ms); 1 M documents 36.9 k → {d1['value']/1e3:.1f} k queries/s (S4 0.77 → {s1['ms_approx']:.2f} ms).  "
+          f"The bench line's `roofline.frac` prices the contract's algorithmic bytes ({d10['roofline']['frac']:.2f} for S4); the bytes the stage "
+          f"really moved (PMC) give `roofline.frac_physical` = {d10['roofline'].get('frac_physical')}."]
     measured = "\n".join(t)
 
     reg = lines(f"{R}_bench_regimes.jsonl")
@@ -109,13 +118,14 @@ def tables():
         pv = d.get("parity_vs_oracle")
         return "—" if not pv else f"{pv['topk_ids_identical']}/{pv['queries']}"
 
-    dist = ["| distinct codes per token (`--rand256`) | candidates / query | u8 rows / batch | queries/s | S3 ms | S4 ms | top-10 = oracle |", "|---|---:|---:|---:|---:|---:|---:|"]
-    for lab, d in (("0.23 (51, the default corpus)", d10), ("0.50 (121)", reg.get("dist05")), ("0.80 (200)", reg.get("dist08")),
-                   ("0.80, single-level filter (`NP_S4_HOT=0`)", reg.get("dist08_single"))):
+    dist = ["| distinct codes per token (`--rand256`) | candidates / query | table rows / batch | queries/s | S3 ms | S4 ms | CPU oracle q/s | top-10 = oracle |", "|---|---:|---:|---:|---:|---:|---:|---:|"]
+    for lab, d in (("0.23 (51, the default corpus)", d10), ("0.50 (121)", reg.get("dist05")), ("0.80 (200)", reg.get("dist08"))):
         if not d:
             continue
         s = d["stages"]
-        dist.append(f"| {lab} | {s['n_candidates']/64/1e3:.0f} k | {s['n_cand_codes']/1e6:.0f} M | {d['value']:.0f} | {s['ms_candidates']:.2f} | {s['ms_approx']:.2f} | {par(d)} |")
+        cpu = (d.get("cpu_baseline") or {}).get("value")
+        dist.append(f"| {lab} | {s['n_candidates']/64/1e3:.0f} k | {s['n_cand_codes']/1e6:.0f} M | {d['value']:.0f} | {s['ms_candidates']:.2f} | {s['ms_approx']:.2f} | "
+                    f"{'—' if not cpu else f'{cpu:.1f}'} | {par(d)} |")
     dist = "\n".join(dist)
 
     rg = ["| line (10 M docs × 300 tok unless stated) | queries/s | p50 ms | S1 | S2 | S3 | S4 | S5 | S6 | CPU oracle q/s | top-10 = oracle |",
@@ -123,7 +133,8 @@ def tables():
     labs = [("lq48_10m", "48-token queries (ONNX encoder default, `next-plaid-onnx/src/lib.rs:628-630`)"),
             ("lq48_1m", "48-token queries, 1 M docs"),
             ("nfs8192_10m", "`n_full_scores = 8192` (ColGREP, `colgrep/src/index/mod.rs:771-777`)"),
-            ("k19_10m", "K = 2¹⁹ (the crate's k-means heuristic at this size, `kmeans.rs:303-309`): batched path"),
+            ("k19_10m", "K = 2¹⁹ (the crate's k-means heuristic at this size, `kmeans.rs:303-309`): batched path, bit-exact S1-S5"),
+            ("k19_split_10m", "K = 2¹⁹ with the opt-in split-bf16 S1 (`s1_split`, no mat-vec re-scoring)"),
             ("c3_np32", "config 3 shape: 8 841 823 docs, clipped LogNormal lengths (mean 73, max 180), K = 2¹⁸, nbits 2, nprobe 32"),
             ("c3_np8", "config 3 shape, nprobe 8")]
     for k, lab in labs:
@@ -136,12 +147,20 @@ def tables():
     cpu = (c4.get("cpu_baseline") or {}).get("value")
     rg.append(f"| config 4's shard: 12.5 M docs on one GPU ({c4['hbm_index_bytes']/1e9:.1f} GB, {c4['hbm_bytes_per_token']:.1f} B/token) | {c4['value']:.0f} | "
               f"{c4['p50_batch_latency_ms']:.2f} | {stage_cells(c4['stages'])} | {'—' if not cpu else f'{cpu:.1f}'} | {par(c4)} |")
+    dk = load(f"{R}_bench_disk_1m.json")
+    do = dk["disk_open"]
+    cpu = (dk.get("cpu_baseline") or {}).get("value")
+    rg.append(f"| 1 M docs opened from its index DIRECTORY ({do['bytes']/1e9:.1f} GB in {do['files']} files: open {do['open_warm_s']:.2f} s warm = "
+              f"{do['open_warm_gbs']:.0f} GB/s, {do['open_cold_s']} s cold) | {dk['value']:.0f} | {dk['p50_batch_latency_ms']:.2f} | {stage_cells(dk['stages'])} | "
+              f"{'—' if not cpu else f'{cpu:.1f}'} | {par(dk)} |")
     rg = "\n".join(rg)
 
     c5 = ["| 10 M docs, B = 64 | queries/s | p50 ms | S4 ms | S6 ms | max rel. score error vs oracle | top-10 ids identical |", "|---|---:|---:|---:|---:|---:|---:|"]
     for lab, d in (("precision 2 (default; split-bf16 QC-reuse)", d10), ("precision 0 (exact-f32 MFMA everywhere)", var.get("prec0")),
                    ("precision 1 (bf16 QC-reuse)", var.get("prec1")), ("precision 3 (plain bf16 MaxSim)", var.get("prec3")),
-                   ("precision 2, single-level filter (`NP_S4_HOT=0`)", var.get("single_level_10m")), ("precision 2, t_cs = None", var.get("tcs_none"))):
+                   ("precision 2, single-level filter (`NP_S4_HOT=0`)", var.get("single_level_10m")),
+                   ("precision 2, round-3 first level (byte maxima, `NP_S4_PLANES=0`)", var.get("planes0_10m")),
+                   ("precision 2, t_cs = None", var.get("tcs_none"))):
         if not d:
             continue
         pv = d["parity_vs_oracle"]
@@ -158,10 +177,10 @@ def tables():
     st += ["", "(Single-GPU runs of a corpus of that size: S6 is the full `n_sel` here, whereas a rank of the real split exact-scores only its share of the global cut.)"]
     st = "\n".join(st)
 
-    hs = ["| S4 filter, 10 M documents | u8 table rows gathered / batch | documents at the exact level | S4 ms | queries/s |", "|---|---:|---:|---:|---:|"]
-    for lab, d in (("single level (the round-2 kernel on the round-3 layout, `NP_S4_HOT=0`)", var.get("single_level_10m")),
-                   ("two levels, 5 % hot", var.get("hot50")), ("two levels, 10 % hot (default)", d10), ("two levels, 20 % hot", var.get("hot200")),
-                   ("two levels, 30 % hot", var.get("hot300"))):
+    hs = ["| S4 filter, 10 M documents | table rows gathered / batch | documents at the exact level | S4 ms | queries/s |", "|---|---:|---:|---:|---:|"]
+    for lab, d in (("single level (exact u8 bound of every candidate, `NP_S4_HOT=0`)", var.get("single_level_10m")),
+                   ("two levels, first level as byte maxima (round 3, `NP_S4_PLANES=0`)", var.get("planes0_10m")),
+                   ("two levels, first level in bit planes (default)", d10)):
         if d:
             x = d["stages"]
             hs.append(f"| {lab} | {x['n_cand_codes']/1e6:.0f} M | {(x['n_level2'] or x['n_candidates'])/1e6:.2f} M | {x['ms_approx']:.2f} | {d['value']:.0f} |")
