@@ -2770,17 +2770,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
 // next to Lambda (geometric, quantiles of the values) are far worse (profiles/r04_sim_s4_planes*_10m.txt).
 // hotbits[b][w] bit i = (M[32 w + i] > Lambda): the filter's workgroups copy it into LDS instead of each rebuilding it from
 // the 64 KB of per-centroid maxima.  One block per query.
-__global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restrict__ chist, const uint32_t* __restrict__ lam_b,
+__global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restrict__ chist, int64_t K, int hot_permille,
                                                          const uint8_t* __restrict__ cmaxu, int64_t KP, int pexp10,
-                                                         uint32_t* __restrict__ lev, uint32_t* __restrict__ hotbits) {
-  __shared__ int s_top;
+                                                         uint32_t* __restrict__ lam_out, uint32_t* __restrict__ lev,
+                                                         uint32_t* __restrict__ hotbits) {
+  // grid (blocks, B): every block derives Lambda from the 256-bin histogram itself (as hot_lam_kernel: the smallest level
+  // with at most hot_permille of the centroids above it) and builds its slice of the bitmap; block 0 publishes Lambda and
+  // the thresholds.  (One block per query took 37 us at K = 2^16, serial in the 64 KB of maxima.)
+  __shared__ uint32_t s_wsum[4];
+  __shared__ int s_ok, s_top;
   __shared__ int s_t[NP_PLANES + 1];
-  const int b = blockIdx.x, v = threadIdx.x;
-  if (v == 0) s_top = 0;
+  const int b = blockIdx.y, v = threadIdx.x, lane = v & 63, wave = v >> 6;
+  if (v == 0) {
+    s_ok = 0;
+    s_top = 0;
+  }
+  const uint32_t hv = chist[(int64_t)b * 256 + v];
+  uint32_t suf = hv;   // -> #(M >= v): suffix sum over the block
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_down((int)suf, o);
+    if (lane + o < 64) suf += t;
+  }
+  if (lane == 0) s_wsum[wave] = suf;
   __syncthreads();
-  if (chist[(int64_t)b * 256 + v]) atomicMax(&s_top, v);
+  for (int k = wave + 1; k < 4; ++k) suf += s_wsum[k];
+  const uint64_t limit = (uint64_t)K * (uint64_t)hot_permille / 1000u;
+  const bool ok = v >= 1 && (uint64_t)suf <= limit;
+  const int cnt = (int)__popcll(__ballot(ok));
+  if (lane == 0 && cnt) atomicAdd(&s_ok, cnt);
+  if (hv) atomicMax(&s_top, v);
   __syncthreads();
-  const int lam = (int)lam_b[b];
+  const int lam = 255 - s_ok;
   if (v <= NP_PLANES) {
     const int top = max(s_top, lam + 1), span = top - lam;
     const float w = __powf((float)v / (float)NP_PLANES, 0.1f * (float)pexp10);
@@ -2789,13 +2810,16 @@ __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restr
     s_t[v] = t;
   }
   __syncthreads();
-  if (v < NP_PLANES) {
-    const int t0 = s_t[v], t1 = max(s_t[v + 1], t0);
-    lev[b * 16 + v] = (uint32_t)t0;
-    lev[b * 16 + 8 + v] = (uint32_t)(t1 - t0);
+  if (blockIdx.x == 0) {
+    if (v == 0) lam_out[b] = (uint32_t)lam;
+    if (v < NP_PLANES) {
+      const int t0 = s_t[v], t1 = max(s_t[v + 1], t0);
+      lev[b * 16 + v] = (uint32_t)t0;
+      lev[b * 16 + 8 + v] = (uint32_t)(t1 - t0);
+    }
   }
   const uint8_t* cm = cmaxu + (int64_t)b * KP;
-  for (int64_t w = v; w < (KP >> 5); w += 256) {
+  for (int64_t w = (int64_t)blockIdx.x * 256 + v; w < (KP >> 5); w += (int64_t)gridDim.x * 256) {
     const uint4 v0 = *reinterpret_cast<const uint4*>(cm + w * 32), v1 = *reinterpret_cast<const uint4*>(cm + w * 32 + 16);
     const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     uint32_t bits = 0;

@@ -619,10 +619,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   if (two_level) {   // per-centroid maxima of the u8 table, their histogram, the hot level's Lambda
     hot_prep_kernel<<<dim3((unsigned)std::min<int64_t>((KP + 255) / 256, 64), B), 256, 0, st>>>(
         w.QCU.as<uint8_t>(), ix->K, KP, RB, w.cmaxu.as<uint8_t>(), w.chist.as<uint32_t>());
-    hot_lam_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.ub_thr2.as<uint32_t>() + B);
-    if (use_planes) {   // thresholds of the 8 planes, then the plane rows of the hot centroids
-      hot_levels_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.cmaxu.as<uint8_t>(), KP,
-                                           ix->tune.s4_pexp, w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>());
+    if (!use_planes) hot_lam_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.ub_thr2.as<uint32_t>() + B);
+    if (use_planes) {   // Lambda, the thresholds of the 8 planes and the hot bitmap in one launch, then the plane rows of the hot centroids
+      hot_levels_kernel<<<dim3((unsigned)std::min<int64_t>(std::max<int64_t>((KP >> 5) / 256, 1), 16), B), 256, 0, st>>>(
+          w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.cmaxu.as<uint8_t>(), KP, ix->tune.s4_pexp, w.ub_thr2.as<uint32_t>() + B,
+          w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>());
       const dim3 pg((unsigned)std::min<int64_t>((KP + 2047) / 2048, 64), B);
       if (RB == 32)
         hot_planes_kernel<32><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,

@@ -85,14 +85,16 @@ def main():
 
             def report(name, B):
                 assert (B >= U).all()
-                thr1 = np.sort(B)[-n_sel]
-                S1 = B >= thr1
-                tau = np.sort(U[S1])[-n_sel] - (LQ + 2)
-                S2 = B >= tau
-                S3 = S2 & (U >= np.sort(U[S2])[-n_sel] - (LQ + 2))
-                miss = int(((U >= thrU) & ~S3).sum())
-                print(f"   f={f:.2f} lam={lam} {name:28s} slack mean {np.mean(B - U):6.1f} |S1| {int(S1.sum()):5d} |S2| {int(S2.sum()):6d} "
-                      f"|S3| {int(S3.sum())} missed {miss}", flush=True)
+                for mult in [int(x) for x in os.environ.get("SIM_S1MULT", "1").split(",")]:
+                    # S1 = the mult * n_sel documents with the largest bound: a larger sample of exact bounds lifts tau
+                    thr1 = np.sort(B)[-min(mult * n_sel, n)]
+                    S1 = B >= thr1
+                    tau = np.sort(U[S1])[-n_sel] - (LQ + 2)
+                    S2 = B >= tau
+                    S3 = S2 & (U >= np.sort(U[S2])[-n_sel] - (LQ + 2))
+                    miss = int(((U >= thrU) & ~S3).sum())
+                    print(f"   f={f:.2f} lam={lam} {name:28s} S1x{mult} slack mean {np.mean(B - U):6.1f} |S1| {int(S1.sum()):5d} |S2| {int(S2.sum()):6d} "
+                          f"|S3| {int(S3.sum())} missed {miss}", flush=True)
             report("exact hot bound U'", hm.sum(axis=1).astype(np.int64))
             kinds = os.environ.get("SIM_KINDS", "uniform:8,geo:8,quant:8,uniform:16,geo:16,quant:16,quant:4")
             for kind, P in [(k.split(":")[0], int(k.split(":")[1])) for k in kinds.split(",")]:
