@@ -124,10 +124,11 @@ struct Tuning {
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
-  int s4_hot = 100;      // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level
-                         // filter).  More hot centroids: fewer documents left to the exact bound (S1 + S2: 2.66 M / 1.19 M of 11.9 M
-                         // at 100 / 200) but more table rows and walk steps per document in the hot kernel, which is VALU-bound:
-                         // 40 / 100 / 200 / 300 -> S4 4.02 / 2.73 / 2.92 / 3.00 ms at 10 M documents
+  int s4_hot = 60;       // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level
+                         // filter).  More hot centroids: fewer documents left to the exact bound (S1 + S2: 2.79 M / 2.20 M / 1.81 M of
+                         // 11.9 M at 60 / 100 / 150) but more plane rows and walk steps per document in the hot kernel.  With the
+                         // floored exact level (s4_warm) behind it, 10 M documents: 40 / 60 / 80 / 100 / 150 -> 18.3 / 18.6 / 18.4 /
+                         // 17.8 / 16.6 k queries/s (round 3, byte maxima and every row at the exact level: 100 was best)
   int s4_planes = 1;     // first filter level in bit-plane form (approx_hotp_kernel: 8 planes per hot centroid, OR + weighted popcount
                          // instead of 32 byte maxima per table row); 0 = approx_hot_kernel.  Read at OPEN too: with it the list blocks
                          // may be up to 512 bytes (corpora with long distinct-code lists), which approx_hot_kernel cannot stage
@@ -136,6 +137,8 @@ struct Tuning {
   int s4_pnbx = 96;      // ... workgroups per XCD (3 per CU at 42 KB of LDS each with 2 lanes per document; 160 = 5 per CU with 4)
   int s4_qm = 1;         // ... a lane's hot codes as a position mask in registers (1) or compacted in place by LDS writes (0)
   int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
+  int s4_warm = 500;     // ... per-mille of the centroids whose rows the exact level still gathers for the S2 list (the rest: floored
+                         // at Lambda2; approx_ub_kernel FLOOR); 1000 = every row
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim
                          // on a line all XCDs share costs ~50 ns, serialised): 2.06 -> 1.68 ms at 10 M documents

@@ -1925,7 +1925,13 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 // MODE 2: the table is read through a buffer descriptor and positions past a document's list carry an out-of-range
 //         offset: the bounds check returns zeros (u >= 1, so 0 is the identity of the max) WITHOUT a memory request, so
 //         the padding of the lockstep walk costs no L2 request slot.
-template <int ROWB, typename CT, int MODE>
+// FLOOR (MODE 2, u16 codes): the rows of the centroids outside `warmbits` (M[c] <= Lambda2: no query token is close to
+// them) are not requested, and every real token's maximum is floored at Lambda2:
+//     up(d) = sum_q max(Lambda2, max_{c kept} u[q, c]) >= U(d) >= lo(d) = sum_q max_{c kept} u[q, c].
+// U[] receives `up` (the cut keeps a document on its UPPER bound) and the histogram counts `lo` (the cut's threshold may
+// only rest on LOWER bounds of the n_sel-th largest U): the selection stays exact, for about half the row requests on the
+// metric corpus and ~1.3x the survivors (tools/sim/s4_warm_sim.py, profiles/r04_sim_s4_warm_10m.txt).
+template <int ROWB, typename CT, int MODE, int FLOOR = 0>
 __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
                                                         const uint4* __restrict__ cand_meta /* records of the list to score */,
                                                         const int32_t* __restrict__ n_begin /* [B] first record (NULL = 0) */,
@@ -1944,7 +1950,11 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         int direct_wpq /* > 0: no hand-out, workgroups [j * wpq, (j+1) * wpq) take the
                                                                           round's j-th query (short lists: every query at once) */,
                                                         int static_claims /* waves take the claims round-robin, no cursor atomic (see
-                                                                             approx_hot_kernel); queries are never shared between XCDs */) {
+                                                                             approx_hot_kernel); queries are never shared between XCDs */,
+                                                        const uint32_t* __restrict__ warmbits = nullptr /* FLOOR: [B][KP / 32] */,
+                                                        const uint32_t* __restrict__ lam2_b = nullptr /* FLOOR: [B] Lambda2 */,
+                                                        const int32_t* __restrict__ qoff = nullptr /* FLOOR: token offsets (Lq) */) {
+  static_assert(FLOOR == 0 || (MODE == 2 && sizeof(CT) == 2 && ROWB <= 64), "the floored level: bounds-checked loads, u16 codes");
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
   constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // distinct codes of one document staged per pass (32 KB of LDS per
@@ -1958,6 +1968,8 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   // 30 M L2 misses and 8x over-fetch per launch.)
   __shared__ uint32_t s_hist[NP_UB_BINS];
   __shared__ CT s_codes[4][DPW][CAP];
+  __shared__ uint32_t s_warm[FLOOR ? 2048 : 4];   // FLOOR: the query's kept-centroid bitmap (K <= 65536)
+  __shared__ int s_ndk[4][FLOOR ? DPW : 1];        // FLOOR: kept codes of each document in the staged window
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2017,6 +2029,14 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
     __syncthreads();
     if (hb)
       for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
+    uint32_t lam2 = 0;
+    int Lq = 0;
+    if constexpr (FLOOR) {
+      const uint32_t* wb = warmbits + (int64_t)b * (KP >> 5);
+      for (int i = tid; i < 2048; i += 256) s_warm[i] = i < (int)(KP >> 5) ? wb[i] : 0u;
+      lam2 = lam2_b[b];
+      Lq = qoff[b + 1] - qoff[b];
+    }
     __syncthreads();
     // static_claims: wave g of the NWS waves working on this query takes claims g, g + NWS, ... (no cursor atomic)
     const int64_t NWS = direct_wpq > 0 ? (int64_t)direct_wpq * 4 : (int64_t)(gridDim.x >> 3) * 4;
@@ -2095,6 +2115,26 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
           for (int j = 0; j < SB; ++j) {
             const int sl = 2 * (sb + j) + half;
             const int pos = p0 + CPS * hl;   // the position this LDS slot stands for (the load above may have been clamped)
+            if constexpr (FLOOR) {
+              // keep only the codes of centroids in the query's bitmap, compacted per document (order is irrelevant to a
+              // max): one ballot per code slot, the half-wave of the document counts its own 32 bits
+              uint32_t wv[CPS];
+#pragma unroll
+              for (int k = 0; k < CPS; ++k) wv[k] = s_warm[(cv[j][k] >> 5) & 0x7FFu];
+              int base = 0;
+              CT* dstc = &s_codes[wave][sl][0];
+#pragma unroll
+              for (int k = 0; k < CPS; ++k) {
+                const bool kp = pos + k < nds[j] && ((wv[k] >> (cv[j][k] & 31u)) & 1u) != 0u;
+                const unsigned long long bal = __ballot(kp);
+                const uint32_t hm = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                if (kp) dstc[base + (int)__popc(hm & ((1u << hl) - 1u))] = (CT)cv[j][k];
+                base += (int)__popc(hm);
+              }
+              if (hl == 0) s_ndk[wave][sl] = base;
+              __builtin_amdgcn_sched_barrier(0);   // one document pair at a time: hoisting every lookup and ballot spills
+              continue;
+            }
 #pragma unroll
             for (int k = 0; k < CPS; ++k)
               if (pos + k >= nds[j]) cv[j][k] = c0[j];
@@ -2112,7 +2152,15 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         // batch B's rows are on their way (a wave alone waits ~3 us for a batch at this occupancy).  Documents are
         // walked in lockstep from position 0 of their SORTED lists, so the rows a wave wants at the same time sit
         // in a narrow band of the table (measured: starting every document at a different position costs 5 %).
-        const int np = (min(CAP, nmax - p0) + 7) & ~7;
+        int np = (min(CAP, nmax - p0) + 7) & ~7;
+        int ndk = 0;
+        if constexpr (FLOOR) {
+          ndk = s_ndk[wave][grp];
+          int km = ndk;
+#pragma unroll
+          for (int o = LPD; o < 64; o <<= 1) km = max(km, __shfl_xor(km, o));
+          np = (__builtin_amdgcn_readfirstlane(km) + 7) & ~7;
+        }
         const CT* mine = &s_codes[wave][grp][0];
         auto issue = [&](int t, uint4 (&v)[8]) {
           uint32_t c[8];
@@ -2129,7 +2177,9 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const uint32_t off = (p0 + t + k < nd) ? c[k] * (uint32_t)ROWB + (uint32_t)(jl * 16) : 0x7FFFFFF0u;
+              // FLOOR: the staged window holds only the ndk KEPT codes of this pass, compacted
+              const bool live = FLOOR ? (t + k < ndk) : (p0 + t + k < nd);
+              const uint32_t off = live ? c[k] * (uint32_t)ROWB + (uint32_t)(jl * 16) : 0x7FFFFFF0u;
               const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(trs, (int)off, 0, 0);
               v[k] = make_uint4(r.x, r.y, r.z, r.w);
             }
@@ -2166,14 +2216,30 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
           fold(va);
         }
       }
-      uint32_t sum = 0;
+      uint32_t sum = 0, sum_lo = 0;
+      if constexpr (FLOOR) {
+        // byte k of lane jl is query token 16 jl + k; padding tokens (>= Lq) hold 0 in every row and stay 0.  (The floor is
+        // fenced: left visible, its 16 per-byte values are hoisted out of the claim loop and live across the walk.)
+        uint32_t fl = lam2;
+        int lq_here = Lq - 16 * jl;
+        asm volatile("" : "+v"(fl), "+v"(lq_here));
 #pragma unroll
-      for (int k = 0; k < 16; ++k) sum += st[k];
+        for (int k = 0; k < 16; ++k) {
+          sum_lo += st[k];
+          sum += max(st[k], k < lq_here ? fl : 0u);
+        }
+#pragma unroll
+        for (int o = 1; o < LPD; o <<= 1) sum_lo += (uint32_t)__shfl_xor((int)sum_lo, o);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += st[k];
+      }
 #pragma unroll
       for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
+      if constexpr (!FLOOR) sum_lo = sum;
       if (valid && jl == 0) {
         U[pbase + i] = (uint16_t)sum;
-        if (hb) atomicAdd(&s_hist[min(sum >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
+        if (hb) atomicAdd(&s_hist[min(sum_lo >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
       }
       __builtin_amdgcn_wave_barrier();   // s_cl / s_nd of this group are rewritten by the next one
     }
@@ -2773,7 +2839,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) a
 __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restrict__ chist, int64_t K, int hot_permille,
                                                          const uint8_t* __restrict__ cmaxu, int64_t KP, int pexp10,
                                                          uint32_t* __restrict__ lam_out, uint32_t* __restrict__ lev,
-                                                         uint32_t* __restrict__ hotbits) {
+                                                         uint32_t* __restrict__ hotbits,
+                                                         int warm_permille /* >= 1000: no second threshold */,
+                                                         uint32_t* __restrict__ lam2_out /* [B] Lambda2 (floor of the exact level) */,
+                                                         uint32_t* __restrict__ warmbits /* [B][KP / 32] bit c = M[c] > Lambda2 */) {
   // grid (blocks, B): every block derives Lambda from the 256-bin histogram itself (as hot_lam_kernel: the smallest level
   // with at most hot_permille of the centroids above it) and builds its slice of the bitmap; block 0 publishes Lambda and
   // the thresholds.  (One block per query took 37 us at K = 2^16, serial in the 64 KB of maxima.)
@@ -2800,8 +2869,20 @@ __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restr
   const int cnt = (int)__popcll(__ballot(ok));
   if (lane == 0 && cnt) atomicAdd(&s_ok, cnt);
   if (hv) atomicMax(&s_top, v);
+  // Lambda2 <= Lambda by the same rule at the (larger) warm share: the exact level skips the rows of the centroids with
+  // M <= Lambda2 and floors every token's maximum there (approx_ub_kernel, FLOOR)
+  __shared__ int s_ok2;
+  if (v == 0) s_ok2 = 0;
+  __syncthreads();
+  const bool warm_on = warm_permille < 1000 && warmbits != nullptr;
+  if (warm_on) {
+    const uint64_t limit2 = (uint64_t)K * (uint64_t)max(warm_permille, hot_permille) / 1000u;
+    const int cnt2 = (int)__popcll(__ballot(v >= 1 && (uint64_t)suf <= limit2));
+    if (lane == 0 && cnt2) atomicAdd(&s_ok2, cnt2);
+  }
   __syncthreads();
   const int lam = 255 - s_ok;
+  const int lam2 = 255 - s_ok2;
   if (v <= NP_PLANES) {
     const int top = max(s_top, lam + 1), span = top - lam;
     const float w = __powf((float)v / (float)NP_PLANES, 0.1f * (float)pexp10);
@@ -2812,6 +2893,7 @@ __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restr
   __syncthreads();
   if (blockIdx.x == 0) {
     if (v == 0) lam_out[b] = (uint32_t)lam;
+    if (v == 0 && warm_on) lam2_out[b] = (uint32_t)lam2;
     if (v < NP_PLANES) {
       const int t0 = s_t[v], t1 = max(s_t[v + 1], t0);
       lev[b * 16 + v] = (uint32_t)t0;
@@ -2822,12 +2904,17 @@ __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restr
   for (int64_t w = (int64_t)blockIdx.x * 256 + v; w < (KP >> 5); w += (int64_t)gridDim.x * 256) {
     const uint4 v0 = *reinterpret_cast<const uint4*>(cm + w * 32), v1 = *reinterpret_cast<const uint4*>(cm + w * 32 + 16);
     const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    uint32_t bits = 0;
+    uint32_t bits = 0, bits2 = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bits |= (((w8[e] >> (8 * k)) & 0xFFu) > (uint32_t)lam ? 1u : 0u) << (4 * e + k);
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t m = (w8[e] >> (8 * k)) & 0xFFu;
+        bits |= (m > (uint32_t)lam ? 1u : 0u) << (4 * e + k);
+        bits2 |= (m > (uint32_t)lam2 ? 1u : 0u) << (4 * e + k);
+      }
     hotbits[(int64_t)b * (KP >> 5) + w] = bits;
+    if (warm_on) warmbits[(int64_t)b * (KP >> 5) + w] = bits2;
   }
 }
 

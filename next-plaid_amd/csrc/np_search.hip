@@ -524,14 +524,14 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     NP_TRY(w.chist.reserve((size_t)B * 256 * 4));
     NP_TRY(w.ub2.reserve((size_t)pool * 2));
     NP_TRY(w.ub_hist2.reserve((size_t)B * NP_UB_BINS * 4));
-    NP_TRY(w.ub_thr2.reserve((size_t)2 * B * 4));   // [B] tau bins, [B] Lambda
+    NP_TRY(w.ub_thr2.reserve((size_t)3 * B * 4));   // [B] tau bins, [B] Lambda, [B] Lambda2 (floor of the exact level)
     NP_TRY(w.list_meta.reserve((size_t)pool * 16));
     NP_TRY(w.n_l1.reserve((size_t)B * 4));
     NP_TRY(w.n_l2.reserve((size_t)B * 4));
     if (use_planes) {
       NP_TRY(w.planes.reserve((size_t)B * KP * RB));
       NP_TRY(w.levels.reserve((size_t)B * 16 * 4));
-      NP_TRY(w.hotbits.reserve((size_t)B * (KP / 32) * 4));
+      NP_TRY(w.hotbits.reserve((size_t)2 * B * (KP / 32) * 4));   // hot bitmap, then the exact level's kept-centroid bitmap
     }
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
@@ -623,7 +623,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     if (use_planes) {   // Lambda, the thresholds of the 8 planes and the hot bitmap in one launch, then the plane rows of the hot centroids
       hot_levels_kernel<<<dim3((unsigned)std::min<int64_t>(std::max<int64_t>((KP >> 5) / 256, 1), 16), B), 256, 0, st>>>(
           w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.cmaxu.as<uint8_t>(), KP, ix->tune.s4_pexp, w.ub_thr2.as<uint32_t>() + B,
-          w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>());
+          w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>(), ix->tune.s4_warm, w.ub_thr2.as<uint32_t>() + 2 * B,
+          w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32));
       const dim3 pg((unsigned)std::min<int64_t>((KP + 2047) / 2048, 64), B);
       if (RB == 32)
         hot_planes_kernel<32><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
@@ -765,11 +766,26 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       // exact u8 bound of the records meta[begin[b] .. begin[b] + count[b]) -> U, histogram (optional)
       // direct_wpq > 0: a short list per query (S1, about n_sel documents): wpq workgroups per query, every query at once,
       // instead of one query per XCD at a time (8 hand-out steps of ~25 us each for a handful of claims)
+      // floor: the S2 list of the two-level filter with u16 codes -- rows of the centroids no query token is close to are
+      // skipped, U = the floored upper bound, the histogram counts the lower bound (approx_ub_kernel, FLOOR)
+      const bool can_floor = two_level && use_planes && !ix->code_wide && oob && RB <= 64 && ix->tune.s4_warm < 1000;
       auto launch_ub = [&](int lvl, const uint4* meta, const int32_t* begin, const int32_t* count, uint16_t* U, uint32_t* hist,
-                           int count_tokens, int direct_wpq) {
+                           int count_tokens, int direct_wpq, bool floor_rows = false) {
         int32_t* sl = xslots(lvl);
         int32_t* tk = sl + 8 * (B + 1);
         const unsigned grid = direct_wpq > 0 ? (unsigned)(B * direct_wpq) : 8 * nbx;
+        if (floor_rows && can_floor) {
+#define NP_LAUNCH_UBF(ROWB)                                                                                                   \
+  approx_ub_kernel<ROWB, uint16_t, 2, 1><<<grid, 256, 0, st>>>(                                                                 \
+      w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(), rp, r, max_rounds, (const uint16_t*)ix->d_ucodes,     \
+      w.qflag.as<uint32_t>(), cs->n_sel, U, hist, hshift, xcursor(lvl), sl, tk, B, ix->tune.ub_steal, w.ctr.as<Counters>(),      \
+      count_tokens, direct_wpq, ix->tune.ub_static, w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32),                           \
+      w.ub_thr2.as<uint32_t>() + 2 * B, d_qoff)
+          if (RB == 32) NP_LAUNCH_UBF(32);
+          else NP_LAUNCH_UBF(64);
+#undef NP_LAUNCH_UBF
+          return;
+        }
 #define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                        \
   approx_ub_kernel<ROWB, CT, NT><<<grid, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(),   \
                                                        rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(),   \
@@ -914,7 +930,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
         cp.dst_begin = w.n_l1.as<int32_t>();
         cp.n_dst = w.n_l2.as<int32_t>();
         ub_cut_kernel<<<dim3(ncut, B), 256, 0, st>>>(cp, rp, r);
-        launch_ub(2, w.list_meta.as<uint4>(), w.n_l1.as<int32_t>(), w.n_l2.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0, 0);
+        launch_ub(2, w.list_meta.as<uint4>(), w.n_l1.as<int32_t>(), w.n_l2.as<int32_t>(), w.ub2.as<uint16_t>(), w.ub_hist2.as<uint32_t>(), 0, 0,
+                  true);
         // every document with U' >= tau now has its exact bound in the histogram: the cut over S1 + S2 is the single-level
         // filter's cut (the n_sel-th largest exact U of ALL candidates lies in S1 + S2), tau can only rise
         ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist2.as<uint32_t>(), hshift, slack, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,

@@ -90,7 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 100), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 60), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1), ("s4_planes", 1), ("s4_lpd", 2), ("s4_qm", 1), ("s4_warm", 500)):
         hx.tune(k, v)
 
 
@@ -319,6 +319,9 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
             hx.tune("ub_direct", 0 if hot == 300 else 8)   # short-list launch: per-XCD hand-out or one group of workgroups per query
             hx.tune("ub_static", 1 if hot in (10, 500) else 0)   # claims from a cursor (with stealing) or round-robin
             hx.tune("hot_static", 0 if hot in (10, 300) else 1)
+            # exact level of the S2 list: every row (1000), or only the rows of the warmest 50 / 30 / 11 % of the centroids with
+            # the other tokens floored (upper bound for the cut, lower bound for its threshold)
+            hx.tune("s4_warm", {0: 500, 10: 110, 100: 500, 300: 1000, 500: 300}[hot])
             got = hx.search_batch(batch, p)
             st = dict(hx.last_stats)
             for i, (g, r) in enumerate(zip(got, ref)):
@@ -335,6 +338,7 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         if nfs == 512:
             assert rows[100] < rows[0], rows        # the hot level gathers fewer table rows than the exact bound alone
     hx.tune("s4_planes", 1)
+    hx.tune("s4_warm", 500)
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got[:8], orc):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
@@ -367,6 +371,7 @@ def test_long_documents_overflow_blocks_and_windows():
             hx.tune("s4_hot", hot)
             hx.tune("s4_planes", planes)
             hx.tune("s4_lpd", 2 if hot == 400 else 4)            # (512-byte blocks take 4 lanes per document whatever the knob)
+            hx.tune("s4_warm", 1000 if hot == 400 else 400)      # floored exact level over several staging windows per list
             got = hx.search_batch(qs, p)
             st = dict(hx.last_stats)
             for i, (g, r) in enumerate(zip(got, ref)):
