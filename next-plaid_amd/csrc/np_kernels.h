@@ -2066,7 +2066,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         s_nd[wave][grp] = nd;
         if (valid) {
           toks += (unsigned long long)(m.w >> 8);
-          ucnt += (unsigned long long)nd;
+          if constexpr (!FLOOR) ucnt += (unsigned long long)nd;   // FLOOR: the rows actually requested, counted per window below
           ++ndoc;
         }
       }
@@ -2156,6 +2156,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         int ndk = 0;
         if constexpr (FLOOR) {
           ndk = s_ndk[wave][grp];
+          if (jl == 0 && valid) ucnt += (unsigned long long)ndk;
           int km = ndk;
 #pragma unroll
           for (int o = LPD; o < 64; o <<= 1) km = max(km, __shfl_xor(km, o));

@@ -338,6 +338,19 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         if nfs == 512:
             assert rows[100] < rows[0], rows        # the hot level gathers fewer table rows than the exact bound alone
     hx.tune("s4_planes", 1)
+    # the floored exact level really skips table rows (n_cand_codes counts the rows requested) and keeps the results
+    hx.tune("s4_hot", 100)
+    p2 = P(n_full_scores=512, top_k=128, n_ivf_probe=32, centroid_score_threshold=None)
+    hx.tune("s4_warm", 1000)
+    full = hx.search_batch(batch, p2)
+    rows_full, lvl2 = hx.last_stats["n_cand_codes"], hx.last_stats["n_level2"]
+    hx.tune("s4_warm", 300)
+    part = hx.search_batch(batch, p2)
+    assert hx.last_stats["n_cand_codes"] <= rows_full, (hx.last_stats["n_cand_codes"], rows_full)
+    if lvl2 > len(batch) * 128:      # more documents at the exact level than the S1 lists hold: some S2 list is not empty
+        assert hx.last_stats["n_cand_codes"] < rows_full, (hx.last_stats["n_cand_codes"], rows_full, lvl2)
+    for g, r in zip(part, full):
+        assert np.array_equal(g.passage_ids, r.passage_ids) and np.array_equal(g.scores, r.scores)
     hx.tune("s4_warm", 500)
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got[:8], orc):
