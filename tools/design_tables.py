@@ -18,7 +18,7 @@ R = "r04"
 
 GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
-    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m", "planes0_10m"],
+    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m", "planes0_10m", "warm1000_10m"],
     f"{R}_bench_regimes.jsonl": ["dist05", "dist08", "lq48_10m", "lq48_1m", "nfs8192_10m", "k19_10m", "k19_split_10m", "c3_np32", "c3_np8"],
 }
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k",
@@ -160,6 +160,7 @@ def tables():
                    ("precision 1 (bf16 QC-reuse)", var.get("prec1")), ("precision 3 (plain bf16 MaxSim)", var.get("prec3")),
                    ("precision 2, single-level filter (`NP_S4_HOT=0`)", var.get("single_level_10m")),
                    ("precision 2, round-3 first level (byte maxima, `NP_S4_PLANES=0`)", var.get("planes0_10m")),
+                   ("precision 2, exact filter level without the floor (`NP_S4_WARM=1000`)", var.get("warm1000_10m")),
                    ("precision 2, t_cs = None", var.get("tcs_none"))):
         if not d:
             continue
@@ -179,8 +180,9 @@ def tables():
 
     hs = ["| S4 filter, 10 M documents | table rows gathered / batch | documents at the exact level | S4 ms | queries/s |", "|---|---:|---:|---:|---:|"]
     for lab, d in (("single level (exact u8 bound of every candidate, `NP_S4_HOT=0`)", var.get("single_level_10m")),
-                   ("two levels, first level as byte maxima (round 3, `NP_S4_PLANES=0`)", var.get("planes0_10m")),
-                   ("two levels, first level in bit planes (default)", d10)):
+                   ("two levels, first level as byte maxima (round 3, `NP_S4_PLANES=0`; 10 % hot)", var.get("planes0_10m")),
+                   ("two levels, first level in bit planes (6 % hot), exact level gathers every row (`NP_S4_WARM=1000`)", var.get("warm1000_10m")),
+                   ("two levels, bit planes (6 % hot) + floored exact level (rows of the warmest 50 % of the centroids): default", d10)):
         if d:
             x = d["stages"]
             hs.append(f"| {lab} | {x['n_cand_codes']/1e6:.0f} M | {(x['n_level2'] or x['n_candidates'])/1e6:.2f} M | {x['ms_approx']:.2f} | {d['value']:.0f} |")
