@@ -61,6 +61,8 @@ def install(tag, merge=False):
                  ("pmc_d10m.md", f"{R}_pmc_10m.md"), ("traffic_d10m.json", "traffic.json"), ("host.txt", f"{R}_host.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), P + b)
+    if not os.path.exists(os.path.join(src, "test_all.log")):
+        return
     with open(P + f"{R}_test_gpu.log", "w") as f:
         for a in ("test_all.log", "smoke.log"):
             if os.path.exists(os.path.join(src, a)):
