@@ -194,8 +194,11 @@ int np_hip_index_write_dir(const char* index_dir, const np_index_arrays* arrays,
  * NP_<UPPER-CASE NAME>, and can be changed on a live handle with this call (sweep tools, kernel-variant parity tests);
  * both paths clamp through one table.  Knobs: "s4_mode" 0..8, "s4_minb" >= 1, "s4_nbx" 8..512, "s4_swz" 0/1,
  * "s4_filter" 0/1, "s4_hot" 0..500 (per-mille of hot centroids in the first filter level; 0 = single-level filter),
+ * "s4_planes" 0/1 (first level in bit planes; read at open too: it sets the list-block cap), "s4_pexp" 5..40, "s4_lpd" 2/4,
+ * "s4_qm" 0/1, "s4_pnbx" 8..512, "s4_warm" 1..1000 (per-mille of centroids whose rows the exact filter level still gathers
+ * for the S2 lists; 1000 = every row), "s1_split" 0/1 (the only knob that changes values: see INTEGRATION.md),
  * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "ub_direct" 0..16, "ub_static" 0/1, "hot_static" 0/1, "s6_xcd" 0/1, "s6_tiles" 0/1, "s6_lds" 0..2, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
- * Results are identical for every setting; not synchronised with concurrent searches.  Unknown name:
+ * Results are identical for every setting except "s1_split"; not synchronised with concurrent searches.  Unknown name:
  * NP_ERR_INVALID_ARGUMENT.  (A library built with -DNP_DIAGNOSTICS also accepts "s4_probe" 0..7, a phase-skipping timing
  * probe whose results are invalid; production builds reject the name and never read it from the environment.) */
 int np_hip_index_tune(np_index* index, const char* name, int32_t value);
