@@ -1,0 +1,153 @@
+"""The arithmetic behind the S4 filter, restated in numpy and checked as properties (no GPU, no library call).
+
+The HIP path never computes the approximate score of most candidates: it keeps a document only while an integer UPPER bound
+of its score reaches a threshold that rests on LOWER bounds of the n_sel-th best score.  The GPU
+tests check the kernels against the oracle; this file checks the inequalities and the cut rule themselves on random
+instances, including the round-4 forms (bit planes, floored exact level), ragged query lengths and heavy ties:
+
+    lo(d) <= U(d) <= up(d),   U(d) <= U'(d) <= U''(d),   U - Lq - 1 <= 127.5 (approx / s + Lq) <= U + 1,
+    survivors of the three-step cut  >=  { d : approx(d) is among the n_sel largest (ties included) }.
+"""
+import numpy as np
+import pytest
+
+PLANES = 8
+
+
+def u8_table(QC, s):
+    """np_kernels.h, qc_gemm epilogue: u = floor((x / s + 1) * 127.5) + 1 in [1, 255], monotone in x."""
+    return (np.floor((QC.astype(np.float32) / np.float32(s) + np.float32(1.0)) * np.float32(127.5)) + 1).astype(np.int64)
+
+
+def lam_for_share(M, permille):
+    """hot_levels_kernel: the smallest level with at most permille/1000 of the centroids above it."""
+    K = M.size
+    limit = K * permille // 1000
+    for lam in range(0, 256):
+        if int((M > lam).sum()) <= limit:
+            return lam
+    return 255
+
+
+def plane_levels(lam, top, pexp10=15):
+    """hot_levels_kernel: t_j = Lambda + ceil(span * (j / 8)^e), strictly increasing while there is room, t_8 = top."""
+    top = max(top, lam + 1)
+    span = top - lam
+    t = []
+    for v in range(PLANES + 1):
+        if v == 0:
+            x = lam
+        elif v == PLANES:
+            x = top
+        else:
+            x = lam + int(np.ceil(np.float32(span) * np.float32((v / PLANES) ** (0.1 * pexp10))))
+        t.append(min(max(x, min(lam + v, top)), top))
+    return t
+
+
+def make_instance(rng, K=512, n_docs=600, Lq=13, dim=16, codes_per_doc=(3, 40), ties=False):
+    cen = rng.standard_normal((K, dim)).astype(np.float32)
+    cen /= np.linalg.norm(cen, axis=1, keepdims=True)
+    q = rng.standard_normal((Lq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    if ties:                       # few distinct centroids: many documents share a score exactly
+        cen[K // 8:] = cen[rng.integers(0, K // 8, K - K // 8)]
+    QC = q @ cen.T                                       # [Lq, K]
+    s = 1.001 * np.linalg.norm(q, axis=1).max() * np.linalg.norm(cen, axis=1).max()
+    docs = [np.unique(rng.integers(0, K, rng.integers(*codes_per_doc))) for _ in range(n_docs)]
+    return QC, s, docs
+
+
+def bounds(QC, s, docs, hot_permille, warm_permille):
+    Lq = QC.shape[0]
+    u = u8_table(QC, s)                                  # [Lq, K]
+    M = u.max(axis=0)
+    lam = lam_for_share(M, hot_permille)
+    lam2 = lam_for_share(M, max(warm_permille, hot_permille))
+    t = plane_levels(lam, int(M.max()))
+    approx = np.array([QC[:, c].max(axis=1).astype(np.float32).sum(dtype=np.float32) for c in docs])
+    U = np.array([u[:, c].max(axis=1).sum() for c in docs])
+    Uh, Up, up, lo = [], [], [], []
+    for c in docs:
+        hot = c[M[c] > lam]
+        hm = np.maximum(u[:, hot].max(axis=1), lam) if hot.size else np.full(Lq, lam)
+        Uh.append(hm.sum())
+        # planes: round every value above Lambda up to the next level
+        b = Lq * lam
+        for j in range(PLANES):
+            bit = (u[:, hot] > t[j]).any(axis=1) if hot.size else np.zeros(Lq, bool)
+            b += (t[j + 1] - t[j]) * int(bit.sum())
+        Up.append(b)
+        kept = c[M[c] > lam2]
+        km = u[:, kept].max(axis=1) if kept.size else np.zeros(Lq, np.int64)
+        up.append(np.maximum(km, lam2).sum())
+        lo.append(km.sum())
+    return approx, U, np.array(Uh), np.array(Up), np.array(up), np.array(lo), lam, lam2
+
+
+def nth_largest(x, n):
+    return np.sort(x)[-min(n, x.size)]
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("hot,warm", [(100, 500), (60, 500), (10, 110), (300, 1000), (500, 300)])
+def test_bounds_are_ordered_and_the_cut_keeps_the_top(seed, hot, warm):
+    rng = np.random.default_rng(1000 + seed)
+    Lq = int(rng.integers(1, 33))
+    QC, s, docs = make_instance(rng, Lq=Lq, ties=(seed % 3 == 2))
+    approx, U, Uh, Up, up, lo, lam, lam2 = bounds(QC, s, docs, hot, warm)
+    assert lam2 <= lam
+    assert (U <= Uh).all() and (Uh <= Up).all(), "hot bound / plane bound must dominate the exact bound"
+    assert (lo <= U).all() and (U <= up).all(), "floored exact level: lower and upper bound"
+    # the bracket of the f32 score by the integer bound (np_kernels.h): z < 1 covers the rounding of u and of the f32 sum
+    scaled = 127.5 * (approx.astype(np.float64) / s + Lq)
+    assert (U - Lq - 1 <= scaled).all() and (scaled <= U + 1).all()
+    slack = Lq + 2
+    for n_sel in (1, 7, 64, len(docs) + 5):
+        true_top = approx >= nth_largest(approx, n_sel)              # ties included
+        # single-level filter (round 2)
+        keep1 = U >= nth_largest(U, n_sel) - slack
+        assert (keep1 | ~true_top).all()
+        # three-step cut with the plane bound in front and the floored exact level behind (np_search.hip)
+        S1 = Up >= nth_largest(Up, n_sel)
+        tau = nth_largest(U[S1], n_sel) - slack                      # S1 keeps its exact bound
+        S2 = (Up >= tau) & ~S1
+        low = np.where(S1, U, lo)                                    # what the histogram counts
+        upp = np.where(S1, U, up)                                    # what the cut compares
+        L = S1 | S2
+        tau2 = nth_largest(low[L], n_sel) - slack
+        assert tau2 >= tau, "the threshold can only rise"
+        surv = L & (upp >= tau2)
+        assert (surv | ~true_top).all(), f"n_sel={n_sel}: a document of the true top was cut"
+        # and the filter is not vacuous on the larger instances
+        if n_sel == 7 and len(docs) >= 500 and not (seed % 3 == 2):
+            assert surv.sum() < len(docs)
+
+
+def test_padding_tokens_are_neutral():
+    """A query padded to the row width: padding columns hold 0 in the u8 table, are never floored, and leave every bound
+    of the real tokens unchanged (the slack follows the query's own token count, not the row width)."""
+    rng = np.random.default_rng(7)
+    QC, s, docs = make_instance(rng, Lq=20)
+    approx, U, Uh, Up, up, lo, lam, lam2 = bounds(QC, s, docs, 100, 500)
+    u = u8_table(QC, s)
+    upad = np.vstack([u, np.zeros((12, u.shape[1]), np.int64)])      # rows 20..31: padding
+    M = upad.max(axis=0)
+    assert (M == u.max(axis=0)).all()
+    for c, U0, up0, lo0 in zip(docs[:50], U, up, lo):
+        assert upad[:, c].max(axis=1).sum() == U0
+        kept = c[M[c] > lam2]
+        km = upad[:, kept].max(axis=1) if kept.size else np.zeros(32, np.int64)
+        floor = np.where(np.arange(32) < 20, lam2, 0)                # approx_ub_kernel FLOOR: real tokens only
+        assert np.maximum(km, floor).sum() == up0 and km.sum() == lo0
+
+
+def test_plane_levels_are_increasing_and_end_at_the_top():
+    for lam, top in ((0, 255), (158, 255), (250, 255), (254, 255), (255, 255), (100, 101), (10, 14)):
+        for e in (10, 15, 30):
+            t = plane_levels(lam, top, e)
+            assert t[0] == lam and t[-1] == max(top, lam + 1)
+            assert all(a <= b for a, b in zip(t, t[1:]))
+            room = max(top, lam + 1) - lam
+            if room >= PLANES:
+                assert all(a < b for a, b in zip(t, t[1:])), (lam, top, e, t)
