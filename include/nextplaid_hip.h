@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 4
+#define NP_ABI_VERSION 5
 
 typedef enum np_status {
   NP_OK = 0,
@@ -87,6 +87,8 @@ typedef struct np_info {            /* accessors of index.rs:1290-1312 */
   int64_t device_bytes;             /* HBM held by the index (without workspaces) */
   int32_t device;
   int32_t abi_version;
+  int64_t workspace_bytes;          /* ABI v5: the LIVE per-context scratch budget (np_open_opts.workspace_bytes, or the
+                                       default, which shrinks under memory pressure and grows back; 0 from probe_dir) */
 } np_info;
 
 /* Per-call stage timings (HIP events on the call's stream) and work counters.  Optional. */
@@ -297,10 +299,12 @@ int np_hip_merge_packed(const np_index* index, const void* d_records, int64_t re
  *
  * Failure of ONE rank never blocks the others: every exchange record carries a status word, a rank whose local work
  * fails (its workspace does not fit, a launch error) still takes part in both all-gathers with empty data and returns its
- * own error at once; on the other ranks the batch comes back EMPTY (every out_counts[i] = 0) and np_hip_comm_status
- * -- valid once `stream` is synchronised -- names the failed rank and its np_status.  With the hosted transport below the
+ * own error at once; on the other ranks the batch comes back ABANDONED -- every out_counts[i] = -1 (NP_COUNT_ABANDONED), a
+ * count no healthy batch produces: a host MUST treat a negative count as a failed batch, whether or not it polls
+ * np_hip_comm_status -- and np_hip_comm_status, valid once `stream` is synchronised, names the failed rank and its np_status.  With the hosted transport below the
  * gathered bytes pass through the host, so every rank returns NP_ERR_SEARCH from the call itself (after gather 1). */
 typedef struct np_comm np_comm;
+#define NP_COUNT_ABANDONED (-1)
 int np_hip_comm_unique_id(void* id128);
 int np_hip_comm_create(const np_index* index, const void* id128, int32_t rank, int32_t nranks, np_comm** out);
 void np_hip_comm_destroy(np_comm* comm);

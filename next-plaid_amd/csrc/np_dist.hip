@@ -142,6 +142,11 @@ int np_hip_comm_unique_id(void* id128) {
 
 int np_hip_comm_create(const np_index* ix, const void* id128, int32_t rank, int32_t nranks, np_comm** out) {
   clear_error();
+  if (!out) {
+    set_error("comm_create: NULL out pointer");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
   if (nranks > 1 && !id128) {
     set_error("comm_create: invalid argument (more than one rank needs the RCCL id)");
     return NP_ERR_INVALID_ARGUMENT;
@@ -172,6 +177,11 @@ int np_hip_comm_create(const np_index* ix, const void* id128, int32_t rank, int3
 int np_hip_comm_create_hosted(const np_index* ix, int32_t rank, int32_t nranks, np_all_gather_host_fn all_gather,
                               void* ctx, int32_t flags, np_comm** out) {
   clear_error();
+  if (!out) {
+    set_error("comm_create_hosted: NULL out pointer");
+    return NP_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
   if (!all_gather) {
     set_error("comm_create_hosted: NULL all-gather callback");
     return NP_ERR_INVALID_ARGUMENT;
@@ -370,7 +380,11 @@ extern "C" int np_hip_search_batch_sharded(const np_index* ix, np_comm* c, const
   // ---- gather 2 + merge
   NP_TRY(all_gather(c, pl, c->pack_all.p, rec2, st, &h_all));
   NP_TRY(merge_packed_status(ix, c->pack_all.p, (int64_t)rec2, (int64_t)o_keys, (int64_t)o_sc, (int64_t)o_cnt,
-                             (int64_t)o_st2, rc == NP_OK ? c->h_status : nullptr /* this rank reports by return code */, G, B, k,
+                             (int64_t)o_st2,
+                             /* a rank that reports the failure by its return code (its own, or -- hosted transport with the
+                                host-side check -- a peer's, below) must not ALSO leave the word behind for the next healthy
+                                batch's np_hip_comm_status */
+                             (rc == NP_OK && !host_check) ? c->h_status : nullptr, G, B, k,
                              d_out_ids, d_out_scores, d_out_counts, st));
   if (rc != NP_OK) return finish(rc);
   if (host_check && h_all) {

@@ -122,6 +122,7 @@ void read_tuning_env(Tuning* t) {
 static void default_workspace(DeviceIndex* ix) {
   ix->ws_auto = ix->opts.workspace_bytes <= 0;
   ix->ws_budget = ix->opts.workspace_bytes;
+  ix->ws_budget_open = ix->opts.workspace_bytes;
   if (!ix->ws_auto) return;
   size_t free_b = 0, total_b = 0;
   int64_t ws = (int64_t)8 << 30;
@@ -131,6 +132,7 @@ static void default_workspace(DeviceIndex* ix) {
   }
   ix->opts.workspace_bytes = ws;
   ix->ws_budget = ws;
+  ix->ws_budget_open = ws;
 }
 
 static int check_device(int dev) {
@@ -815,14 +817,17 @@ struct Uploader {
   }
 };
 
-// codes as stored (i64, N.codes.npy) -> u16 / u32 with the loader's range check (first offending value to *bad, -1 = none)
+// codes as stored (i64, N.codes.npy) -> u16 / u32 with the loader's range check: bad[0] = flag (0 = every code in range),
+// bad[1] = one offending value (the thread that raises the flag stores it: any i64, -1 included, is reportable)
 __global__ void __launch_bounds__(256) narrow_codes_kernel(const int64_t* __restrict__ src, int64_t n, int64_t K, void* __restrict__ dst,
                                                            int wide, long long* __restrict__ bad) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int64_t v = src[i];
   if (v < 0 || v >= K) {
-    atomicCAS((unsigned long long*)bad, (unsigned long long)-1ll, (unsigned long long)v);
+    if (atomicExch((unsigned long long*)bad, 1ull) == 0ull) bad[1] = v;
+    if (wide) static_cast<uint32_t*>(dst)[i] = 0u;   // never leave an unwritten (garbage) code behind
+    else static_cast<uint16_t*>(dst)[i] = 0;
     return;
   }
   if (wide) static_cast<uint32_t*>(dst)[i] = (uint32_t)v;
@@ -947,8 +952,8 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
       }
     } free_stage{d_stage, &d_bad};
     for (int i = 0; i < NP_UP_SLOTS; ++i) NP_HIP(hipMalloc(&d_stage[i], NP_UP_PIECE));
-    NP_HIP(hipMalloc(&d_bad, 8));
-    NP_HIP(hipMemset(d_bad, 0xFF, 8));
+    NP_HIP(hipMalloc(&d_bad, 16));
+    NP_HIP(hipMemset(d_bad, 0, 16));
     const bool repack = ix->pd != ix->lpd;
     const int widen = ix->lnbits != ix->nbits;
     int64_t pos = 0;  // token position of the current chunk's first token in the host arrays
@@ -992,10 +997,10 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
       set_error("Index load failed: chunks hold %lld tokens, doclens need %lld", (long long)pos, (long long)te);
       return NP_ERR_INDEX_LOAD;
     }
-    long long bad = -1;
-    NP_HIP(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
-    if (bad != -1) {
-      set_error("Index load failed: code %lld out of range [0,%lld)", bad, (long long)ix->K);
+    long long bad[2] = {0, 0};
+    NP_HIP(hipMemcpy(bad, d_bad, 16, hipMemcpyDeviceToHost));
+    if (bad[0] != 0) {
+      set_error("Index load failed: code %lld out of range [0,%lld)", bad[1], (long long)ix->K);
       return NP_ERR_INDEX_LOAD;
     }
   }
@@ -1663,6 +1668,7 @@ int np_hip_index_info(const np_index* ix, np_info* out) {
   out->device_bytes = (int64_t)ix->device_bytes;
   out->device = ix->device;
   out->abi_version = NP_ABI_VERSION;
+  out->workspace_bytes = ix->ws_budget.load(std::memory_order_relaxed);
   return NP_OK;
 }
 

@@ -201,6 +201,7 @@ struct DeviceIndex {
   // grow, and halved when a reservation still fails: a second index opened on the device (the "swap handles" reload pattern),
   // or an encoder allocating later, shrinks the pool (more rounds) instead of failing the search with OutOfMemory.
   mutable std::atomic<int64_t> ws_budget{0};
+  int64_t ws_budget_open = 0;   // the budget at open: the live one grows back towards it when the device has headroom again
   bool ws_auto = false;
   Tuning tune;
   CodeArr codes() const { return CodeArr{d_codes, code_wide}; }

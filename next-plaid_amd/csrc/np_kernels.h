@@ -4828,8 +4828,9 @@ __global__ void or_reduce_kernel(const uint32_t* __restrict__ all, int G, int64_
 
 // merge G x top_k triples by (exact desc [finite first], approx key desc); rank by counting.  Rank g's arrays start
 // rs_* elements after rank g-1's (contiguous [G][B][top_k] arrays, or one packed record per rank).  status (nullable):
-// one u64 per rank, rs_status words apart; a non-zero word of any rank empties every query of the batch and the first such
-// word is left in *host_status (pinned host memory the caller reads after synchronising the stream).
+// one u64 per rank, rs_status words apart; a non-zero word of any rank ABANDONS every query of the batch -- out_counts[b] = -1,
+// a count no healthy batch produces, so a host that never polls np_hip_comm_status cannot mistake the batch for "no results" --
+// and the first such word is left in *host_status (pinned host memory the caller reads after synchronising the stream).
 __global__ void __launch_bounds__(256) merge_topk_kernel(const int64_t* __restrict__ ids, const float* __restrict__ scores,
                                                          const uint64_t* __restrict__ keys,
                                                          const int32_t* __restrict__ counts, int64_t rs_ids,
@@ -4844,7 +4845,7 @@ __global__ void __launch_bounds__(256) merge_topk_kernel(const int64_t* __restri
     for (int g = 0; g < G && !failed; ++g) failed = status[(int64_t)g * rs_status];
     if (failed) {   // wave-uniform: every thread read the same words
       if (tid == 0) {
-        out_counts[b] = 0;
+        out_counts[b] = -1;
         if (b == 0 && host_status) *host_status = failed;
       }
       return;

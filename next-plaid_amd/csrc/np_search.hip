@@ -21,17 +21,25 @@ struct Workspace {
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
   bool done_valid = false;
+  std::vector<DevBuf*> all_bufs() {
+    return {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
+            &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
+            &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
+            &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits};
+  }
   void release_all() {
-    DevBuf* all[] = {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-                     &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
-                     &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
-                     &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits};
+    const std::vector<DevBuf*> all = all_bufs();
     for (DevBuf* b : all) b->release();
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
     h_pin_cap = 0;
     if (done) (void)hipEventDestroy(done);
     done = nullptr;
+  }
+  size_t total_bytes() {   // everything this workspace holds on the device
+    size_t t = 0;
+    for (DevBuf* b : all_bufs()) t += b->cap;
+    return t;
   }
   size_t pool_bytes() const {   // the candidate pool and its companions (sized by the budget)
     return cand.cap + cand_meta.cap + approx.cap + ub.cap + surv_meta.cap + ub2.cap + list_meta.cap;
@@ -456,16 +464,22 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   const int nsel1 = std::max(cs->n_sel, 1), topk1 = std::max(prm.top_k, 1);
   WsPlan plan = plan_workspace(ix, B, LQP, &prm);
   if (ix->ws_auto) {
-    // the default budget was what the device had free at open: before a pool GROWS, look at what is free now
+    // The default budget was what the device had free at open.  Before a pool GROWS, and whenever the budget stands below
+    // its value at open, look at what is free now: the budget covers this context's scratch AND pool, so what this context
+    // could hold in total is the free memory plus everything it already holds (minus a margin for the other contexts'
+    // small buffers).  It shrinks when the batch would not fit (another tenant took the memory since open: more rounds, not
+    // OutOfMemory) and grows back towards the open value once the tenant is gone.
     const int64_t want = std::min<int64_t>(plan.pool, (int64_t)std::max(B, 1) * std::max<int64_t>(ix->n_docs, 1));
-    if ((int64_t)w.cand.cap < want * 4) {
+    const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
+    if ((int64_t)w.cand.cap < want * 4 || budget < ix->ws_budget_open) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const int64_t held = (int64_t)w.pool_bytes();
-        const int64_t avail = (int64_t)free_b + held - ((int64_t)1 << 30);   // keep 1 GiB for the per-query scratch to come
-        const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
-        if (want * NP_POOL_ENTRY > avail && avail < budget) {
-          ix->ws_budget.store(std::max<int64_t>(avail, (int64_t)256 << 20), std::memory_order_relaxed);
+        const int64_t held = (int64_t)w.total_bytes();
+        const int64_t avail = (int64_t)free_b + held - ((int64_t)512 << 20);
+        const int64_t nb = std::min<int64_t>(ix->ws_budget_open, std::max<int64_t>(avail, (int64_t)256 << 20));
+        if ((nb < budget && plan.S * per_query_bytes(ix, LQP, n_sel_of(&prm), prm.top_k) + want * NP_POOL_ENTRY > avail) ||
+            nb > budget) {
+          ix->ws_budget.store(nb, std::memory_order_relaxed);
           plan = plan_workspace(ix, B, LQP, &prm);
         }
       }

@@ -75,7 +75,8 @@ class np_info(C.Structure):
     _fields_ = [("num_documents", C.c_int64), ("num_embeddings", C.c_int64), ("num_partitions", C.c_int64),
                 ("embedding_dim", C.c_int32), ("nbits", C.c_int32), ("avg_doclen", C.c_double),
                 ("shard_doc_begin", C.c_int64), ("shard_doc_end", C.c_int64), ("shard_embeddings", C.c_int64),
-                ("device_bytes", C.c_int64), ("device", C.c_int32), ("abi_version", C.c_int32)]
+                ("device_bytes", C.c_int64), ("device", C.c_int32), ("abi_version", C.c_int32),
+                ("workspace_bytes", C.c_int64)]
 
 
 class np_stats(C.Structure):
@@ -215,9 +216,13 @@ def lib():
     return L
 
 
-def _check(rc: int):
+def last_error() -> str:
+    return lib().np_hip_last_error().decode("utf-8", "replace")
+
+
+def _check(rc: int, msg: str | None = None):
     if rc:
-        msg = lib().np_hip_last_error().decode("utf-8", "replace")
+        msg = last_error() if msg is None else msg
         raise _ERR.get(rc, NextPlaidError)(msg or f"np_status {rc}")
 
 
@@ -455,6 +460,13 @@ class MmapIndex:
     @property
     def info(self) -> np_info:
         return self._info
+
+    def workspace_bytes(self) -> int:
+        """The LIVE per-context scratch budget (np_info.workspace_bytes, ABI v5): the default one shrinks when another
+        tenant of the device leaves less room than at open and grows back towards its open value afterwards."""
+        live = np_info()
+        _check(lib().np_hip_index_info(self._h, C.byref(live)))
+        return int(live.workspace_bytes)
 
     # -- search ------------------------------------------------------------------------------------------
     def _pack(self, queries):

@@ -305,12 +305,18 @@ class CShardedSearcher:
                        t.zeros(B, dtype=t.int32, device=self.device))
         p = params._c()
         hq = np.ascontiguousarray(h_qoff, np.int32)
-        api._check(api.lib().np_hip_search_batch_sharded(
+        rc = api.lib().np_hip_search_batch_sharded(
             self.index._h, self.comm._h, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_qoff.data_ptr()),
             hq.ctypes.data_as(C.c_void_p), B, self.index.embedding_dim(), C.byref(p),
             None if d_subset is None else C.c_void_p(d_subset.data_ptr()), -1 if d_subset is None else d_subset.numel(),
             C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()),
-            C.c_void_p(self.stream.cuda_stream)))
+            C.c_void_p(self.stream.cuda_stream))
+        if rc != 0:
+            msg = api.last_error()
+            # a failed batch must not leave its status word behind for the next healthy one: drain it before raising
+            self.stream.synchronize()
+            self.comm.status()
+            api._check(rc, msg)
         return out
 
     def search_batch(self, queries, params, subset=None):
@@ -325,7 +331,7 @@ class CShardedSearcher:
             ids, sc, cnt = self.search_batch_device(dq, do, off, params, ds)
             ids, sc, cnt = ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
         self.stream.synchronize()
-        rank, code = self.comm.status()   # a peer's failure empties the batch on every rank (np_dist.hip)
-        if code:
+        rank, code = self.comm.status()   # a peer's failure abandons the batch on every rank: counts = -1 (np_dist.hip)
+        if code or (cnt < 0).any():
             raise api.SearchError(f"Search failed: shard {rank} failed with status {code}; the batch was abandoned on every rank")
         return [api.QueryResult(i, ids[i, : cnt[i]].copy(), sc[i, : cnt[i]].copy()) for i in range(len(qs))]

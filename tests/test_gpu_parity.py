@@ -479,6 +479,21 @@ def test_on_disk_index_equals_arrays(tmp_path):
         assert np.array_equal(r1.passage_ids, r2.passage_ids) and np.array_equal(r1.scores, r2.scores)
 
 
+@pytest.mark.parametrize("bad", [-1, 128, -(1 << 62), 1 << 40])
+def test_open_rejects_an_out_of_range_code(bad):
+    """The device-side narrowing of the i64 codes keeps the loader's range check (mmap.rs / index.rs:1026-1139 reject nothing
+    here, but a code >= K would index past the centroid table): ANY out-of-range value fails the open with IndexLoad --
+    -1 included, which a value-as-sentinel check would let through."""
+    spec, a = make_arrays(num_docs=300, num_centroids=128, dim=64, nbits=4, doc_len_min=5, doc_len_max=30, seed=31)
+    b = dict(a)
+    b["codes"] = np.array(a["codes"], np.int64, copy=True)
+    b["codes"][b["codes"].size // 2] = bad
+    with pytest.raises(npa.IndexLoadError) as e:
+        hip_index(b)
+    assert str(bad) in str(e.value) and "out of range" in str(e.value)
+    hip_index(a).close()                                   # the untouched arrays still open
+
+
 def test_reload_after_the_directory_changed(tmp_path):
     """MmapIndex::reload (index.rs:1767-1775): delete() rewrites the chunk files and re-sequences the ids
     (delete.rs:66-120); reload() must serve the new directory -- here: the same corpus without its first 100 documents."""

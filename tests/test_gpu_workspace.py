@@ -44,14 +44,20 @@ def test_pool_shrinks_instead_of_out_of_memory():
     # no threshold + a wide probe: hundreds of thousands of candidates per query, so the pool size matters
     p = npa.SearchParameters(n_full_scores=256, top_k=10, n_ivf_probe=64, centroid_score_threshold=None)
     first = ix.search_batch(qs, p)
+    at_open = ix.workspace_bytes()
     free, _total = torch.cuda.mem_get_info()
     hog = torch.empty(max(free - (3 << 30), 1 << 20), dtype=torch.uint8, device="cuda")   # leave ~3 GiB
     try:
         again = ix.search_batch(qs, p)          # least-recently-used hand-out: this is the second context
         assert _same(again, first)
         assert ix.last_stats["n_rounds"] >= 1
+        assert ix.workspace_bytes() < at_open   # the live budget is what np_hip_index_info reports
         third = ix.search_batch(qs, p)          # and the first context again
         assert _same(third, first)
     finally:
         del hog
         torch.cuda.empty_cache()
+    # the tenant is gone: the budget grows back to its value at open instead of staying pinned to the small pool
+    for _ in range(2):
+        assert _same(ix.search_batch(qs, p), first)
+    assert ix.workspace_bytes() == at_open

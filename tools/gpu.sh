@@ -11,6 +11,8 @@
 #   bench <name> [bench args]    python bench.py <args>                             -> b_<name>.json (+ .err), one summary line
 #   stats <name> [bench args]    rocprofv3 --kernel-trace --stats of a short bench  -> stats_<name>/ (+ kernel table .md)
 #   pmc   <name> [bench args]    separate rocprofv3 --pmc passes of a short bench   -> pmc_<name>/  (+ traffic json)
+#   probe <name> <binary> [args] tools/probes/<binary> alone (stdout -> probe_<name>.log), then under separate rocprofv3 --pmc passes
+#                                (FETCH_SIZE; TCC_EA0_RDREQ_sum; TCC_EA0_RDREQ_32B_sum)            -> probe_<name>/ + probe_<name>.md
 #   env   K=V                    export for the following jobs
 #   sh    <name> <command...>    anything else                                      -> sh_<name>.log
 # Per-job time limits: JOB_TIMEOUT (default 900 s).
@@ -70,6 +72,19 @@ for job in "$@"; do
       python3 tools/pmc_summary.py $O/pmc_$name $O/pmc_$name.md > /dev/null 2>&1
       python3 tools/make_traffic.py $O/pmc_$name ${PMC_DOCS:-10000000} $O/traffic_$name.json > $O/traffic_$name.log 2>&1
       find $O/pmc_$name -name "*.csv" -size +20M -delete; du -sh $O/pmc_$name;;
+    probe) shift 2
+      bin=$REPO/tools/probes/$1; shift
+      timeout $T $bin "$@" > $O/probe_$name.log 2>&1
+      mkdir -p $O/probe_$name
+      i=0
+      for set in "FETCH_SIZE" "TCC_EA0_RDREQ_sum" "TCC_EA0_RDREQ_32B_sum" "WRITE_SIZE"; do
+        i=$((i+1))
+        ( cd /tmp && export TMPDIR=/tmp && timeout $T rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/probe_$name/p$i -o p -- \
+            $bin "$@" > /dev/null 2> $O/probe_$name/p$i.err )
+        echo "$set" > $O/probe_$name/p$i.set
+      done
+      python3 tools/probes/fetch_probe_summary.py $O/probe_$name.log $O/probe_$name $O/probe_$name.md | head -n 12
+      find $O/probe_$name -name "*.csv" -size +20M -delete;;
     sh) shift 2; timeout $T bash -c "$*" > $O/sh_$name.log 2>&1; echo "sh $name rc=$? : $(tail -n 2 $O/sh_$name.log)";;
     *) echo "unknown job kind: $kind";;
   esac
