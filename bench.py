@@ -12,8 +12,8 @@ in HBM by the seeded generator of next_plaid_amd/synth.py.  With N GPUs the SAME
 top-k over RCCL (dist.py), so the merged result is the unsharded result.
 
 A "step" is ONE pass of the hot path (S1 centroid scoring -> S7 top-k) over one batch of 64 queries whose
-embeddings are already resident in HBM; value = queries / second, whole job (`value_pcie_inclusive` = the same through
-np_hip_search_batch with host query/result buffers).
+embeddings are already resident in HBM; value = queries / second, whole job (`value_pcie_inclusive` = the same batches through
+np_hip_search_batch -- host query buffers in, host results out -- from as many host threads as `value` uses streams).
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel: algorithmic bytes or flops per launch /
 its HIP-event duration on the call's stream vs the chip peak), "cpu_baseline" (the oracle restatement of the
@@ -83,6 +83,11 @@ def parse():
                     help="document shards of the corpus (0 = one per rank, the north_star layout).  With S < N ranks the job runs "
                          "N/S REPLICAS of an S-way sharded index: rank r holds shard r %% S in replica group r // S, the groups "
                          "answer DIFFERENT batches concurrently (S = 1: every GPU holds the whole index, no collective at all)")
+    ap.add_argument("--hosted", action="store_true",
+                    help="N > 1 ranks that SHARE GPU 0, the collectives over the hosted transport (np_hip_comm_create_hosted + gloo): "
+                         "executes this script's whole multi-rank control flow (process group, replica groups, one communicator per "
+                         "stream, status polling, max-over-ranks timing) on a 1-GPU box.  RCCL refuses two ranks on one device, so this "
+                         "is NOT a scaling measurement and the line says so")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin (each step = one full batch pass; the "
                          "small launch-bound kernels of one batch overlap the memory-bound ones of the next)")
@@ -133,8 +138,11 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if npa.device_count() < 1:
         raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
+    if a.hosted:
+        local_rank = 0                                   # every rank on GPU 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if a.hosted else dev      # where the harness's own small collectives live (gloo: host tensors)
     n_shards = a.shards if a.shards > 0 else world
     if world % n_shards:
         raise SystemExit(f"--shards {n_shards} does not divide the {world} ranks")
@@ -146,7 +154,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.hosted:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- corpus: ONE fixed corpus generated in HBM, document-sharded over the ranks -------------------------------
     dim = 128
@@ -236,7 +247,7 @@ def main():
         # the whole protocol below the C ABI (np_hip_search_batch_sharded, RCCL all-gathers issued by the library on
         # the call's stream): one communicator per stream so the collectives of batch i overlap the kernels of batch
         # i+1; rank 0's ncclUniqueId reaches the other ranks through a torch.distributed broadcast
-        from next_plaid_amd.dist import CShardedSearcher, ShardComm
+        from next_plaid_amd.dist import CShardedSearcher, ShardComm, gloo_all_gather
 
         grp = None
         if use_dist and n_repl > 1:   # new_group is collective over ALL ranks: every rank creates every replica group
@@ -253,26 +264,30 @@ def main():
         comms, err = [], ""
         try:
             try:
-                if shard == 0 and n_shards > 1:
+                if shard == 0 and n_shards > 1 and not a.hosted:
                     buf = C.create_string_buffer(128)
                     api._check(L.np_hip_comm_unique_id(buf))   # librccl loads here, before any collective is entered
             except Exception as ex:   # noqa: BLE001
                 err = f"{type(ex).__name__}: {ex}"
+                print(f"bench.py: rank {rank}: np_hip_comm_unique_id failed: {err}", file=sys.stderr)
             if use_dist:
-                flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+                flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=cdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 if int(flag.item()) and not err:
                     err = "np_hip_comm_unique_id failed on another rank"
-            if not err:
+            if not err and a.hosted:
+                comms = [ShardComm(ix, shard, n_shards, all_gather=gloo_all_gather(grp)) for _ in range(nstr)]
+            elif not err:
                 comms = [ShardComm(ix, shard, n_shards, exchange=exchange if n_shards > 1 else None) for _ in range(nstr)]
         except Exception as ex:       # noqa: BLE001 -- a failure inside ncclCommInitRank itself
             err = err or f"{type(ex).__name__}: {ex}"
+            print(f"bench.py: rank {rank} (shard {shard}, replica group {repl}): communicator creation failed: {err}", file=sys.stderr)
         if use_dist:
-            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()) and not err:
                 err = "np_hip_comm_create failed on another rank"
-        if err and n_repl == 1 and use_dist:
+        if err and n_repl == 1 and use_dist and not a.hosted:
             for cm in comms:
                 cm.close()
             dist_impl = "torch"
@@ -333,7 +348,7 @@ def main():
             if code:
                 raise SystemExit(f"bench.py: shard {fr} failed with np_status {code} inside the timed region")
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     qps = a.batch * a.steps * n_repl / dt      # every replica group answered `steps` batches of its own in that time
@@ -361,7 +376,63 @@ def main():
         for k, v in ix.last_stats.items():
             acc[k] = acc.get(k, 0) + v
     stages = {k: v / nprof for k, v in acc.items()}
-    qps_pcie = a.batch / float(np.median(host_t)) if world == 1 else None   # one call in flight, host buffers
+    qps_pcie_1 = a.batch / float(np.median(host_t)) if world == 1 else None   # ONE call in flight, host buffers
+
+    # ---- SURVEY 8(d)'s protocol at the SAME concurrency as `value`: np_hip_search_batch (host query buffers in, host results
+    # out: H2D + S1..S7 + D2H inside the call) from as many host threads as `value` uses streams -- the way the API's tokio
+    # workers call MmapIndex::search_batch (next-plaid-api/src/handlers/search.rs:219-229).  Each thread has its own host
+    # buffers; the library hands each concurrent call its own context (stream + workspace + pinned result staging).
+    qps_pcie, pcie_calls = None, 0
+    if world == 1:
+        import threading
+        hq = [np.ascontiguousarray(np.concatenate(qs[i * a.batch:(i + 1) * a.batch], 0), np.float32) for i in range(a.query_batches)]
+        hoff = np.ascontiguousarray(off, np.int32)
+        k1 = max(a.top_k, 1)
+        per_thread = max(4, min(a.steps, 240) // nstr)
+        outs = [(np.zeros(a.batch * k1, np.int64), np.zeros(a.batch * k1, np.float32), np.zeros(a.batch, np.int32)) for _ in range(nstr)]
+        errs = []
+        gate = threading.Barrier(nstr + 1)
+
+        def host_worker(t):
+            oi, osc, oc = outs[t]
+            try:
+                for j in range(2):          # untimed: the thread's first calls
+                    api._check(L.np_hip_search_batch(ix._h, hq[(t + j) % a.query_batches].ctypes.data, hoff.ctypes.data, a.batch, dim,
+                                                     C.byref(cp), None, -1, oi.ctypes.data, osc.ctypes.data, oc.ctypes.data, None))
+                gate.wait()
+                for j in range(per_thread):
+                    api._check(L.np_hip_search_batch(ix._h, hq[(t + j) % a.query_batches].ctypes.data, hoff.ctypes.data, a.batch, dim,
+                                                     C.byref(cp), None, -1, oi.ctypes.data, osc.ctypes.data, oc.ctypes.data, None))
+            except Exception as ex:   # noqa: BLE001
+                errs.append(f"{type(ex).__name__}: {ex}")
+                try:
+                    gate.abort()
+                except Exception:   # noqa: BLE001
+                    pass
+
+        ths = [threading.Thread(target=host_worker, args=(t,)) for t in range(nstr)]
+        for th in ths:
+            th.start()
+        try:
+            gate.wait()
+            t1 = time.perf_counter()
+            for th in ths:
+                th.join()
+            dt_h = time.perf_counter() - t1
+            if not errs:
+                pcie_calls = per_thread * nstr
+                qps_pcie = a.batch * pcie_calls / dt_h
+        except threading.BrokenBarrierError:
+            for th in ths:
+                th.join()
+        if errs:
+            print("bench.py: PCIe-inclusive leg failed: " + "; ".join(errs[:2]), file=sys.stderr)
+
+    # ---- N > 1: the merged result of the sharded protocol against the oracle on the WHOLE corpus (small corpora only: rank 0
+    # builds the unsharded corpus next to its shard to export it for the CPU oracle).  Collective: every rank takes part.
+    got_sharded = None
+    if use_shards and world > 1 and a.parity_queries > 0 and a.docs <= 1_000_000:
+        got_sharded = ss.search_batch(qs[:min(a.parity_queries, nq)], prm)
 
     if rank != 0:
         if use_dist:
@@ -387,7 +458,7 @@ def main():
     dom = max(per_stage, key=lambda k: per_stage[k][0])
     ms, bound, units, unit, peak = per_stage[dom]
     achieved = units / (ms * 1e-3) if ms > 0 else 0.0
-    traffic, traffic_src = None, None
+    traffic, traffic_src, tj_ok = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if collected
     if os.path.exists(tpath):
         try:
@@ -400,6 +471,7 @@ def main():
             if default_workload and tj.get("docs_per_gpu") == docs_local and tj.get("kernels_sha") == kernels_sha():
                 traffic = tj.get(dom)
                 traffic_src = {"commit": tj.get("commit"), "kernels_sha": tj.get("kernels_sha")}
+                tj_ok = tj
         except Exception:
             traffic = None
     # `frac` prices the contract's ALGORITHMIC bytes (Tc*4 + C*8 for S4) against the stage's duration; the filter
@@ -407,9 +479,32 @@ def main():
     frac_phys = None
     if traffic and ms > 0 and bound == "hbm":
         frac_phys = round(traffic / 1e9 / (ms * 1e-3) / peak, 5)
+    # The dominant KERNEL of that stage by itself: the first filter level (one launch per batch, timed by its own pair of HIP events
+    # on the call's stream, np_stats.ms_hot_level).  Its algorithmic bytes are what ITS algorithm has to move per launch -- per
+    # candidate the id (4 B in), the list block's header (16 B) and distinct codes, the 16-B record and the u16 bound it writes,
+    # plus one plane row per hot (document, code) pair it gathers -- not the contract's per-token figure, which this kernel exists
+    # to avoid; `traffic` = what the PMC counters saw for this kernel alone.
+    dom_kernel = None
+    ms_hot = stages.get("ms_hot_level", 0.0)
+    if dom == "approx(S4)" and ms_hot > 0:
+        code_b = 2 if a.centroids <= 65536 else 4
+        row_b = 32 if Lq <= 32 else 64
+        # rows gathered by the hot level alone are not counted separately (n_cand_codes = both levels): the upper bound of its
+        # share is all of them
+        alg = stages["n_candidates"] * (4 + 16 + 16 + 2) + stages.get("n_cand_dcodes", 0) * code_b
+        kname = "approx_hotp_kernel" if os.environ.get("NP_S4_PLANES", "1") != "0" else "approx_hot_kernel"
+        ktr = None
+        if tj_ok is not None:
+            ktr = (tj_ok.get("per_kernel", {}).get(kname) or {}).get("bytes_per_batch")
+        dom_kernel = dict(kernel=kname, ms_per_launch=round(ms_hot, 4), bound="hbm", algorithmic_bytes=int(alg),
+                          achieved=round(alg / 1e9 / (ms_hot * 1e-3), 2), unit="GB/s", peak=HBM_PEAK_GBS,
+                          frac=round(alg / 1e9 / (ms_hot * 1e-3) / HBM_PEAK_GBS, 5), traffic=ktr,
+                          frac_physical=None if not ktr else round(ktr / 1e9 / (ms_hot * 1e-3) / HBM_PEAK_GBS, 5),
+                          note="algorithmic bytes = candidates x (4 B id + 16 B block header + 16 B record + 2 B bound) + distinct "
+                               "(document, code) pairs x code bytes; plane rows (L2-resident) not counted")
     roofline = dict(kernel=dom, bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
                     frac=round(achieved / peak, 5), frac_physical=frac_phys, traffic=traffic, traffic_source=traffic_src,
-                    ms_per_launch=round(ms, 4),
+                    ms_per_launch=round(ms, 4), dominant_kernel=dom_kernel,
                     all={k: dict(ms=round(v[0], 4), bound=v[1], achieved=round(v[2] / (v[0] * 1e-3), 2) if v[0] > 0 else None,
                                  unit=v[3], frac=round(v[2] / (v[0] * 1e-3) / v[4], 4) if v[0] > 0 else None)
                          for k, v in per_stage.items()},
@@ -418,18 +513,18 @@ def main():
     # ---- CPU baseline + parity at full size: the oracle restatement on this box's host cores ----------------------------
     cpu = None
     parity = None
-    if (a.cpu_queries > 0 or a.parity_queries > 0) and world == 1:
+    if ((a.cpu_queries > 0 or a.parity_queries > 0) and world == 1) or got_sharded is not None:
         try:
             from oracle import oracle as O
             cix, cdocs, e = ix, a.docs, None
-            if not (0 < a.cpu_docs < a.docs):
+            if not (0 < a.cpu_docs < a.docs) and world == 1:
                 try:
                     e = ix.export()                     # whole corpus back to host arrays in the on-disk dtypes
                 except (MemoryError, npa.NextPlaidError):
                     e = None
             if e is None:
                 # bounded sample: the first cdocs documents of the same corpus (same generator, same seed)
-                cdocs = a.cpu_docs if 0 < a.cpu_docs < a.docs else min(a.docs, 1_000_000)
+                cdocs = a.cpu_docs if 0 < a.cpu_docs < a.docs and world == 1 else min(a.docs, 1_000_000)
                 sspec = synth.SynthSpec(num_docs=cdocs, num_centroids=a.centroids, dim=dim, nbits=a.nbits,
                                         doc_len_min=len_min, doc_len_max=a.doc_len, seed=1236, **gen)
                 cix = npa.MmapIndex.synth(sspec, centroids=cen, device=local_rank, max_batch=a.batch, n_contexts=1)
@@ -438,7 +533,7 @@ def main():
                                e["codes"], e["residuals"], a.nbits)
             po = O.SearchParameters(n_full_scores=a.n_full_scores, top_k=a.top_k, n_ivf_probe=a.nprobe,
                                     centroid_batch_size=a.centroid_batch_size, centroid_score_threshold=thr)
-            if a.cpu_queries > 0:
+            if a.cpu_queries > 0 and world == 1:
                 nc = min(a.cpu_queries, nq)
                 ox.search_batch(qs[:min(4, nc)], po)            # warm page cache / threads
                 reps = []
@@ -455,12 +550,16 @@ def main():
             if a.parity_queries > 0:
                 npq = min(a.parity_queries, nq)
                 ref = ox.search_batch(qs[:npq], po)
-                got = ss.search_batch(qs[:npq], prm) if (use_shards and cix is ix) else cix.search_batch(qs[:npq], prm)
+                if got_sharded is not None:
+                    got = got_sharded
+                else:
+                    got = ss.search_batch(qs[:npq], prm) if (use_shards and cix is ix) else cix.search_batch(qs[:npq], prm)
                 agree = sum(int(np.array_equal(g.passage_ids, r.passage_ids)) for g, r in zip(got, ref))
                 top1 = sum(int(g.passage_ids[:1].tolist() == r.passage_ids[:1].tolist()) for g, r in zip(got, ref))
                 rel = max((float(np.max(np.abs(g.scores - r.scores) / np.maximum(np.abs(r.scores), 1e-6)))
                            for g, r in zip(got, ref) if g.scores.size and g.scores.size == r.scores.size), default=0.0)
-                parity = dict(queries=npq, docs=cdocs, topk_ids_identical=agree, top1_identical=top1, max_rel_score_err=rel,
+                parity = dict(queries=npq, docs=cdocs, through="np_hip_search_batch_sharded over %d ranks" % world if got_sharded is not None else "np_hip_search_batch",
+                              topk_ids_identical=agree, top1_identical=top1, max_rel_score_err=rel,
                               source_doc_rank1=sum(int(g.passage_ids[0] == s) for g, s in zip(got, src[:npq])
                                                    if g.passage_ids.size and s < cdocs))
             del ox, e
@@ -473,11 +572,19 @@ def main():
         "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "p50_batch_latency_ms": None if p50 is None else round(p50, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "hosted": bool(a.hosted),
+        "hosted_note": ("all %d ranks share GPU 0 and the collectives run over the hosted (gloo) transport: a run of the multi-rank "
+                        "control flow, NOT a scaling measurement (RCCL refuses two ranks on one device)" % world) if a.hosted else None,
         "dtype": {0: "f32", 1: "f32 (bf16 MFMA on the residual term of MaxSim)",
                   2: "f32 (split-bf16 hi/lo MFMA on the residual term of MaxSim, f32-class accuracy)",
                   3: "f32 + bf16 MaxSim"}[a.precision], "data": "synthetic",
         "streams": nstr,
+        "value_note": "value = device-resident I/O (queries and results stay in HBM, np_hip_search_batch_device on `streams` HIP streams); "
+                      "value_pcie_inclusive = SURVEY 8(d)'s protocol, host buffers in / host results out through np_hip_search_batch from "
+                      "the same number of host threads",
         "value_pcie_inclusive": None if qps_pcie is None else round(qps_pcie, 2),
+        "pcie_inclusive": None if qps_pcie is None else dict(host_threads=nstr, calls=pcie_calls, one_call_in_flight=round(qps_pcie_1, 2),
+                                                              ratio_to_value=round(qps_pcie / qps, 4)),
         "config": {"workload": f"{a.docs} docs x {a.doc_len if len_min == a.doc_len else f'{len_min}-{a.doc_len}'} tok x d128 "
                                f"(nbits={a.nbits}), 2^{k2} centroids, nprobe={a.nprobe}, batch={a.batch}x{a.query_tokens} tok, "
                                f"n_full_scores={a.n_full_scores}, t_cs={thr}, top_k={a.top_k}; one fixed corpus sharded "
@@ -487,7 +594,7 @@ def main():
                                       f"tokens, the batched-probe regime: run --centroids 524288 for that line") if a.centroids == 65536 and a.docs >= 5_000_000 else None,
                    "s1_split": bool(s1_split),
                    "docs_total": a.docs, "docs_per_gpu": docs_local, "batch": a.batch, "shards": n_shards, "replicas": n_repl,
-                   "parallelism": ((f"doc-shard x{n_shards} + RCCL all-gather ({'np_hip_search_batch_sharded' if dist_impl == 'c' else 'torch.distributed harness'}){dist_note}"
+                   "parallelism": ((f"doc-shard x{n_shards} + {'hosted gloo' if a.hosted else 'RCCL'} all-gather ({'np_hip_search_batch_sharded' if dist_impl == 'c' else 'torch.distributed harness'}){dist_note}"
                                     if use_shards else "whole index per GPU")
                                    + (f", x{n_repl} replica groups on different batches" if n_repl > 1 else ""))
                                   if use_dist else "single GPU"},

@@ -113,6 +113,9 @@ typedef struct np_stats {
   int64_t n_survivors;   /* candidates that passed the S4 upper-bound filter and got an exact approximate score */
   int64_t n_cand_dcodes; /* distinct (document, code) pairs of the candidates (<= n_cand_tokens) */
   int64_t n_level2;      /* two-level filter: documents that took the exact u8 bound after the hot bound */
+  float ms_hot_level;    /* ABI v5: the first filter level's launch alone (approx_hotp_kernel / approx_hot_kernel of round 0;
+                            part of ms_approx; 0 when the two-level filter does not apply) */
+  int32_t reserved0;
 } np_stats;
 
 /* ---- runtime ------------------------------------------------------------------------------ */

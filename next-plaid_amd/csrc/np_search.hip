@@ -129,6 +129,7 @@ struct CallState {
   np_search_params prm{};
   bool empty_subset = false;
   bool timed = false;
+  bool hot_timed = false;   // ev[8] .. ev[9] bracket the first filter level of round 0 (np_stats.ms_hot_level)
   bool trace = false;   // debug_trace: every candidate keeps its exact approximate score
   const uint32_t* elig_global = nullptr;   // sharded + subset: eligible-centroid bitmap OR-ed over all shards (search.rs:350-364)
 };
@@ -908,6 +909,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   } while (0)
           const int plpd = (ix->ublock_stride > old_cap || ix->tune.s4_lpd == 4) ? 4 : 2;
           const unsigned pnbx = (unsigned)ix->tune.s4_pnbx;   // workgroups per XCD of the plane kernel
+          if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[8], st));
           if (use_planes) {
             if (!ix->code_wide) {
               if (RB == 32) NP_LAUNCH_HOTP_L(32, uint16_t);
@@ -922,6 +924,10 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
 #undef NP_LAUNCH_HOTP
 #undef NP_LAUNCH_HOT_RB
 #undef NP_LAUNCH_HOT
+          if (cs->timed && r == 0) {
+            NP_HIP(hipEventRecord(cs->ctx->ev[9], st));
+            cs->hot_timed = true;
+          }
         }
         // S1 = the n_sel documents with the largest U' (whole bins): exact bound -> tau
         ub_thr_kernel<<<B, 256, 0, st>>>(w.ub_hist.as<uint32_t>(), hshift, 0, cs->n_sel, w.n_cand.as<int32_t>(), rp, r,
@@ -1297,6 +1303,11 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
       float tot = 0;
       (void)hipEventElapsedTime(&tot, cs.ctx->ev[0], cs.ctx->ev[7]);
       acc.ms_total += tot;
+      if (cs.hot_timed) {
+        float hot = 0;
+        (void)hipEventElapsedTime(&hot, cs.ctx->ev[8], cs.ctx->ev[9]);
+        acc.ms_hot_level += hot;
+      }
       acc.n_cells += (int64_t)h_ctr->n_cells;
       acc.n_ivf_ids += (int64_t)h_ctr->n_ivf_ids;
       acc.n_candidates += (int64_t)h_ctr->n_candidates;

@@ -86,10 +86,11 @@ class np_stats(C.Structure):
                 ("n_cells", C.c_int64), ("n_ivf_ids", C.c_int64), ("n_candidates", C.c_int64),
                 ("n_cand_tokens", C.c_int64), ("n_exact_docs", C.c_int64), ("n_exact_tokens", C.c_int64),
                 ("n_cand_codes", C.c_int64), ("n_queries", C.c_int32), ("n_rounds", C.c_int32),
-                ("n_survivors", C.c_int64), ("n_cand_dcodes", C.c_int64), ("n_level2", C.c_int64)]
+                ("n_survivors", C.c_int64), ("n_cand_dcodes", C.c_int64), ("n_level2", C.c_int64),
+                ("ms_hot_level", C.c_float), ("reserved0", C.c_int32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 class np_index_arrays(C.Structure):
