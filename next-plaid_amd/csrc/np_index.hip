@@ -80,7 +80,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "s4_qm") t->s4_qm = value != 0;
   else if (n == "s4_pnbx") t->s4_pnbx = clamp(value, 8, 512);
   else if (n == "s3_slices") t->s3_slices = value != 0;
-  else if (n == "s4_warm") t->s4_warm = clamp(value, 1, 1000);
+  else if (n == "s4_warm") t->s4_warm = clamp(value, 0, 1000);
   else if (n == "ub_nt") t->ub_nt = value < 0 || value > 2 ? 0 : value;
   else if (n == "ub_steal") t->ub_steal = value < 1 ? 1 : value;
   else if (n == "ub_nbx") t->ub_nbx = clamp(value, 8, 256);
@@ -92,7 +92,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "hot_static") t->hot_static = value != 0;
   else if (n == "s6_xcd") t->s6_xcd = value != 0;
   else if (n == "s6_tiles") t->s6_tiles = value != 0;
-  else if (n == "s6_lds") t->s6_lds = clamp(value, 0, 2);
+  else if (n == "s6_lds") t->s6_lds = clamp(value, 0, 3);
   else if (n == "gemm_cpw") t->gemm_cpw = value == 2 ? 2 : 1;
   else if (n == "s1_split") t->s1_split = value != 0;
   else if (n == "exact_rowmax") t->exact_rowmax = value != 0;
@@ -601,6 +601,9 @@ static int build_unique_codes(DeviceIndex* ix, int64_t** d_uoff_out) {
     }
     (void)hipFree(d_hist);
     NP_HIP(e);
+    double usum = 0;
+    for (int q2 = 0; q2 < NP_ULEN_BINS; ++q2) usum += (double)q2 * h_hist[q2];
+    ix->ulen_mean = (float)(usum / (double)N);
     const int64_t allow = N / 100;    // lists allowed to overflow (1 %: the filter re-reads only those)
     int64_t over = 0;
     int q = NP_ULEN_BINS - 1;

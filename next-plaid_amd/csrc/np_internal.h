@@ -137,8 +137,8 @@ struct Tuning {
   int s4_pnbx = 96;      // ... workgroups per XCD (3 per CU at 42 KB of LDS each with 2 lanes per document; 160 = 5 per CU with 4)
   int s4_qm = 1;         // ... a lane's hot codes as a position mask in registers (1) or compacted in place by LDS writes (0)
   int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
-  int s4_warm = 500;     // ... per-mille of the centroids whose rows the exact level still gathers for the S2 list (the rest: floored
-                         // at Lambda2; approx_ub_kernel FLOOR); 1000 = every row
+  int s4_warm = 0;       // ... per-mille of the centroids whose rows the exact level still gathers for the S2 list (the rest: floored
+                         // at Lambda2; approx_ub_kernel FLOOR); 1000 = every row; 0 = by query length and list length (np_search.hip)
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim
                          // on a line all XCDs share costs ~50 ns, serialised): 2.06 -> 1.68 ms at 10 M documents
@@ -181,6 +181,7 @@ struct DeviceIndex {
   uint4* d_useg = nullptr;        // [n_docs] 8 x u16: distinct codes below each eighth of the centroid range (derived)
   uint4* d_doc_meta = nullptr;    // [n_docs] the 16-B candidate record of every document {doc, n distinct codes, offset of its
                                   // distinct-code list in d_ucodes: low 32 bits, bits 32..39 | doc length << 8} (derived)
+  float ulen_mean = 0.f;          // mean number of distinct codes per document (derived; scales the exact level's floor)
   bool sliced_ok = false;         // every document's distinct-code list is sorted and < 65536 long
   float cmax = 0.f;               // upper bound of the centroid row norms (derived; scales the S4 u8 score table)
   bool filter_ok = false;         // every centroid value is finite: the S4 upper-bound filter may run

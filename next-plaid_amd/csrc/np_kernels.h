@@ -246,15 +246,17 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
       k0 = max(k0, (uint32_t)__shfl_xor((int)k0, 32));
       if (kk == 0) gmax[((int64_t)b * G + ((c0 >> 5) + f)) * LQP + qt * 32 + li] = k0;
       if (QCU) {
-        // u8 UPPER bound of every score for the S4 filter: u = floor((x / s + 1) * 127.5) + 1 in [1, 255] (never
-        // clipped: |x| <= s / 1.001), monotone in x, so max over a document's codes commutes with it; 0 marks the
-        // padding tokens q >= Lq.  One RB-byte row per centroid (bytes LQP .. RB-1 are zeroed by the host).
+        // u8 UPPER bound of every score for the S4 filter (round 5: the table spans the POSITIVE scores only, twice the
+        // resolution): u = floor(max(x, 0) / s * 254) + 1 in [1, 254] (x <= s / 1.001), monotone in x, so max over a
+        // document's codes commutes with it; u = 1 is the clipped bottom entry (x < s / 254: the score may be anything down
+        // to -s, which the LOWER bounds account for -- approx_ub_kernel); 0 marks the padding tokens q >= Lq.  One RB-byte
+        // row per centroid (bytes LQP .. RB-1 are zeroed by the host).
         const float inv = qinv[b];
         const bool qv = qt * 32 + li < qoff[b + 1] - qoff[b];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float hh = fmaf(acc[f][r] * inv, 127.5f, 127.5f);   // < 254.9 (|x| <= s / 1.001): u <= 255 without a clamp,
-          const uint32_t u = qv ? (uint32_t)hh + 1u : 0u;            // and the byte store keeps the low 8 bits anyway
+          const float hh = fmaxf(acc[f][r] * inv, 0.f) * 254.0f;    // < 253.8: u <= 254 without a clamp (NaN -> 0: flagged queries
+          const uint32_t u = qv ? (uint32_t)hh + 1u : 0u;            // never reach the filter)
           sU[wave][mfma_row(r, kk) * 32 + li] = (uint8_t)u;
         }
       }
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(256) qc_gemm_b3_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // the split product can exceed the Cauchy-Schwarz bound of the f32 chain by its own error: clamp to the table's range
-        const float hh = fminf(fmaxf(fmaf(acc[r] * inv, 127.5f, 127.5f), 0.f), 254.5f);
+        const float hh = fminf(fmaxf(acc[r] * inv, 0.f) * 254.0f, 254.5f);
         const uint32_t u = qv ? (uint32_t)hh + 1u : 0u;
         sU[wave][mfma_row(r, kk) * 32 + li] = (uint8_t)u;
       }
@@ -1900,13 +1902,20 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 // S4, upper-bound filter (ahead of the exact kernels above; selection-preserving).
 // The exact approximate score needs one 128-B f32 table row per (document, distinct code) and one query's f32
 // table (8.4 MB) does not fit an XCD's 4 MB L2.  S1 also writes a u8 table (2 MB per query at Lq <= 32) whose
-// entry is a monotone UPPER bound of the score: u = floor((x / s + 1) * 127.5) + 1.  Monotone, so
+// entry is a monotone UPPER bound of the score: u = floor(max(x, 0) / s * 254) + 1 (round 5: positive scores only --
+// half the step of rounds 2-4's floor((x / s + 1) * 127.5) + 1, i.e. half the slack in score units).  Monotone, so
 //     U(d) = sum_q max_{c in codes(d)} u[q, c]     (integers, exact)
-// brackets the f32 score:  U - Lq - z <= 127.5 * (approx(d) / s + Lq) <= U + z  with z < 1 covering the rounding
-// of u and of the reference's q-ordered f32 sum.  Hence approx(d1) >= approx(d2)  =>  U(d1) >= U(d2) - (Lq + 2),
-// and every document of the true top n_sel has U >= (n_sel-th largest U) - (Lq + 2): ub_cut_kernel keeps exactly
+// is an upper bound of the f32 score in table units:  254 * approx(d) / s <= U + z  with z < 1 covering the rounding of u
+// and of the reference's q-ordered f32 sum; and a LOWER bound needs the clipped entries: a token whose maximum is the
+// bottom entry (u = 1: every code of the document scores below s / 254 against it, possibly negative) contributes at
+// least -254, any other token at least u - 1, so
+//     L(d) = U(d) - 254 * #{q : max_c u[q, c] = 1}   obeys   L - Lq - z <= 254 * approx(d) / s.
+// The threshold of a cut rests on lower bounds and the cut itself compares upper bounds: with tau = (n_sel-th largest L)
+// every document of the true top n_sel has U >= tau - (Lq + 2) -- if U(d) < tau - (Lq + 2), n_sel documents e have
+// 254 approx(e) / s >= L(e) - Lq - z >= tau - Lq - z > U(d) + 2 - z > 254 approx(d) / s.  ub_cut_kernel keeps exactly
 // those ("survivors", typically n_sel plus a few hundred) and only they get the exact f32 score, from which S5
-// selects -- the same documents in the same order as without the filter.  Random row gathers run at ~260 G rows/s
+// selects -- the same documents in the same order as without the filter.  (A document with a clipped token is one whose
+// every code is nearly orthogonal or opposed to a query token: it merely stops counting towards the threshold.)  Random row gathers run at ~260 G rows/s
 // out of L2 whatever the row size (tools/probes/gather_probe2.hip: the L2 serves one request per channel per
 // clock), vs ~57 G rows/s once they miss it, so the win is the table fitting L2, not the smaller rows.
 // One XCD owns a query (workgroup w -> XCD w % 8); a row is ROWB = LQP bytes = LPD lanes x 16 B, so a wave walks
@@ -1925,8 +1934,10 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 // MODE 2: the table is read through a buffer descriptor and positions past a document's list carry an out-of-range
 //         offset: the bounds check returns zeros (u >= 1, so 0 is the identity of the max) WITHOUT a memory request, so
 //         the padding of the lockstep walk costs no L2 request slot.
-// FLOOR (MODE 2, u16 codes): the rows of the centroids outside `warmbits` (M[c] <= Lambda2: no query token is close to
-// them) are not requested, and every real token's maximum is floored at Lambda2:
+// FLOOR (MODE 2): the rows of the centroids outside `warmbits` (M[c] <= Lambda2: no query token is close to
+// them) are not requested, and every real token's maximum is floored at Lambda2 (u16 codes: the K-bit map is copied into
+// LDS; u32 codes, K up to 2^19: the staging lanes look their codes up in the map where it lies, in the L2 -- all lookups of
+// a staging batch in flight at once):
 //     up(d) = sum_q max(Lambda2, max_{c kept} u[q, c]) >= U(d) >= lo(d) = sum_q max_{c kept} u[q, c].
 // U[] receives `up` (the cut keeps a document on its UPPER bound) and the histogram counts `lo` (the cut's threshold may
 // only rest on LOWER bounds of the n_sel-th largest U): the selection stays exact, for about half the row requests on the
@@ -1954,7 +1965,8 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
                                                         const uint32_t* __restrict__ warmbits = nullptr /* FLOOR: [B][KP / 32] */,
                                                         const uint32_t* __restrict__ lam2_b = nullptr /* FLOOR: [B] Lambda2 */,
                                                         const int32_t* __restrict__ qoff = nullptr /* FLOOR: token offsets (Lq) */) {
-  static_assert(FLOOR == 0 || (MODE == 2 && sizeof(CT) == 2 && ROWB <= 64), "the floored level: bounds-checked loads, u16 codes");
+  static_assert(FLOOR == 0 || (MODE == 2 && ROWB <= 64), "the floored level: bounds-checked loads");
+  constexpr bool WLDS = FLOOR && sizeof(CT) == 2;   // the kept-centroid bitmap in LDS (K <= 65536) or read from memory
   constexpr int LPD = ROWB / 16;   // lanes per document (one 16-B piece of the row each)
   constexpr int DPW = 64 / LPD;    // documents per wave
   constexpr int CAP = sizeof(CT) == 2 ? 128 : 64;   // distinct codes of one document staged per pass (32 KB of LDS per
@@ -1968,7 +1980,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
   // 30 M L2 misses and 8x over-fetch per launch.)
   __shared__ uint32_t s_hist[NP_UB_BINS];
   __shared__ CT s_codes[4][DPW][CAP];
-  __shared__ uint32_t s_warm[FLOOR ? 2048 : 4];   // FLOOR: the query's kept-centroid bitmap (K <= 65536)
+  __shared__ uint32_t s_warm[WLDS ? 2048 : 4];    // FLOOR, u16 codes: the query's kept-centroid bitmap (K <= 65536)
   __shared__ int s_ndk[4][FLOOR ? DPW : 1];        // FLOOR: kept codes of each document in the staged window
   __shared__ int64_t s_cl[4][DPW];
   __shared__ int s_nd[4][DPW];
@@ -2031,9 +2043,11 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
       for (int i = tid; i < NP_UB_BINS; i += 256) s_hist[i] = 0;
     uint32_t lam2 = 0;
     int Lq = 0;
+    const uint32_t* wb = nullptr;
     if constexpr (FLOOR) {
-      const uint32_t* wb = warmbits + (int64_t)b * (KP >> 5);
-      for (int i = tid; i < 2048; i += 256) s_warm[i] = i < (int)(KP >> 5) ? wb[i] : 0u;
+      wb = warmbits + (int64_t)b * (KP >> 5);
+      if constexpr (WLDS)
+        for (int i = tid; i < 2048; i += 256) s_warm[i] = i < (int)(KP >> 5) ? wb[i] : 0u;
       lam2 = lam2_b[b];
       Lq = qoff[b + 1] - qoff[b];
     }
@@ -2087,7 +2101,7 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         constexpr int SB = DPW / 2 < 8 ? DPW / 2 : 8;   // staging steps per batch (two documents per step)
 #pragma unroll 1
         for (int sb = 0; sb < DPW / 2; sb += SB) {
-          uint32_t cv[SB][4], c0[SB];
+          uint32_t cv[SB][4], c0[SB], wvg[(FLOOR && !WLDS) ? SB : 1][CPS];
           int nds[SB];
 #pragma unroll
           for (int j = 0; j < SB; ++j) {
@@ -2111,6 +2125,12 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
               }
             }
           }
+          if constexpr (FLOOR && !WLDS) {   // every bitmap word of the batch requested before the first one is used
+#pragma unroll
+            for (int j = 0; j < SB; ++j)
+#pragma unroll
+              for (int k = 0; k < CPS; ++k) wvg[j][k] = wb[cv[j][k] >> 5];
+          }
 #pragma unroll
           for (int j = 0; j < SB; ++j) {
             const int sl = 2 * (sb + j) + half;
@@ -2120,7 +2140,10 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
               // max): one ballot per code slot, the half-wave of the document counts its own 32 bits
               uint32_t wv[CPS];
 #pragma unroll
-              for (int k = 0; k < CPS; ++k) wv[k] = s_warm[(cv[j][k] >> 5) & 0x7FFu];
+              for (int k = 0; k < CPS; ++k) {
+                if constexpr (WLDS) wv[k] = s_warm[(cv[j][k] >> 5) & 0x7FFu];
+                else wv[k] = wvg[j][k];
+              }
               int base = 0;
               CT* dstc = &s_codes[wave][sl][0];
 #pragma unroll
@@ -2217,7 +2240,10 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
           fold(va);
         }
       }
-      uint32_t sum = 0, sum_lo = 0;
+      // sum = the upper bound; slo = the LOWER bound the histogram counts: a real token whose maximum is the table's bottom
+      // entry (1; with FLOOR also 0: none of its rows was requested) may score anything down to -s, i.e. 254 units lower
+      uint32_t sum = 0;
+      int slo = 0;
       if constexpr (FLOOR) {
         // byte k of lane jl is query token 16 jl + k; padding tokens (>= Lq) hold 0 in every row and stay 0.  (The floor is
         // fenced: left visible, its 16 per-byte values are hoisted out of the claim loop and live across the walk.)
@@ -2226,18 +2252,22 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
         asm volatile("" : "+v"(fl), "+v"(lq_here));
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          sum_lo += st[k];
+          slo += (int)st[k] - ((k < lq_here && st[k] <= 1u) ? 254 : 0);
           sum += max(st[k], k < lq_here ? fl : 0u);
         }
-#pragma unroll
-        for (int o = 1; o < LPD; o <<= 1) sum_lo += (uint32_t)__shfl_xor((int)sum_lo, o);
       } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sum += st[k];
+        for (int k = 0; k < 16; ++k) {
+          sum += st[k];
+          slo += (int)st[k] - (st[k] == 1u ? 254 : 0);   // real tokens hold >= 1 (the list is not empty), padding tokens 0
+        }
       }
 #pragma unroll
-      for (int o = 1; o < LPD; o <<= 1) sum += (uint32_t)__shfl_xor((int)sum, o);
-      if constexpr (!FLOOR) sum_lo = sum;
+      for (int o = 1; o < LPD; o <<= 1) {
+        sum += (uint32_t)__shfl_xor((int)sum, o);
+        slo += __shfl_xor(slo, o);
+      }
+      const uint32_t sum_lo = (uint32_t)max(slo, 0);
       if (valid && jl == 0) {
         U[pbase + i] = (uint16_t)sum;
         if (hb) atomicAdd(&s_hist[min(sum_lo >> hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
@@ -4503,7 +4533,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQT ==
 // padded by 16 B: the 1 KiB a wave reads per step spreads over all banks), which frees the registers for (a) the codes
 // two tiles ahead and the C-in rows ONE TILE AHEAD of their MFMAs, so the L2-miss latency of the row gather overlaps a
 // whole tile of matrix work, and (b) four waves per SIMD.  Arithmetic and summation order identical to exact_qct_kernel.
-template <int DIM, int NBITS, int SPLIT, int WPE /* waves per SIMD the register budget is cut for */>
+// HREG (round 5): the kernel is LDS-BANDWIDTH bound, not latency bound -- per k-step a wave reads 4 x 512 B of LUT entries and
+// 2 x 1 KiB of query fragments = 32 LDS cycles at 128 B / clk, i.e. 128 cycles for the four SIMDs of a CU against the 96 cycles
+// their 3 MFMAs take (PMC: LdsUtil 65 % + 29 % bank-conflict stalls, MFMA 40 % busy; replicating the LUT cannot help, the bytes
+// are the limit).  With HREG the hi fragments (half of the fragment bytes; all of them at precision 1) stay in 4 * NS VGPRs for
+// the whole kernel -- 24 LDS cycles per k-step, 96 per CU: level with the MFMA pipe -- and only the lo fragments are read per
+// k-step.  144 VGPRs: still three waves per SIMD.  Arithmetic unchanged (bit-identical scores).
+template <int DIM, int NBITS, int SPLIT, int WPE /* waves per SIMD the register budget is cut for */, bool HREG = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) exact_qcl_kernel(ExactP p) {
   constexpr int NS = DIM / 16;
   constexpr int PD = DIM * NBITS / 8;
@@ -4565,6 +4601,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   const __bf16* ql = &sQl[SPLIT == 3 ? li * QS + kk * (DIM / 2) : 0];
   const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP) + 128 * qt0 + 16 * kk;
   const uint32_t row_bytes = (uint32_t)LQP * 4u;
+  bf16x8 bhr[HREG ? NS : 1];
+  if constexpr (HREG) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bhr[s] = *reinterpret_cast<const bf16x8*>(qh + 8 * s);
+  }
   for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
     const int j = (bx * 4 + wave) * NP_EXACT_DPW + dd;
     if (j >= nsel) break;
@@ -4638,13 +4679,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
       // k-steps: the query fragments of step s+1 are read from LDS while step s runs; a scheduling barrier per step keeps
       // the compiler from hoisting every step's LDS reads (fragments + LUT words) to the top of the tile (that is the 64
       // VGPRs this kernel exists to give back)
-      bf16x8 bh_c = *reinterpret_cast<const bf16x8*>(qh), bl_c = bh_c;
+      bf16x8 bh_c, bl_c;
+      if constexpr (HREG) bh_c = bhr[0];
+      else bh_c = *reinterpret_cast<const bf16x8*>(qh);
+      bl_c = bh_c;
       if constexpr (SPLIT == 3) bl_c = *reinterpret_cast<const bf16x8*>(ql);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         bf16x8 bh_n = bh_c, bl_n = bl_c;
         if (s + 1 < NS) {
-          bh_n = *reinterpret_cast<const bf16x8*>(qh + 8 * (s + 1));
+          if constexpr (HREG) bh_n = bhr[s + 1];
+          else bh_n = *reinterpret_cast<const bf16x8*>(qh + 8 * (s + 1));
           if constexpr (SPLIT == 3) bl_n = *reinterpret_cast<const bf16x8*>(ql + 8 * (s + 1));
         }
         uint32_t wh[4], wl[4];

@@ -8,6 +8,7 @@
 #include "np_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 
@@ -271,7 +272,10 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
       for (int qt = 0; qt < p.LQP / 32; ++qt) {
         px.qt0 = qt;
         px.acc = qt > 0;
-        if (ix->tune.s6_lds == 2) {   // query fragments in LDS, C-in rows one tile ahead; registers cut for 4 waves per SIMD
+        if (ix->tune.s6_lds == 3) {   // hi query fragments in registers, lo ones in LDS: a quarter less LDS traffic per k-step
+          if (precision == 1) exact_qcl_kernel<DIM, NBITS, 1, 3, true><<<grid, 256, 0, st>>>(px);
+          else exact_qcl_kernel<DIM, NBITS, 3, 3, true><<<grid, 256, 0, st>>>(px);
+        } else if (ix->tune.s6_lds == 2) {   // query fragments in LDS, C-in rows one tile ahead; registers cut for 4 waves per SIMD
           if (precision == 1) exact_qcl_kernel<DIM, NBITS, 1, 4><<<grid, 256, 0, st>>>(px);
           else exact_qcl_kernel<DIM, NBITS, 3, 4><<<grid, 256, 0, st>>>(px);
         } else if (ix->tune.s6_lds == 1) {   // the same at 3 waves per SIMD (no spills)
@@ -523,6 +527,14 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   const bool use_planes = ix->tune.s4_planes && RB <= 64;
   const bool two_level = use_filter && ix->tune.s4_hot > 0 && KP / 8 <= 64 * 1024 && KP * RB < ((int64_t)1 << 31) &&
                          ix->ublock_stride > 0 && (use_planes || ix->ublock_stride <= old_cap);
+  // Share of the centroids whose rows the exact level still gathers (the rest: floored at Lambda2).  A token more is a floor
+  // more and a longer list has a higher maximum per token, so the best share RISES with the query length and FALLS with the
+  // documents' distinct-code count (tools/sim/s4_warm_sim.py: 50 % at 32 tokens / 68 codes, ~70 % at 48 tokens, ~30 % at 240
+  // codes per document; measured at 48 tokens: 10.10 k -> 10.47 k queries/s with 70 %).  s4_warm > 0 pins one value.
+  const int s4_warm = ix->tune.s4_warm > 0
+                          ? ix->tune.s4_warm
+                          : (int)std::min(1000.f, std::max(300.f, 500.f + 12.5f * (float)std::max(0, maxLq - 32) -
+                                                                      1.16f * std::max(0.f, ix->ulen_mean - 68.f)));
   const size_t slot_words = (size_t)(8 * (B + 1) + 1);   // hand-out slots + ticket of one filter launch
   if (use_filter) {
     NP_TRY(w.QCU.reserve((size_t)B * KP * RB));
@@ -638,7 +650,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     if (use_planes) {   // Lambda, the thresholds of the 8 planes and the hot bitmap in one launch, then the plane rows of the hot centroids
       hot_levels_kernel<<<dim3((unsigned)std::min<int64_t>(std::max<int64_t>((KP >> 5) / 256, 1), 16), B), 256, 0, st>>>(
           w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.cmaxu.as<uint8_t>(), KP, ix->tune.s4_pexp, w.ub_thr2.as<uint32_t>() + B,
-          w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>(), ix->tune.s4_warm, w.ub_thr2.as<uint32_t>() + 2 * B,
+          w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>(), s4_warm, w.ub_thr2.as<uint32_t>() + 2 * B,
           w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32));
       const dim3 pg((unsigned)std::min<int64_t>((KP + 2047) / 2048, 64), B);
       if (RB == 32)
@@ -783,21 +795,26 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       // instead of one query per XCD at a time (8 hand-out steps of ~25 us each for a handful of claims)
       // floor: the S2 list of the two-level filter with u16 codes -- rows of the centroids no query token is close to are
       // skipped, U = the floored upper bound, the histogram counts the lower bound (approx_ub_kernel, FLOOR)
-      const bool can_floor = two_level && use_planes && !ix->code_wide && oob && RB <= 64 && ix->tune.s4_warm < 1000;
+      const bool can_floor = two_level && use_planes && oob && RB <= 64 && s4_warm < 1000;
       auto launch_ub = [&](int lvl, const uint4* meta, const int32_t* begin, const int32_t* count, uint16_t* U, uint32_t* hist,
                            int count_tokens, int direct_wpq, bool floor_rows = false) {
         int32_t* sl = xslots(lvl);
         int32_t* tk = sl + 8 * (B + 1);
         const unsigned grid = direct_wpq > 0 ? (unsigned)(B * direct_wpq) : 8 * nbx;
         if (floor_rows && can_floor) {
-#define NP_LAUNCH_UBF(ROWB)                                                                                                   \
-  approx_ub_kernel<ROWB, uint16_t, 2, 1><<<grid, 256, 0, st>>>(                                                                 \
-      w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(), rp, r, max_rounds, (const uint16_t*)ix->d_ucodes,     \
+#define NP_LAUNCH_UBF(ROWB, CT)                                                                                               \
+  approx_ub_kernel<ROWB, CT, 2, 1><<<grid, 256, 0, st>>>(                                                                       \
+      w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes,           \
       w.qflag.as<uint32_t>(), cs->n_sel, U, hist, hshift, xcursor(lvl), sl, tk, B, ix->tune.ub_steal, w.ctr.as<Counters>(),      \
       count_tokens, direct_wpq, ix->tune.ub_static, w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32),                           \
       w.ub_thr2.as<uint32_t>() + 2 * B, d_qoff)
-          if (RB == 32) NP_LAUNCH_UBF(32);
-          else NP_LAUNCH_UBF(64);
+          if (!ix->code_wide) {
+            if (RB == 32) NP_LAUNCH_UBF(32, uint16_t);
+            else NP_LAUNCH_UBF(64, uint16_t);
+          } else {
+            if (RB == 32) NP_LAUNCH_UBF(32, uint32_t);
+            else NP_LAUNCH_UBF(64, uint32_t);
+          }
 #undef NP_LAUNCH_UBF
           return;
         }
@@ -830,7 +847,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
       // (per query the bracket is Lq + 2 with its OWN token count: padding tokens contribute exactly 0 to both sides, so the
       // slice's longest query bounds it -- 48-token queries in 64-token rows keep 50, not 66)
-      const int slack = maxLq + 2 + (batched ? 1 : 0);
+      // (that unit count follows gcut_kernel's bound e >= |G - R| = 1.5 (152 Lq + 2 Lq^2) 2^-24 s, in table units of s / 254:
+      // below one unit up to 64 tokens, four at 256)
+      const float lqf = (float)maxLq;
+      const int slack = maxLq + 2 +
+                        (batched ? std::max(1, (int)std::ceil(1.5f * (152.0f * lqf + 2.0f * lqf * lqf) * 5.9604645e-8f * 254.0f)) : 0);
       CutP cp{};
       cp.hshift = hshift;
       cp.all_src = w.cand_meta.as<uint4>();

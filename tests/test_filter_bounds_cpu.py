@@ -5,8 +5,14 @@ of its score reaches a threshold that rests on LOWER bounds of the n_sel-th best
 tests check the kernels against the oracle; this file checks the inequalities and the cut rule themselves on random
 instances, including the round-4 forms (bit planes, floored exact level), ragged query lengths and heavy ties:
 
-    lo(d) <= U(d) <= up(d),   U(d) <= U'(d) <= U''(d),   U - Lq - 1 <= 127.5 (approx / s + Lq) <= U + 1,
+    lo(d) <= L(d) <= U(d) <= up(d),   U(d) <= U'(d) <= U''(d),   L - Lq - 1 <= 254 approx / s <= U + 1,
     survivors of the three-step cut  >=  { d : approx(d) is among the n_sel largest (ties included) }.
+
+Round 5: the u8 table spans the POSITIVE scores only (u = floor(max(x, 0) / s * 254) + 1: twice the resolution of rounds
+2-4's table over [-s, s]).  The bottom entry u = 1 is then a clipped one -- the score may be anything down to -s -- so a
+LOWER bound charges 254 units for every real token whose maximum is the bottom entry: L(d) = U(d) - 254 #{q: max u = 1}.
+Thresholds rest on lower bounds (the histograms of approx_ub_kernel count them), cuts compare upper bounds; the instances
+below include documents of one or two codes, whose maxima against a query token are negative about as often as not.
 """
 import numpy as np
 import pytest
@@ -14,9 +20,20 @@ import pytest
 PLANES = 8
 
 
+SCALE = 254.0
+
+
 def u8_table(QC, s):
-    """np_kernels.h, qc_gemm epilogue: u = floor((x / s + 1) * 127.5) + 1 in [1, 255], monotone in x."""
-    return (np.floor((QC.astype(np.float32) / np.float32(s) + np.float32(1.0)) * np.float32(127.5)) + 1).astype(np.int64)
+    """np_kernels.h, qc_gemm epilogue: u = floor(max(x * (1 / s), 0) * 254) + 1 in [1, 254], monotone in x."""
+    inv = np.float32(1.0) / np.float32(s)
+    return (np.floor(np.maximum(QC.astype(np.float32) * inv, np.float32(0.0)) * np.float32(SCALE)) + 1).astype(np.int64)
+
+
+def clipped_charge(m, real=None):
+    """approx_ub_kernel: 254 units off the lower bound per real token whose maximum is the bottom entry (or, with the floor,
+    none of whose rows was requested: 0)."""
+    real = np.ones(m.shape, bool) if real is None else real
+    return 254 * int(((m <= 1) & real).sum())
 
 
 def lam_for_share(M, permille):
@@ -67,6 +84,7 @@ def bounds(QC, s, docs, hot_permille, warm_permille):
     t = plane_levels(lam, int(M.max()))
     approx = np.array([QC[:, c].max(axis=1).astype(np.float32).sum(dtype=np.float32) for c in docs])
     U = np.array([u[:, c].max(axis=1).sum() for c in docs])
+    Lb = np.array([u[:, c].max(axis=1).sum() - clipped_charge(u[:, c].max(axis=1)) for c in docs])   # signed: may be < 0
     Uh, Up, up, lo = [], [], [], []
     for c in docs:
         hot = c[M[c] > lam]
@@ -81,8 +99,8 @@ def bounds(QC, s, docs, hot_permille, warm_permille):
         kept = c[M[c] > lam2]
         km = u[:, kept].max(axis=1) if kept.size else np.zeros(Lq, np.int64)
         up.append(np.maximum(km, lam2).sum())
-        lo.append(km.sum())
-    return approx, U, np.array(Uh), np.array(Up), np.array(up), np.array(lo), lam, lam2
+        lo.append(km.sum() - clipped_charge(km))
+    return approx, U, Lb, np.array(Uh), np.array(Up), np.array(up), np.array(lo), lam, lam2
 
 
 def nth_largest(x, n):
@@ -94,25 +112,32 @@ def nth_largest(x, n):
 def test_bounds_are_ordered_and_the_cut_keeps_the_top(seed, hot, warm):
     rng = np.random.default_rng(1000 + seed)
     Lq = int(rng.integers(1, 33))
-    QC, s, docs = make_instance(rng, Lq=Lq, ties=(seed % 3 == 2))
-    approx, U, Uh, Up, up, lo, lam, lam2 = bounds(QC, s, docs, hot, warm)
+    # every other seed: documents of one or two codes, so that many per-token maxima are negative (clipped entries)
+    QC, s, docs = make_instance(rng, Lq=Lq, ties=(seed % 3 == 2), codes_per_doc=(1, 3) if seed % 2 else (3, 40))
+    approx, U, Lb, Uh, Up, up, lo, lam, lam2 = bounds(QC, s, docs, hot, warm)
     assert lam2 <= lam
     assert (U <= Uh).all() and (Uh <= Up).all(), "hot bound / plane bound must dominate the exact bound"
-    assert (lo <= U).all() and (U <= up).all(), "floored exact level: lower and upper bound"
-    # the bracket of the f32 score by the integer bound (np_kernels.h): z < 1 covers the rounding of u and of the f32 sum
-    scaled = 127.5 * (approx.astype(np.float64) / s + Lq)
-    assert (U - Lq - 1 <= scaled).all() and (scaled <= U + 1).all()
+    assert (lo <= Lb).all() and (Lb <= U).all() and (U <= up).all(), "floored exact level: lower and upper bound"
+    # the bracket of the f32 score by the integer bounds (np_kernels.h): z < 1 covers the rounding of u and of the f32 sum
+    scaled = SCALE * approx.astype(np.float64) / s
+    assert (Lb - Lq - 1 <= scaled).all() and (scaled <= U + 1).all()
+    if seed % 2:
+        assert (Lb < U).any(), "the instance was meant to hold clipped entries"
     slack = Lq + 2
+    # the kernels clamp a negative lower bound into histogram bin 0, and a threshold that reaches bin 0 means "the filter does
+    # not apply" (everything is kept): harmless, documents lumped at 0 only ever define a threshold of 0
+    Lb, lo = np.maximum(Lb, 0), np.maximum(lo, 0)
     for n_sel in (1, 7, 64, len(docs) + 5):
         true_top = approx >= nth_largest(approx, n_sel)              # ties included
-        # single-level filter (round 2)
-        keep1 = U >= nth_largest(U, n_sel) - slack
+        # single-level filter (round 2): the threshold counts lower bounds, the cut compares upper bounds
+        thr1 = nth_largest(Lb, n_sel) - slack
+        keep1 = (U >= thr1) | (thr1 <= 0)
         assert (keep1 | ~true_top).all()
         # three-step cut with the plane bound in front and the floored exact level behind (np_search.hip)
         S1 = Up >= nth_largest(Up, n_sel)
-        tau = nth_largest(U[S1], n_sel) - slack                      # S1 keeps its exact bound
+        tau = nth_largest(Lb[S1], n_sel) - slack                     # S1 keeps its exact bound (the histogram: its lower form)
         S2 = (Up >= tau) & ~S1
-        low = np.where(S1, U, lo)                                    # what the histogram counts
+        low = np.where(S1, Lb, lo)                                   # what the histogram counts
         upp = np.where(S1, U, up)                                    # what the cut compares
         L = S1 | S2
         tau2 = nth_largest(low[L], n_sel) - slack
@@ -120,7 +145,7 @@ def test_bounds_are_ordered_and_the_cut_keeps_the_top(seed, hot, warm):
         surv = L & (upp >= tau2)
         assert (surv | ~true_top).all(), f"n_sel={n_sel}: a document of the true top was cut"
         # and the filter is not vacuous on the larger instances
-        if n_sel == 7 and len(docs) >= 500 and not (seed % 3 == 2):
+        if n_sel == 7 and len(docs) >= 500 and not (seed % 3 == 2) and not (seed % 2):   # (one-code documents: thresholds reach 0)
             assert surv.sum() < len(docs)
 
 
@@ -129,7 +154,7 @@ def test_padding_tokens_are_neutral():
     of the real tokens unchanged (the slack follows the query's own token count, not the row width)."""
     rng = np.random.default_rng(7)
     QC, s, docs = make_instance(rng, Lq=20)
-    approx, U, Uh, Up, up, lo, lam, lam2 = bounds(QC, s, docs, 100, 500)
+    approx, U, Lb, Uh, Up, up, lo, lam, lam2 = bounds(QC, s, docs, 100, 500)
     u = u8_table(QC, s)
     upad = np.vstack([u, np.zeros((12, u.shape[1]), np.int64)])      # rows 20..31: padding
     M = upad.max(axis=0)
@@ -139,7 +164,8 @@ def test_padding_tokens_are_neutral():
         kept = c[M[c] > lam2]
         km = upad[:, kept].max(axis=1) if kept.size else np.zeros(32, np.int64)
         floor = np.where(np.arange(32) < 20, lam2, 0)                # approx_ub_kernel FLOOR: real tokens only
-        assert np.maximum(km, floor).sum() == up0 and km.sum() == lo0
+        assert np.maximum(km, floor).sum() == up0
+        assert km.sum() - clipped_charge(km, np.arange(32) < 20) == lo0      # padding tokens are never charged
 
 
 def test_plane_levels_are_increasing_and_end_at_the_top():

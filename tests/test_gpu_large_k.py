@@ -100,6 +100,21 @@ def test_production_path_selects_the_oracles_set(big):
                 assert np.array_equal(g.passage_ids, o.passage_ids) and np.array_equal(g.scores, o.scores)
         finally:
             hx.tune("s4_filter", 1)
+        # round 5: the floored exact level also runs on u32 code lists (K > 65536: the kept-centroid bitmap is looked up in
+        # memory instead of LDS) -- any share of kept centroids gives the same documents, order and scores, and a floor
+        # requests fewer table rows than no floor
+        rows = {}
+        try:
+            for warm in (1000, 300, 0):
+                hx.tune("s4_warm", warm)
+                res = hx.search_batch(qs, p)
+                rows[warm] = hx.last_stats["n_cand_codes"]
+                for i, (g, o) in enumerate(zip(res, got)):
+                    assert np.array_equal(g.passage_ids, o.passage_ids) and np.array_equal(g.scores, o.scores), f"{name} warm={warm} q{i}"
+        finally:
+            hx.tune("s4_warm", 0)
+        if hx.last_stats["n_level2"] > len(qs) * k:      # some S2 list is not empty: the floor had rows to skip
+            assert rows[300] < rows[1000], (name, rows)
     # default parameters of the configuration, top-10: ids identical to the oracle's, the source document first
     p = P(n_full_scores=4096, top_k=10, n_ivf_probe=32, centroid_score_threshold=0.4, centroid_batch_size=cbs)
     got = hx.search_batch(qs, p)

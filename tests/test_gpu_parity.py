@@ -90,7 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 60), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1), ("s4_planes", 1), ("s4_lpd", 2), ("s4_qm", 1), ("s4_warm", 500)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 60), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1), ("s4_planes", 1), ("s4_lpd", 2), ("s4_qm", 1), ("s4_warm", 0)):
         hx.tune(k, v)
 
 
@@ -226,10 +226,12 @@ def test_s6_kernel_variants_identical(mid, tuned):
     for prec in (2, 1):
         p = P(n_full_scores=1024, top_k=32, n_ivf_probe=16, precision=prec)
         ref = None
-        for xcd, rep, steal in ((1, 0, 16384), (0, 0, 1), (0, 0, 0x7FFFFFFF), (1, 1, 16384), (0, 2, 16384)):
+        for xcd, rep, steal in ((1, 0, 16384), (0, 0, 1), (0, 0, 0x7FFFFFFF), (1, 1, 16384), (0, 2, 16384), (1, 3, 16384), (1, 4, 16384)):
             hx.tune("s6_xcd", xcd)
             hx.tune("ub_steal", steal)
-            hx.tune("s6_lds", 0 if rep == 0 else 1)      # query fragments in registers (exact_qct_kernel) or in LDS (exact_qcl_kernel)
+            # query fragments in registers (exact_qct_kernel), in LDS (exact_qcl_kernel; 4: the 4-waves-per-SIMD instantiation)
+            # or hi in registers / lo in LDS (round 5: exact_qcl_kernel<..., HREG>)
+            hx.tune("s6_lds", {0: 0, 1: 1, 2: 1, 3: 3, 4: 2}[rep])
             hx.tune("s6_tiles", 0 if rep == 2 else 1)    # multi-tile kernels or one launch per 32-token query tile
             got = hx.search_batch(qs[:24], p)
             if ref is None:
@@ -351,7 +353,7 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
         assert hx.last_stats["n_cand_codes"] < rows_full, (hx.last_stats["n_cand_codes"], rows_full, lvl2)
     for g, r in zip(part, full):
         assert np.array_equal(g.passage_ids, r.passage_ids) and np.array_equal(g.scores, r.scores)
-    hx.tune("s4_warm", 500)
+    hx.tune("s4_warm", 0)
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got[:8], orc):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
