@@ -213,6 +213,7 @@ def main():
                               "JSON doclens, ivf.npy): seconds until the handle is searchable, derived structures included")
     if a.hot >= 0:
         ix.tune("s4_hot", a.hot)
+        ix.tune("s4_hot_auto", 0)      # exactly this share, whatever the candidate count
     if a.s1_split:
         ix.tune("s1_split", 1)
     s1_split = (a.s1_split or os.environ.get("NP_S1_SPLIT", "0") not in ("", "0")) and a.precision >= 1 and \

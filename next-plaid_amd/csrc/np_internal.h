@@ -129,6 +129,9 @@ struct Tuning {
                          // 11.9 M at 60 / 100 / 150) but more plane rows and walk steps per document in the hot kernel.  With the
                          // floored exact level (s4_warm) behind it, 10 M documents: 40 / 60 / 80 / 100 / 150 -> 18.3 / 18.6 / 18.4 /
                          // 17.8 / 16.6 k queries/s (round 3, byte maxima and every row at the exact level: 100 was best)
+  int s4_hot_auto = 200000;   // candidates per query up to which s4_hot applies as given; beyond, the share falls with the
+                         // candidate count^(-2/3), never below 8 per mille (hot_levels_kernel; 0 = s4_hot always).  The REST
+                         // API's default regime (t_cs = None, nprobe 8: 2 M candidates per query at 10 M documents) wants ~13
   int s4_planes = 1;     // first filter level in bit-plane form (approx_hotp_kernel: 8 planes per hot centroid, OR + weighted popcount
                          // instead of 32 byte maxima per table row); 0 = approx_hot_kernel.  Read at OPEN too: with it the list blocks
                          // may be up to 512 bytes (corpora with long distinct-code lists), which approx_hot_kernel cannot stage
@@ -136,6 +139,7 @@ struct Tuning {
                          // CU hide the latency of the block loads), 2: claims of 32.  512-byte blocks always take 4
   int s4_pnbx = 96;      // ... workgroups per XCD (3 per CU at 42 KB of LDS each with 2 lanes per document; 160 = 5 per CU with 4)
   int s4_qm = 1;         // ... a lane's hot codes as a position mask in registers (1) or compacted in place by LDS writes (0)
+  int s4_rs = 0;         // ... the next claim's list blocks travel in registers during the whole current claim (approx_hotp_kernel RS)
   int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
   int s4_warm = 0;       // ... per-mille of the centroids whose rows the exact level still gathers for the S2 list (the rest: floored
                          // at Lambda2; approx_ub_kernel FLOOR); 1000 = every row; 0 = by query length and list length (np_search.hip)

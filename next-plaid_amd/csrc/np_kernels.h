@@ -2873,7 +2873,10 @@ __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ hotbits,
                                                          int warm_permille /* >= 1000: no second threshold */,
                                                          uint32_t* __restrict__ lam2_out /* [B] Lambda2 (floor of the exact level) */,
-                                                         uint32_t* __restrict__ warmbits /* [B][KP / 32] bit c = M[c] > Lambda2 */) {
+                                                         uint32_t* __restrict__ warmbits /* [B][KP / 32] bit c = M[c] > Lambda2 */,
+                                                         const int32_t* __restrict__ n_cand = nullptr /* [B]: scale the hot share by the
+                                                                                                         query's candidate count */,
+                                                         int hot_ref = 0 /* candidates up to which hot_permille applies as given */) {
   // grid (blocks, B): every block derives Lambda from the 256-bin histogram itself (as hot_lam_kernel: the smallest level
   // with at most hot_permille of the centroids above it) and builds its slice of the bitmap; block 0 publishes Lambda and
   // the thresholds.  (One block per query took 37 us at K = 2^16, serial in the 64 KB of maxima.)
@@ -2895,6 +2898,16 @@ __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restr
   if (lane == 0) s_wsum[wave] = suf;
   __syncthreads();
   for (int k = wave + 1; k < 4; ++k) suf += s_wsum[k];
+  // Round 5: the hot share follows the query's candidate count.  Every candidate pays the first level in proportion to the
+  // share h (plane rows and walk steps), while what a larger h buys -- fewer documents at the exact level, ~ 1 / sqrt(h) -- does
+  // not grow with the candidates: minimising  t1 n h + c / sqrt(h)  gives  h ~ n^(-2/3).  Measured at 10 M documents: 186 k
+  // candidates per query (t_cs = 0.4) are best served by 40-80 per mille, 2.06 M (the REST API's default, t_cs = None with
+  // nprobe 8) by 10-30: S4 15.8 / 11.7 / 10.5 ms at 120 / 60 / 30.
+  if (n_cand != nullptr && hot_ref > 0) {
+    const float nq = (float)max(n_cand[blockIdx.y], 1);
+    if (nq > (float)hot_ref)
+      hot_permille = max(min(hot_permille, 8), (int)((float)hot_permille * __powf((float)hot_ref / nq, 0.6666667f)));
+  }
   const uint64_t limit = (uint64_t)K * (uint64_t)hot_permille / 1000u;
   const bool ok = v >= 1 && (uint64_t)suf <= limit;
   const int cnt = (int)__popcll(__ballot(ok));
@@ -3023,7 +3036,15 @@ __global__ void __launch_bounds__(256) hot_planes_kernel(const uint8_t* __restri
 
 template <int RB, typename CT, int LPD, int PF /* walk steps in flight ahead of the prefetch: 1 or 2 */,
           int DPI /* documents per staging instruction: 4 (blocks <= 240 B), 2 (<= 496 B), 1 */,
-          int QM /* hot codes of a lane: 0 = compacted in place over its share (LDS writes), 1 = a 64-bit position mask in registers */>
+          int QM /* hot codes of a lane: 0 = compacted in place over its share (LDS writes), 1 = a 64-bit position mask in registers */,
+          int RS = 0 /* round 5: the NEXT claim's blocks travel in REGISTERS (DPW / DPI x 16 bytes per lane) from the moment this
+                        claim's rows are in LDS, i.e. during its whole scan, pops, walk and bound, and are written to the (single)
+                        row buffer when the walk has read its last code.  With LDS-direct staging the blocks can only be requested
+                        once the rows are free -- right behind the first walk steps' row requests -- so all that overlaps their
+                        ~3 us from HBM is the fold and the bound, and a second LDS buffer is no way out: the compiler orders every
+                        LDS read behind an outstanding LDS-direct load of the same (dynamic) array.  vmcnt is in order, so the first
+                        fold of a claim now also waits for the next claim's blocks -- by then they have been under way for the
+                        whole scan.  +32 VGPRs, the LDS footprint and the three workgroups per CU stay */>
 __global__ void __launch_bounds__(256) approx_hotp_kernel(
     const uint32_t* __restrict__ planes /* [B][KP][RB / 4] */, int64_t K, int64_t KP, const uint32_t* __restrict__ hotbits /* [B][KP / 32] */,
     const uint32_t* __restrict__ lam_b, const uint32_t* __restrict__ lev /* [B][16] */,
@@ -3156,7 +3177,33 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
         }
       }
     };
+    // RS: the packed block loads of a claim into registers (returns false when the claim's ids span too many blocks for the
+    // 32-bit offsets: that claim takes the LDS-direct path when the rows are free), and their way into the rows
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NSI = RS ? DPW / DPI : 1;          // staging instructions per claim
+    u32x4 nb[NSI];
+    auto stage_regs = [&](uint32_t dv) -> bool {
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 63);
+      if (!((uint64_t)(d1 - d0) * (uint64_t)stride_b < 0x7FFF0000ull && d1 >= d0)) return false;
+      const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<CT*>(codes) + (int64_t)d0 * ublock_stride, 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < NSI; ++k) {
+        const uint32_t dj = (uint32_t)__shfl((int)dv, LPD * (k * DPI + sslot));
+        const uint32_t voff = sslot < DPI ? (dj - d0) * (uint32_t)stride_b + 16u * (uint32_t)spiece : 0xFFFFFFF0u;
+        nb[k] = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)voff, 0, 0);
+      }
+      return true;
+    };
+    auto rows_from_regs = [&]() {
+      // the same bytes at the same places as the LDS-direct form: 16 bytes per lane at row base + 16 x lane, idle lanes write
+      // their zeros onto the head of the rows the next instruction fills (program order) / the slack behind the last row
+#pragma unroll
+      for (int k = 0; k < NSI; ++k)
+        *reinterpret_cast<u32x4*>(s_rows + (size_t)k * DPI * row_b + 16 * lane) = nb[k];
+    };
     uint32_t did = i0 + grp < n ? idb[i0 + grp] : id_last;
+    bool in_regs = false;                            // wave-uniform: the next claim's blocks are in nb[]
     if (i0 < n) stage(did);
     for (;;) {
       if (i0 >= n) break;
@@ -3167,6 +3214,10 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
       __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): the claim's rows are in LDS
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if constexpr (RS) {
+        in_regs = false;
+        if (more && !(probe & 4)) in_regs = stage_regs(did_next);   // under way during the whole claim
+      }
       const uint4 hd = *reinterpret_cast<const uint4*>(row);   // {#distinct, doc length, overflow index, 0}
       const int nd = valid ? (int)hd.x : 0;
       const bool ovf = nd > fit;
@@ -3421,7 +3472,14 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
         const bool last_window = p0 + fit >= nmax;   // wave-uniform
         if (!last_window) walk(false);
       }
-      walk(more);                                    // the last window's queue; the next claim's blocks ride behind its first step
+      if constexpr (RS) {
+        walk(false);                                 // the rows' last reader
+        __builtin_amdgcn_wave_barrier();
+        if (in_regs) rows_from_regs();               // (the loads were waited for by the walk's first fold: vmcnt is in order)
+        else if (more) stage(did_next);
+      } else {
+        walk(more);                                  // the last window's queue; the next claim's blocks ride behind its first step
+      }
       // ---- bound: OR across the document's lanes, weighted popcount
 #pragma unroll
       for (int k = 0; k < NS; ++k) {

@@ -647,19 +647,6 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     hot_prep_kernel<<<dim3((unsigned)std::min<int64_t>((KP + 255) / 256, 64), B), 256, 0, st>>>(
         w.QCU.as<uint8_t>(), ix->K, KP, RB, w.cmaxu.as<uint8_t>(), w.chist.as<uint32_t>());
     if (!use_planes) hot_lam_kernel<<<B, 256, 0, st>>>(w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.ub_thr2.as<uint32_t>() + B);
-    if (use_planes) {   // Lambda, the thresholds of the 8 planes and the hot bitmap in one launch, then the plane rows of the hot centroids
-      hot_levels_kernel<<<dim3((unsigned)std::min<int64_t>(std::max<int64_t>((KP >> 5) / 256, 1), 16), B), 256, 0, st>>>(
-          w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.cmaxu.as<uint8_t>(), KP, ix->tune.s4_pexp, w.ub_thr2.as<uint32_t>() + B,
-          w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>(), s4_warm, w.ub_thr2.as<uint32_t>() + 2 * B,
-          w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32));
-      const dim3 pg((unsigned)std::min<int64_t>((KP + 2047) / 2048, 64), B);
-      if (RB == 32)
-        hot_planes_kernel<32><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
-                                                  w.levels.as<uint32_t>(), w.planes.as<uint32_t>());
-      else
-        hot_planes_kernel<64><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
-                                                  w.levels.as<uint32_t>(), w.planes.as<uint32_t>());
-    }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[1], st));
 
@@ -755,6 +742,22 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     }
     plan_rounds_kernel<<<1, 256, 0, st>>>(w.chunk_counts.as<int32_t>(), nchunks, B, pool, max_rounds, rp,
                                           w.ctr.as<Counters>());
+    // Lambda, the thresholds of the 8 planes and the hot bitmap in one launch, then the plane rows of the hot centroids -- AFTER
+    // the round plan: the hot share of a query follows its candidate count (hot_levels_kernel), which S3 has just counted
+    if (two_level && use_planes) {
+      hot_levels_kernel<<<dim3((unsigned)std::min<int64_t>(std::max<int64_t>((KP >> 5) / 256, 1), 16), B), 256, 0, st>>>(
+          w.chist.as<uint32_t>(), ix->K, ix->tune.s4_hot, w.cmaxu.as<uint8_t>(), KP, ix->tune.s4_pexp, w.ub_thr2.as<uint32_t>() + B,
+          w.levels.as<uint32_t>(), w.hotbits.as<uint32_t>(), s4_warm, w.ub_thr2.as<uint32_t>() + 2 * B,
+          w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32), ix->tune.s4_hot_auto ? w.n_cand.as<int32_t>() : nullptr,
+          ix->tune.s4_hot_auto);
+      const dim3 pg((unsigned)std::min<int64_t>((KP + 2047) / 2048, 64), B);
+      if (RB == 32)
+        hot_planes_kernel<32><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
+                                                  w.levels.as<uint32_t>(), w.planes.as<uint32_t>());
+      else
+        hot_planes_kernel<64><<<pg, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, w.cmaxu.as<uint8_t>(), w.ub_thr2.as<uint32_t>() + B,
+                                                  w.levels.as<uint32_t>(), w.planes.as<uint32_t>());
+    }
   }
   SelectP sp;
   sp.approx = w.approx.as<float>();
@@ -896,7 +899,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     else if (RB == 128) NP_LAUNCH_HOT(128, CT); \
     else NP_LAUNCH_HOT(256, CT);                \
   } while (0)
-#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV, QMV)                                                                         \
+#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV, QMV, RSV)                                                                     \
   do {                                                                                                                   \
     const size_t bm = sizeof(CT) == 2 ? 0 : (size_t)(((KP >> 5) + 3) & ~(int64_t)3) * 4;   /* u16 codes: static bitmap */   \
     /* idle lanes of the last packed staging instruction write 16 B each past the rows it fills (1 KiB per instruction);     \
@@ -905,9 +908,9 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     const int slack = (int)std::max<int64_t>(256, 1024 - (int64_t)(DPIV) * (int64_t)rowb);                                   \
     const size_t dynp = bm + (size_t)4 * ((64 / LPDV) * rowb + (size_t)slack);                                               \
     if (dynp > 16 * 1024)                                                                                                \
-      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV>),           \
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV, RSV>), \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynp));                                \
-    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV><<<8 * pnbx, 256, dynp, st>>>(                                           \
+    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV, RSV><<<8 * pnbx, 256, dynp, st>>>(                 \
         w.planes.as<uint32_t>(), ix->K, KP, w.hotbits.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.levels.as<uint32_t>(), \
         w.cand.as<uint32_t>(), w.cand_meta.as<uint4>(), ix->ublock_stride, (int64_t)ix->n_docs * ix->ublock_stride,        \
         w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), d_qoff, cs->n_sel,     \
@@ -921,12 +924,13 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   do {                                                                  \
     const int sb = ix->ublock_stride * (int)sizeof(CT);                 \
     if (plpd == 2) {                                                    \
-      if (sb <= 240 && ix->tune.s4_qm) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 1);   \
-      else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 0);         \
-      else NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 2, 0);                        \
-    } else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 4, 0);         \
-    else if (sb <= 496) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 2, 0);           \
-    else NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 1, 0);                          \
+      if (sb <= 240 && ix->tune.s4_qm && ix->tune.s4_rs) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 1, 1);   \
+      else if (sb <= 240 && ix->tune.s4_qm) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 1, 0);   \
+      else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 0, 0);         \
+      else NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 2, 0, 0);                        \
+    } else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 4, 0, 0);         \
+    else if (sb <= 496) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 2, 0, 0);           \
+    else NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 1, 0, 0);                          \
   } while (0)
           const int plpd = (ix->ublock_stride > old_cap || ix->tune.s4_lpd == 4) ? 4 : 2;
           const unsigned pnbx = (unsigned)ix->tune.s4_pnbx;   // workgroups per XCD of the plane kernel

@@ -19,13 +19,15 @@ S1, S2, S3, S4, S5, S6, S7 = "qc_gemm(S1)", "probe(S2)", "candidates(S3)", "appr
 STAGES = (S1, S2, S3, S4, S5, S6, S7)
 
 STAGE = {
-    # ev[0] .. ev[1]: queries -> Q.C^T, the u8 table, the hot level's thresholds / bitmaps / plane rows
+    # ev[0] .. ev[1]: queries -> Q.C^T, the u8 table, its per-centroid maxima
     "clear_regions_kernel": S1, "pad_rows_kernel": S1, "prep_queries_kernel": S1, "qc_gemm_kernel": S1, "qc_gemm_b3_kernel": S1,
-    "hot_prep_kernel": S1, "hot_lam_kernel": S1, "hot_levels_kernel": S1, "hot_planes_kernel": S1,
+    "hot_prep_kernel": S1, "hot_lam_kernel": S1,
     # ev[1] .. ev[2]: subset pre-filter, per-token top-nprobe, threshold, cell list
     "subset_kernel": S2, "subset_nprobe_kernel": S2, "masked_gmax_kernel": S2, "probe_mark_kernel": S2, "probe_finish_kernel": S2,
     # ev[2] .. ev[3]: posting-list union, round plan, compaction
+    # (round 5: the hot level's thresholds / bitmaps / plane rows follow the round plan -- the hot share depends on the candidate count)
     "mark_slices_kernel": S3, "mark_candidates_kernel": S3, "count_chunks_kernel": S3, "plan_rounds_kernel": S3, "compact_kernel": S3,
+    "hot_levels_kernel": S3, "hot_planes_kernel": S3,
     # ev[3] .. ev[4]: the two-level upper-bound filter and the exact approximate scores of the survivors
     "approx_hotp_kernel": S4, "approx_hot_kernel": S4, "approx_ub_kernel": S4, "ub_thr_kernel": S4, "ub_cut_kernel": S4,
     "approx_xcd_kernel": S4, "approx_kernel": S4, "approx_stream_kernel": S4, "gcut_kernel": S4, "approx_matvec_kernel": S4,
