@@ -82,6 +82,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "s3_slices") t->s3_slices = value != 0;
   else if (n == "s4_warm") t->s4_warm = clamp(value, 0, 1000);
   else if (n == "s4_rs") t->s4_rs = clamp(value, 0, 1);
+  else if (n == "s3_bisect") t->s3_bisect = clamp(value, 0, 1);
   else if (n == "s4_hot_auto") t->s4_hot_auto = clamp(value, 0, 0x7fffffff);
   else if (n == "ub_nt") t->ub_nt = value < 0 || value > 2 ? 0 : value;
   else if (n == "ub_steal") t->ub_steal = value < 1 ? 1 : value;
@@ -105,7 +106,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
 void read_tuning_env(Tuning* t) {
   static const char* const knobs[][2] = {
       {"NP_S4_MODE", "s4_mode"}, {"NP_S4_MINB", "s4_minb"}, {"NP_S4_NBX", "s4_nbx"}, {"NP_S4_SWZ", "s4_swz"},
-      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S4_LPD", "s4_lpd"}, {"NP_S4_QM", "s4_qm"}, {"NP_S4_PNBX", "s4_pnbx"}, {"NP_S4_WARM", "s4_warm"}, {"NP_S4_RS", "s4_rs"}, {"NP_S4_HOT_AUTO", "s4_hot_auto"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
+      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S4_LPD", "s4_lpd"}, {"NP_S4_QM", "s4_qm"}, {"NP_S4_PNBX", "s4_pnbx"}, {"NP_S4_WARM", "s4_warm"}, {"NP_S4_RS", "s4_rs"}, {"NP_S3_BISECT", "s3_bisect"}, {"NP_S4_HOT_AUTO", "s4_hot_auto"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
       {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"}, {"NP_S1_SPLIT", "s1_split"},
       {"NP_EXACT_ROWMAX", "exact_rowmax"}};
   for (const auto& k : knobs) {
@@ -1064,19 +1065,26 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
       }
     for (int64_t c = 0; c < ix->K; ++c) ioff[c + 1] += ioff[c];
     std::vector<uint32_t> ivf((size_t)ioff[ix->K]);
+    std::vector<int> unsorted((size_t)NT, 0);   // the crate writes ascending unique ids (index.rs:479-504); S3 relies on it only if true
     run([&](int t) {   // pass 2
       int64_t c0, c1;
       range(t, &c0, &c1);
       for (int64_t c = c0; c < c1; ++c) {
         uint32_t* out = ivf.data() + ioff[c];
         const char* src = (const char*)h.ivf + lstart[c] * 8;
+        int64_t prev = -1;
         for (int64_t i = 0, l = lstart[c + 1] - lstart[c]; i < l; ++i) {
           int64_t id;
           memcpy(&id, src + i * 8, 8);
+          if (id <= prev) unsorted[(size_t)t] = 1;
+          prev = id;
           if (whole || (id >= sb && id < se)) *out++ = (uint32_t)(id - sb);
         }
       }
     });
+    ix->ivf_sorted = true;
+    for (int t = 0; t < NT; ++t)
+      if (unsorted[(size_t)t]) ix->ivf_sorted = false;
     ix->ivf_size = (int64_t)ivf.size();
     NP_TRY(dev_alloc(&ix->d_ivf, ivf.size(), &ix->device_bytes));
     if (!ivf.empty()) NP_HIP(hipMemcpy(ix->d_ivf, ivf.data(), ivf.size() * 4, hipMemcpyHostToDevice));
@@ -1316,6 +1324,7 @@ static int build_ivf_from_ucodes(DeviceIndex* ix, const int64_t* d_uoff) {
   NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
   NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
   NP_HIP(hipDeviceSynchronize());
+  ix->ivf_sorted = true;   // (code, document) pairs radix-sorted, ranges ascending: every list ascends
   return NP_OK;
 }
 

@@ -122,6 +122,7 @@ struct Tuning {
   int s4_minb = 8;       // smallest batch that takes the per-XCD kernels
   int s4_nbx = 128;      // workgroups per XCD
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
+  int s3_bisect = 1;     // S3: a bitmap range reads only its part of every (ascending) posting list instead of sweeping all of it
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
   int s4_hot = 60;       // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level
@@ -130,8 +131,8 @@ struct Tuning {
                          // floored exact level (s4_warm) behind it, 10 M documents: 40 / 60 / 80 / 100 / 150 -> 18.3 / 18.6 / 18.4 /
                          // 17.8 / 16.6 k queries/s (round 3, byte maxima and every row at the exact level: 100 was best)
   int s4_hot_auto = 200000;   // candidates per query up to which s4_hot applies as given; beyond, the share falls with the
-                         // candidate count^(-2/3), never below 8 per mille (hot_levels_kernel; 0 = s4_hot always).  The REST
-                         // API's default regime (t_cs = None, nprobe 8: 2 M candidates per query at 10 M documents) wants ~13
+                         // candidate count^(-1/3), never below 8 per mille (hot_levels_kernel; 0 = s4_hot always).  The REST
+                         // API's default regime (t_cs = None, nprobe 8: 2 M candidates per query at 10 M documents) wants ~30
   int s4_planes = 1;     // first filter level in bit-plane form (approx_hotp_kernel: 8 planes per hot centroid, OR + weighted popcount
                          // instead of 32 byte maxima per table row); 0 = approx_hot_kernel.  Read at OPEN too: with it the list blocks
                          // may be up to 512 bytes (corpora with long distinct-code lists), which approx_hot_kernel cannot stage
@@ -199,6 +200,7 @@ struct DeviceIndex {
   uint32_t* d_ivf = nullptr;
   int64_t* d_ivf_offsets = nullptr;
   int64_t ivf_size = 0;
+  bool ivf_sorted = false;        // every posting list ascends (what the crate writes): S3 may bisect a list for a document range
   size_t device_bytes = 0;
   np_open_opts opts{};
   // per-context scratch budget the planner uses.  A caller-given workspace_bytes is kept as it is; the default (what the device

@@ -1010,7 +1010,11 @@ __global__ void __launch_bounds__(1024) mark_slices_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ ivf,
                                                            const uint32_t* __restrict__ subset_bits, int64_t NW,
                                                            int slice_chunks, int nchunks, uint32_t* __restrict__ docbits,
-                                                           int32_t* __restrict__ chunk_counts, Counters* ctr) {
+                                                           int32_t* __restrict__ chunk_counts, Counters* ctr,
+                                                           int sorted_lists /* every posting list ascends: a block reads only the
+                                                                               part of each list inside its range (two bisections per
+                                                                               list) instead of sweeping all of it -- with ns ranges
+                                                                               per query the sweep reads every list ns times */) {
   extern __shared__ uint32_t s_bits[];   // slice_chunks * NP_CHUNK_WORDS words
   __shared__ int64_t s_start[NP_MARK_CELLS];
   __shared__ uint32_t s_len[NP_MARK_CELLS];
@@ -1029,11 +1033,31 @@ __global__ void __launch_bounds__(1024) mark_slices_kernel(const uint32_t* __res
     uint32_t len = 0;
     if (tid < m) {
       const uint32_t c = cells[(int64_t)b * KP + c0 + tid];
-      const int64_t s0 = ivf_off[c];
+      int64_t s0 = ivf_off[c];
       len = (uint32_t)(ivf_off[c + 1] - s0);
+      ids += len;
+      if (sorted_lists && gridDim.x > 1 && len > 64u) {
+        // entries with lo <= id < lo + span: [first id >= lo, first id >= lo + span)
+        const uint32_t* L = ivf + s0;
+        uint32_t a = 0, z = len;
+        while (a < z) {
+          const uint32_t mid = (a + z) >> 1;
+          if (L[mid] < lo) a = mid + 1;
+          else z = mid;
+        }
+        const uint32_t first = a;
+        const uint64_t hi64 = (uint64_t)lo + (uint64_t)span;
+        z = len;
+        while (a < z) {
+          const uint32_t mid = (a + z) >> 1;
+          if ((uint64_t)L[mid] < hi64) a = mid + 1;
+          else z = mid;
+        }
+        s0 += first;
+        len = a - first;
+      }
       s_start[tid] = s0;
       s_len[tid] = len;
-      ids += len;
     }
     // exclusive scan of the item counts over the block
     const uint32_t items = (len + 511u) >> 9;
@@ -2899,14 +2923,14 @@ __global__ void __launch_bounds__(256) hot_levels_kernel(const uint32_t* __restr
   __syncthreads();
   for (int k = wave + 1; k < 4; ++k) suf += s_wsum[k];
   // Round 5: the hot share follows the query's candidate count.  Every candidate pays the first level in proportion to the
-  // share h (plane rows and walk steps), while what a larger h buys -- fewer documents at the exact level, ~ 1 / sqrt(h) -- does
-  // not grow with the candidates: minimising  t1 n h + c / sqrt(h)  gives  h ~ n^(-2/3).  Measured at 10 M documents: 186 k
-  // candidates per query (t_cs = 0.4) are best served by 40-80 per mille, 2.06 M (the REST API's default, t_cs = None with
-  // nprobe 8) by 10-30: S4 15.8 / 11.7 / 10.5 ms at 120 / 60 / 30.
+  // share h (plane rows and walk steps), while what a larger h buys -- fewer documents at the exact level -- does not grow with
+  // the candidates, so the best share falls as they grow.  Measured at 10 M documents: 186 k candidates per query (t_cs = 0.4)
+  // are best served by 40-80 per mille; 2.06 M (the REST API's default, t_cs = None with nprobe 8) by ~30: 3.5 / 4.5 / 4.9 /
+  // 4.4 / 3.2 k queries/s at 8 / 15 / 30 / 60 / 120.  h = h0 (n_ref / n)^(1/3) passes through both.
   if (n_cand != nullptr && hot_ref > 0) {
     const float nq = (float)max(n_cand[blockIdx.y], 1);
     if (nq > (float)hot_ref)
-      hot_permille = max(min(hot_permille, 8), (int)((float)hot_permille * __powf((float)hot_ref / nq, 0.6666667f)));
+      hot_permille = max(min(hot_permille, 8), (int)((float)hot_permille * __powf((float)hot_ref / nq, 0.3333333f)));
   }
   const uint64_t limit = (uint64_t)K * (uint64_t)hot_permille / 1000u;
   const bool ok = v >= 1 && (uint64_t)suf <= limit;
@@ -3332,7 +3356,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
             u32x4 v0[G][RB / 16], v1[PF == 2 ? G : 1][RB / 16];
             issue(0, v0);
             if constexpr (PF == 2) issue(G, v1);
-            stage(did_next);
+            if constexpr (!RS) stage(did_next);
             fold(v0);
             if constexpr (PF == 2) fold(v1);
           }
@@ -3349,7 +3373,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
           u32x4 v0[G][RB / 16], v1[PF == 2 ? G : 1][RB / 16];
           issue(0, v0);
           if constexpr (PF == 2) issue(G, v1);
-          stage(did_next);
+          if constexpr (!RS) stage(did_next);
           fold(v0);
           if constexpr (PF == 2) fold(v1);
         }
@@ -3473,7 +3497,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
         if (!last_window) walk(false);
       }
       if constexpr (RS) {
-        walk(false);                                 // the rows' last reader
+        walk(true);                                  // the rows' last reader (the first PF steps' rows requested together)
         __builtin_amdgcn_wave_barrier();
         if (in_regs) rows_from_regs();               // (the loads were waited for by the walk's first fold: vmcnt is in order)
         else if (more) stage(did_next);

@@ -731,7 +731,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
                                                               ix->d_ivf_offsets, ix->d_ivf,
                                                               have_subset ? w.subset_bits.as<uint32_t>() : nullptr, NW,
                                                               slice_chunks, nchunks, w.docbits.as<uint32_t>(),
-                                                              w.chunk_counts.as<int32_t>(), w.ctr.as<Counters>());
+                                                              w.chunk_counts.as<int32_t>(), w.ctr.as<Counters>(),
+                                                              (ix->ivf_sorted && ix->tune.s3_bisect) ? 1 : 0);
     } else {
       mark_candidates_kernel<<<dim3(128, B), 256, 0, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
                                                            ix->d_ivf_offsets, ix->d_ivf,
