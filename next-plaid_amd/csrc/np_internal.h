@@ -140,10 +140,10 @@ struct Tuning {
                          // CU hide the latency of the block loads), 2: claims of 32.  512-byte blocks always take 4
   int s4_pnbx = 96;      // ... workgroups per XCD (3 per CU at 42 KB of LDS each with 2 lanes per document; 160 = 5 per CU with 4)
   int s4_qm = 1;         // ... a lane's hot codes as a position mask in registers (1) or compacted in place by LDS writes (0)
-  int s4_rs = 0;         // ... the next claim's list blocks travel in registers during the whole current claim (approx_hotp_kernel RS)
   int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
   int s4_warm = 0;       // ... per-mille of the centroids whose rows the exact level still gathers for the S2 list (the rest: floored
                          // at Lambda2; approx_ub_kernel FLOOR); 1000 = every row; 0 = by query length and list length (np_search.hip)
+  int ub_ncut = 32;      // workgroups per query of the cut kernels (each appends 2048 records per step: latency-bound per step)
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim
                          // on a line all XCDs share costs ~50 ns, serialised): 2.06 -> 1.68 ms at 10 M documents

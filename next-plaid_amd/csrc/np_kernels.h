@@ -3060,15 +3060,13 @@ __global__ void __launch_bounds__(256) hot_planes_kernel(const uint8_t* __restri
 
 template <int RB, typename CT, int LPD, int PF /* walk steps in flight ahead of the prefetch: 1 or 2 */,
           int DPI /* documents per staging instruction: 4 (blocks <= 240 B), 2 (<= 496 B), 1 */,
-          int QM /* hot codes of a lane: 0 = compacted in place over its share (LDS writes), 1 = a 64-bit position mask in registers */,
-          int RS = 0 /* round 5: the NEXT claim's blocks travel in REGISTERS (DPW / DPI x 16 bytes per lane) from the moment this
-                        claim's rows are in LDS, i.e. during its whole scan, pops, walk and bound, and are written to the (single)
-                        row buffer when the walk has read its last code.  With LDS-direct staging the blocks can only be requested
-                        once the rows are free -- right behind the first walk steps' row requests -- so all that overlaps their
-                        ~3 us from HBM is the fold and the bound, and a second LDS buffer is no way out: the compiler orders every
-                        LDS read behind an outstanding LDS-direct load of the same (dynamic) array.  vmcnt is in order, so the first
-                        fold of a claim now also waits for the next claim's blocks -- by then they have been under way for the
-                        whole scan.  +32 VGPRs, the LDS footprint and the three workgroups per CU stay */>
+          int QM /* hot codes of a lane: 0 = compacted in place over its share (LDS writes), 1 = a 64-bit position mask in registers */>
+// (Round 5, measured and removed -- commit 122dafe has the code: the NEXT claim's blocks requested into REGISTERS the moment this
+// claim's rows are in LDS, so that they travel during its whole scan, and written to the rows after the walk.  The ISA did what
+// was asked -- 8 buffer loads at the top of the claim, no vector-memory wait until the walk's first fold -- and the kernel did
+// not move: 2.19 vs 2.18 ms of S4 at 10 M documents, and 5.07 vs 5.34 k queries/s in the dense regime (t_cs = None), where the
+// 141 VGPRs cost more than the overlap gained.  A claim's time is one HBM round trip under load plus its compute whichever way the
+// two are arranged; what would help is more claims in flight per CU, which LDS rows or registers both cap.)
 __global__ void __launch_bounds__(256) approx_hotp_kernel(
     const uint32_t* __restrict__ planes /* [B][KP][RB / 4] */, int64_t K, int64_t KP, const uint32_t* __restrict__ hotbits /* [B][KP / 32] */,
     const uint32_t* __restrict__ lam_b, const uint32_t* __restrict__ lev /* [B][16] */,
@@ -3201,33 +3199,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
         }
       }
     };
-    // RS: the packed block loads of a claim into registers (returns false when the claim's ids span too many blocks for the
-    // 32-bit offsets: that claim takes the LDS-direct path when the rows are free), and their way into the rows
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NSI = RS ? DPW / DPI : 1;          // staging instructions per claim
-    u32x4 nb[NSI];
-    auto stage_regs = [&](uint32_t dv) -> bool {
-      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 63);
-      if (!((uint64_t)(d1 - d0) * (uint64_t)stride_b < 0x7FFF0000ull && d1 >= d0)) return false;
-      const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<CT*>(codes) + (int64_t)d0 * ublock_stride, 0, 0x7FFFFFFF, 0x00020000);
-#pragma unroll
-      for (int k = 0; k < NSI; ++k) {
-        const uint32_t dj = (uint32_t)__shfl((int)dv, LPD * (k * DPI + sslot));
-        const uint32_t voff = sslot < DPI ? (dj - d0) * (uint32_t)stride_b + 16u * (uint32_t)spiece : 0xFFFFFFF0u;
-        nb[k] = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)voff, 0, 0);
-      }
-      return true;
-    };
-    auto rows_from_regs = [&]() {
-      // the same bytes at the same places as the LDS-direct form: 16 bytes per lane at row base + 16 x lane, idle lanes write
-      // their zeros onto the head of the rows the next instruction fills (program order) / the slack behind the last row
-#pragma unroll
-      for (int k = 0; k < NSI; ++k)
-        *reinterpret_cast<u32x4*>(s_rows + (size_t)k * DPI * row_b + 16 * lane) = nb[k];
-    };
     uint32_t did = i0 + grp < n ? idb[i0 + grp] : id_last;
-    bool in_regs = false;                            // wave-uniform: the next claim's blocks are in nb[]
     if (i0 < n) stage(did);
     for (;;) {
       if (i0 >= n) break;
@@ -3238,10 +3210,6 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
       __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): the claim's rows are in LDS
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if constexpr (RS) {
-        in_regs = false;
-        if (more && !(probe & 4)) in_regs = stage_regs(did_next);   // under way during the whole claim
-      }
       const uint4 hd = *reinterpret_cast<const uint4*>(row);   // {#distinct, doc length, overflow index, 0}
       const int nd = valid ? (int)hd.x : 0;
       const bool ovf = nd > fit;
@@ -3356,7 +3324,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
             u32x4 v0[G][RB / 16], v1[PF == 2 ? G : 1][RB / 16];
             issue(0, v0);
             if constexpr (PF == 2) issue(G, v1);
-            if constexpr (!RS) stage(did_next);
+            stage(did_next);
             fold(v0);
             if constexpr (PF == 2) fold(v1);
           }
@@ -3373,7 +3341,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
           u32x4 v0[G][RB / 16], v1[PF == 2 ? G : 1][RB / 16];
           issue(0, v0);
           if constexpr (PF == 2) issue(G, v1);
-          if constexpr (!RS) stage(did_next);
+          stage(did_next);
           fold(v0);
           if constexpr (PF == 2) fold(v1);
         }
@@ -3496,14 +3464,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
         const bool last_window = p0 + fit >= nmax;   // wave-uniform
         if (!last_window) walk(false);
       }
-      if constexpr (RS) {
-        walk(true);                                  // the rows' last reader (the first PF steps' rows requested together)
-        __builtin_amdgcn_wave_barrier();
-        if (in_regs) rows_from_regs();               // (the loads were waited for by the walk's first fold: vmcnt is in order)
-        else if (more) stage(did_next);
-      } else {
-        walk(more);                                  // the last window's queue; the next claim's blocks ride behind its first step
-      }
+      walk(more);                                    // the last window's queue; the next claim's blocks ride behind its first step
       // ---- bound: OR across the document's lanes, weighted popcount
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
@@ -4615,13 +4576,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQT ==
 // padded by 16 B: the 1 KiB a wave reads per step spreads over all banks), which frees the registers for (a) the codes
 // two tiles ahead and the C-in rows ONE TILE AHEAD of their MFMAs, so the L2-miss latency of the row gather overlaps a
 // whole tile of matrix work, and (b) four waves per SIMD.  Arithmetic and summation order identical to exact_qct_kernel.
-// HREG (round 5): the kernel is LDS-BANDWIDTH bound, not latency bound -- per k-step a wave reads 4 x 512 B of LUT entries and
-// 2 x 1 KiB of query fragments = 32 LDS cycles at 128 B / clk, i.e. 128 cycles for the four SIMDs of a CU against the 96 cycles
-// their 3 MFMAs take (PMC: LdsUtil 65 % + 29 % bank-conflict stalls, MFMA 40 % busy; replicating the LUT cannot help, the bytes
-// are the limit).  With HREG the hi fragments (half of the fragment bytes; all of them at precision 1) stay in 4 * NS VGPRs for
-// the whole kernel -- 24 LDS cycles per k-step, 96 per CU: level with the MFMA pipe -- and only the lo fragments are read per
-// k-step.  144 VGPRs: still three waves per SIMD.  Arithmetic unchanged (bit-identical scores).
-template <int DIM, int NBITS, int SPLIT, int WPE /* waves per SIMD the register budget is cut for */, bool HREG = false>
+// (Round 5, measured and removed -- commit 122dafe: the hi query fragments held in 4 * NS VGPRs for the whole kernel, only the lo
+// ones read from LDS per k-step: a quarter less LDS traffic, 143 VGPRs, three waves per SIMD instead of four -- S6 0.575 -> 0.616 ms.
+// Per k-step a wave reads 2 KiB of LUT entries and 2 KiB of fragments, 32 LDS cycles against the 96 cycles of its 3 MFMAs x 4 SIMDs:
+// LDS is the busiest unit (PMC: 65 % + 29 % conflict stalls) but trading a wave per SIMD for LDS bytes loses.)
+template <int DIM, int NBITS, int SPLIT, int WPE /* waves per SIMD the register budget is cut for */>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) exact_qcl_kernel(ExactP p) {
   constexpr int NS = DIM / 16;
   constexpr int PD = DIM * NBITS / 8;
@@ -4683,11 +4642,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   const __bf16* ql = &sQl[SPLIT == 3 ? li * QS + kk * (DIM / 2) : 0];
   const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP) + 128 * qt0 + 16 * kk;
   const uint32_t row_bytes = (uint32_t)LQP * 4u;
-  bf16x8 bhr[HREG ? NS : 1];
-  if constexpr (HREG) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) bhr[s] = *reinterpret_cast<const bf16x8*>(qh + 8 * s);
-  }
   for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
     const int j = (bx * 4 + wave) * NP_EXACT_DPW + dd;
     if (j >= nsel) break;
@@ -4761,17 +4715,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
       // k-steps: the query fragments of step s+1 are read from LDS while step s runs; a scheduling barrier per step keeps
       // the compiler from hoisting every step's LDS reads (fragments + LUT words) to the top of the tile (that is the 64
       // VGPRs this kernel exists to give back)
-      bf16x8 bh_c, bl_c;
-      if constexpr (HREG) bh_c = bhr[0];
-      else bh_c = *reinterpret_cast<const bf16x8*>(qh);
-      bl_c = bh_c;
+      bf16x8 bh_c = *reinterpret_cast<const bf16x8*>(qh), bl_c = bh_c;
       if constexpr (SPLIT == 3) bl_c = *reinterpret_cast<const bf16x8*>(ql);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         bf16x8 bh_n = bh_c, bl_n = bl_c;
         if (s + 1 < NS) {
-          if constexpr (HREG) bh_n = bhr[s + 1];
-          else bh_n = *reinterpret_cast<const bf16x8*>(qh + 8 * (s + 1));
+          bh_n = *reinterpret_cast<const bf16x8*>(qh + 8 * (s + 1));
           if constexpr (SPLIT == 3) bl_n = *reinterpret_cast<const bf16x8*>(ql + 8 * (s + 1));
         }
         uint32_t wh[4], wl[4];

@@ -272,10 +272,7 @@ static int launch_exact(hipStream_t st, const DeviceIndex* ix, const ExactP& p, 
       for (int qt = 0; qt < p.LQP / 32; ++qt) {
         px.qt0 = qt;
         px.acc = qt > 0;
-        if (ix->tune.s6_lds == 3) {   // hi query fragments in registers, lo ones in LDS: a quarter less LDS traffic per k-step
-          if (precision == 1) exact_qcl_kernel<DIM, NBITS, 1, 3, true><<<grid, 256, 0, st>>>(px);
-          else exact_qcl_kernel<DIM, NBITS, 3, 3, true><<<grid, 256, 0, st>>>(px);
-        } else if (ix->tune.s6_lds == 2) {   // query fragments in LDS, C-in rows one tile ahead; registers cut for 4 waves per SIMD
+        if (ix->tune.s6_lds == 2) {   // query fragments in LDS, C-in rows one tile ahead; registers cut for 4 waves per SIMD
           if (precision == 1) exact_qcl_kernel<DIM, NBITS, 1, 4><<<grid, 256, 0, st>>>(px);
           else exact_qcl_kernel<DIM, NBITS, 3, 4><<<grid, 256, 0, st>>>(px);
         } else if (ix->tune.s6_lds == 1) {   // the same at 3 waves per SIMD (no spills)
@@ -847,7 +844,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
 #undef NP_LAUNCH_UB_RB
 #undef NP_LAUNCH_UB
       };
-      const unsigned ncut = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, ix->n_docs / 16384));
+      const unsigned ncut = (unsigned)std::min<int64_t>(ix->tune.ub_ncut, std::max<int64_t>(1, ix->n_docs / 16384));
       // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
       // (per query the bracket is Lq + 2 with its OWN token count: padding tokens contribute exactly 0 to both sides, so the
       // slice's longest query bounds it -- 48-token queries in 64-token rows keep 50, not 66)
@@ -900,7 +897,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     else if (RB == 128) NP_LAUNCH_HOT(128, CT); \
     else NP_LAUNCH_HOT(256, CT);                \
   } while (0)
-#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV, QMV, RSV)                                                                     \
+#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV, QMV)                                                                          \
   do {                                                                                                                   \
     const size_t bm = sizeof(CT) == 2 ? 0 : (size_t)(((KP >> 5) + 3) & ~(int64_t)3) * 4;   /* u16 codes: static bitmap */   \
     /* idle lanes of the last packed staging instruction write 16 B each past the rows it fills (1 KiB per instruction);     \
@@ -909,9 +906,9 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     const int slack = (int)std::max<int64_t>(256, 1024 - (int64_t)(DPIV) * (int64_t)rowb);                                   \
     const size_t dynp = bm + (size_t)4 * ((64 / LPDV) * rowb + (size_t)slack);                                               \
     if (dynp > 16 * 1024)                                                                                                \
-      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV, RSV>), \
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV>), \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynp));                                \
-    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV, RSV><<<8 * pnbx, 256, dynp, st>>>(                 \
+    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV><<<8 * pnbx, 256, dynp, st>>>(                 \
         w.planes.as<uint32_t>(), ix->K, KP, w.hotbits.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.levels.as<uint32_t>(), \
         w.cand.as<uint32_t>(), w.cand_meta.as<uint4>(), ix->ublock_stride, (int64_t)ix->n_docs * ix->ublock_stride,        \
         w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), d_qoff, cs->n_sel,     \
@@ -925,13 +922,12 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   do {                                                                  \
     const int sb = ix->ublock_stride * (int)sizeof(CT);                 \
     if (plpd == 2) {                                                    \
-      if (sb <= 240 && ix->tune.s4_qm && ix->tune.s4_rs) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 1, 1);   \
-      else if (sb <= 240 && ix->tune.s4_qm) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 1, 0);   \
-      else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 0, 0);         \
-      else NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 2, 0, 0);                        \
-    } else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 4, 0, 0);         \
-    else if (sb <= 496) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 2, 0, 0);           \
-    else NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 1, 0, 0);                          \
+      if (sb <= 240 && ix->tune.s4_qm) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 1);   \
+      else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 4, 0);         \
+      else NP_LAUNCH_HOTP(ROWB, CT, 2, 2, 2, 0);                        \
+    } else if (sb <= 240) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 4, 0);         \
+    else if (sb <= 496) NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 2, 0);           \
+    else NP_LAUNCH_HOTP(ROWB, CT, 4, 1, 1, 0);                          \
   } while (0)
           const int plpd = (ix->ublock_stride > old_cap || ix->tune.s4_lpd == 4) ? 4 : 2;
           const unsigned pnbx = (unsigned)ix->tune.s4_pnbx;   // workgroups per XCD of the plane kernel

@@ -90,7 +90,7 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 60), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1), ("s4_planes", 1), ("s4_lpd", 2), ("s4_qm", 1), ("s4_warm", 0), ("s4_rs", 0), ("s4_hot_auto", 200000)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 60), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1), ("s4_planes", 1), ("s4_lpd", 2), ("s4_qm", 1), ("s4_warm", 0), ("s4_hot_auto", 200000), ("s3_bisect", 1)):
         hx.tune(k, v)
 
 
@@ -226,12 +226,11 @@ def test_s6_kernel_variants_identical(mid, tuned):
     for prec in (2, 1):
         p = P(n_full_scores=1024, top_k=32, n_ivf_probe=16, precision=prec)
         ref = None
-        for xcd, rep, steal in ((1, 0, 16384), (0, 0, 1), (0, 0, 0x7FFFFFFF), (1, 1, 16384), (0, 2, 16384), (1, 3, 16384), (1, 4, 16384)):
+        for xcd, rep, steal in ((1, 0, 16384), (0, 0, 1), (0, 0, 0x7FFFFFFF), (1, 1, 16384), (0, 2, 16384), (1, 4, 16384)):
             hx.tune("s6_xcd", xcd)
             hx.tune("ub_steal", steal)
-            # query fragments in registers (exact_qct_kernel), in LDS (exact_qcl_kernel; 4: the 4-waves-per-SIMD instantiation)
-            # or hi in registers / lo in LDS (round 5: exact_qcl_kernel<..., HREG>)
-            hx.tune("s6_lds", {0: 0, 1: 1, 2: 1, 3: 3, 4: 2}[rep])
+            # query fragments in registers (exact_qct_kernel) or in LDS (exact_qcl_kernel; 4: the 4-waves-per-SIMD instantiation)
+            hx.tune("s6_lds", {0: 0, 1: 1, 2: 1, 4: 2}[rep])
             hx.tune("s6_tiles", 0 if rep == 2 else 1)    # multi-tile kernels or one launch per 32-token query tile
             got = hx.search_batch(qs[:24], p)
             if ref is None:
@@ -318,7 +317,7 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
             hx.tune("s4_planes", planes)
             hx.tune("s4_lpd", 2 if hot in (10, 100, 500) else 4) # plane kernel: claims of 32 documents (2 lanes each) or 16 (4 lanes)
             hx.tune("s4_qm", 0 if hot == 500 else 1)             # ... hot codes as a position mask or compacted in place
-            hx.tune("s4_rs", 1 if hot == 100 else 0)             # ... the next claim's blocks by LDS-direct loads or through registers
+            hx.tune("s3_bisect", 0 if hot == 100 else 1)         # S3: bitmap ranges sweep the posting lists or bisect them
             hx.tune("s4_hot_auto", 50 if hot == 300 else 200000) # ... the share scaled down by the candidate count (300 -> >= 8 per mille)
             hx.tune("ub_direct", 0 if hot == 300 else 8)   # short-list launch: per-XCD hand-out or one group of workgroups per query
             hx.tune("ub_static", 1 if hot in (10, 500) else 0)   # claims from a cursor (with stealing) or round-robin
