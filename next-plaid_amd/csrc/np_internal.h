@@ -143,7 +143,7 @@ struct Tuning {
   int s4_pexp = 15;      // plane levels: t_j = Lambda + span * (j / 8)^(s4_pexp / 10); 10 = uniform (hot_levels_kernel)
   int s4_warm = 0;       // ... per-mille of the centroids whose rows the exact level still gathers for the S2 list (the rest: floored
                          // at Lambda2; approx_ub_kernel FLOOR); 1000 = every row; 0 = by query length and list length (np_search.hip)
-  int ub_ncut = 32;      // workgroups per query of the cut kernels (each appends 2048 records per step: latency-bound per step)
+  int ub_ncut = 96;      // workgroups per query of the cut kernels (each appends 2048 records per step: latency-bound per step)
   int ub_direct = 8;     // workgroups per query of the short-list (S1) exact-bound launch; 0 = the per-XCD hand-out
   int hot_static = 1;    // hot kernel: waves take a query's claims round-robin (no cursor atomic: a device-scope atomic per claim
                          // on a line all XCDs share costs ~50 ns, serialised): 2.06 -> 1.68 ms at 10 M documents
@@ -159,6 +159,8 @@ struct Tuning {
   int s6_tiles = 1;      // QC-reuse S6: one launch of the one-tile kernel per 32-token query tile (0: the multi-tile kernels)
   int s1_split = 0;      // OPT-IN (np_hip_index_tune / NP_S1_SPLIT): split-bf16 S1 (qc_gemm_b3_kernel) when precision >= 1 and K >
                          // centroid_batch_size -- S1-S5 are then no longer bit-equal to the f32 chain (near-ties < ~1e-5 can reorder)
+  int gemm_prio = 0;     // S1: the epilogue of a tile runs at raised issue priority (s_setprio)
+  int s6_prio = 0;       // S6: the MFMAs of a k-step are issued at raised priority
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };
