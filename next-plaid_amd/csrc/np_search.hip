@@ -173,8 +173,9 @@ static int validate(const DeviceIndex* ix, int32_t B, int32_t dim, const np_sear
               p->n_full_scores);
     return NP_ERR_SEARCH;
   }
-  if (n_sel_of(p) > 8192) {
-    set_error("Search failed: max(n_full_scores/4, top_k) = %d exceeds the HIP path's 8192-document re-rank window",
+  // S5 / S7 order a query's re-rank window in LDS (8 bytes per document, 128 KB of the CU's 160): n_full_scores up to 65536
+  if (n_sel_of(p) > 16384) {
+    set_error("Search failed: max(n_full_scores/4, top_k) = %d exceeds the HIP path's 16384-document re-rank window",
               n_sel_of(p));
     return NP_ERR_SEARCH;
   }

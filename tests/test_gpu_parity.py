@@ -244,6 +244,22 @@ def test_s6_kernel_variants_identical(mid, tuned):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_BF16)
 
 
+def test_rerank_window_up_to_16384_documents(mid):
+    """search.rs:26-69 puts no bound on n_full_scores; the HIP path orders a query's re-rank window in LDS, 16384 documents
+    since round 5 (n_full_scores = 65536; 8192 before).  20000 documents, no threshold, a wide probe: nearly the whole corpus
+    is a candidate and 16384 of them are exact-scored; the top of the ranking equals the oracle's.  One document more is a
+    Search error, not a silent truncation."""
+    spec, a, ox, hx, qs, src = mid
+    p = P(n_full_scores=65536, top_k=50, n_ivf_probe=64, centroid_score_threshold=None)
+    got = hx.search_batch(qs[:4], p)
+    assert hx.last_stats["n_exact_docs"] > 4 * 12000, hx.last_stats
+    for i, (g, o) in enumerate(zip(got, ox.search_batch(qs[:4], to_oracle_params(p)))):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"n_sel 16384 q{i}")
+        assert g.passage_ids[0] == src[i]
+    with pytest.raises(npa.SearchError):
+        hx.search_batch(qs[:1], P(n_full_scores=65540, top_k=10, n_ivf_probe=8))
+
+
 def test_huge_norm_query_keeps_reference_semantics(mid):
     """A query whose norm exceeds 1e12 is flagged like a non-finite one: the S4 filter is skipped and S6 keeps its
     non-finite guard (products could overflow).  Scores scale with the query, rankings equal the oracle's."""

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Installs the evidence of a final GPU call under profiles/ and regenerates the measured tables of DESIGN.md
-(between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r04_*.
+(between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r05_*.
 
-  design_tables.py install <gpurun_out tag> [--merge]   copy gpurun_out/<tag>/... to profiles/r04_* (names below); --merge keeps
+  design_tables.py install <gpurun_out tag> [--merge]   copy gpurun_out/<tag>/... to profiles/r05_* (names below); --merge keeps
                                                 the committed lines the call did not re-measure
-  design_tables.py                              regenerate the tables from profiles/r04_*
+  design_tables.py                              regenerate the tables from profiles/r05_*
 """
 import json
 import os
@@ -14,12 +14,13 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 P = os.path.join(ROOT, "profiles") + "/"
-R = "r04"
+R = "r05"
 
 GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
-    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "tcs_none", "single_level_10m", "planes0_10m", "warm1000_10m"],
-    f"{R}_bench_regimes.jsonl": ["dist05", "dist08", "lq48_10m", "lq48_1m", "nfs8192_10m", "k19_10m", "k19_split_10m", "c3_np32", "c3_np8"],
+    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "single_level_10m", "planes0_10m", "warm1000_10m"],
+    f"{R}_bench_regimes.jsonl": ["api_default", "tcs_none", "dist05", "dist08", "lq48_10m", "lq48_1m", "nfs8192_10m", "colgrep_10m", "k19_10m",
+                                 "k19_split_10m", "c3_np32", "c3_np8", "c4_k18_12500k"],
 }
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k",
            f"{R}_bench_disk_1m.json": "disk1m"}
