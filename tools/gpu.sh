@@ -20,7 +20,7 @@ TAG=$1; shift
 REPO=$(pwd)
 O=$REPO/gpurun_out/$TAG
 mkdir -p "$O"
-T=${JOB_TIMEOUT:-900}
+T=${JOB_TIMEOUT:-600}
 summ() {
   python3 - "$1" "$2" <<'EOF'
 import json, sys
