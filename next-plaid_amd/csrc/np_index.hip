@@ -82,8 +82,6 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "s3_slices") t->s3_slices = value != 0;
   else if (n == "s4_warm") t->s4_warm = clamp(value, 0, 1000);
   else if (n == "ub_ncut") t->ub_ncut = clamp(value, 1, 512);
-  else if (n == "gemm_prio") t->gemm_prio = clamp(value, 0, 1);
-  else if (n == "s6_prio") t->s6_prio = clamp(value, 0, 2);
   else if (n == "s3_bisect") t->s3_bisect = clamp(value, 0, 1);
   else if (n == "s4_hot_auto") t->s4_hot_auto = clamp(value, 0, 0x7fffffff);
   else if (n == "ub_nt") t->ub_nt = value < 0 || value > 2 ? 0 : value;
@@ -108,7 +106,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
 void read_tuning_env(Tuning* t) {
   static const char* const knobs[][2] = {
       {"NP_S4_MODE", "s4_mode"}, {"NP_S4_MINB", "s4_minb"}, {"NP_S4_NBX", "s4_nbx"}, {"NP_S4_SWZ", "s4_swz"},
-      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S4_LPD", "s4_lpd"}, {"NP_S4_QM", "s4_qm"}, {"NP_S4_PNBX", "s4_pnbx"}, {"NP_S4_WARM", "s4_warm"}, {"NP_UB_NCUT", "ub_ncut"}, {"NP_GEMM_PRIO", "gemm_prio"}, {"NP_S6_PRIO", "s6_prio"}, {"NP_S3_BISECT", "s3_bisect"}, {"NP_S4_HOT_AUTO", "s4_hot_auto"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
+      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S4_LPD", "s4_lpd"}, {"NP_S4_QM", "s4_qm"}, {"NP_S4_PNBX", "s4_pnbx"}, {"NP_S4_WARM", "s4_warm"}, {"NP_UB_NCUT", "ub_ncut"}, {"NP_S3_BISECT", "s3_bisect"}, {"NP_S4_HOT_AUTO", "s4_hot_auto"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
       {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"}, {"NP_S1_SPLIT", "s1_split"},
       {"NP_EXACT_ROWMAX", "exact_rowmax"}};
   for (const auto& k : knobs) {

@@ -159,8 +159,6 @@ struct Tuning {
   int s6_tiles = 1;      // QC-reuse S6: one launch of the one-tile kernel per 32-token query tile (0: the multi-tile kernels)
   int s1_split = 0;      // OPT-IN (np_hip_index_tune / NP_S1_SPLIT): split-bf16 S1 (qc_gemm_b3_kernel) when precision >= 1 and K >
                          // centroid_batch_size -- S1-S5 are then no longer bit-equal to the f32 chain (near-ties < ~1e-5 can reorder)
-  int gemm_prio = 0;     // S1: the epilogue of a tile runs at raised issue priority (s_setprio)
-  int s6_prio = 0;       // S6: the MFMAs of a k-step are issued at raised priority
   int gemm_cpw = 1;      // centroid fragments per wave in S1
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };

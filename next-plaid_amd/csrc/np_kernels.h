@@ -172,8 +172,7 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ Qt, int B, int LQP,
                                                       float* __restrict__ QCT, uint32_t* __restrict__ gmax,
                                                       uint8_t* __restrict__ QCU, int RB /* u8 row bytes: power of two >= LQP */,
-                                                      const float* __restrict__ qinv, const int32_t* __restrict__ qoff,
-                                                      int epi_prio /* raise the wave's issue priority for the epilogue */) {
+                                                      const float* __restrict__ qinv, const int32_t* __restrict__ qoff) {
   // The block's 4 waves walk the same sequence of 32-token query tiles ([DIM][32] f32, k-major).  Tile t+1 is
   // copied global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers) while tile t feeds
   // the MFMAs as conflict-free ds_read B operands; tile t-1's epilogue (QCT stores, group maxima) is issued
@@ -222,10 +221,8 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float sT[4][32 * TS];
   __shared__ __attribute__((aligned(16))) uint8_t sU[4][32 * 32];
   auto epilogue = [&](const f32x16 (&acc)[CPW], int tile) {
-    // VALU issue between the waves of a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md): next to a sibling
-    // wave that issues back-to-back MFMAs the ~250 VALU / LDS instructions of this epilogue went out at one per 25-30 cycles.
-    // With priority the epilogue is over sooner and this wave is back in its own MFMA chain while the sibling is in ITS epilogue.
-    if (epi_prio) __builtin_amdgcn_s_setprio(2);
+    // (Round 5, measured and removed: s_setprio 2 for the epilogue -- VALU issue between the waves of a SIMD is arbitrated by
+    // priority, then age -- left S1 where it was: 0.43 vs 0.44 ms at K = 2^16, 3.25 vs 3.37 ms at K = 2^19.)
     const int b = nqt == 1 ? tile : tile / nqt, qt = tile - b * nqt;
     const int h = lane >> 5, rr = (lane & 31) >> 3, c4 = lane & 7;   // store role: half, row in the group of 4, 16-B chunk
 #pragma unroll
@@ -281,7 +278,6 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
       }
       __builtin_amdgcn_wave_barrier();   // the next fragment / tile overwrites sT and sU
     }
-    if (epi_prio) __builtin_amdgcn_s_setprio(0);
   };
   if (ntiles > 0) dma_tile(0, 0);
   __syncthreads();
@@ -3885,7 +3881,6 @@ struct ExactP {
   int qt0;                  // exact_qct_kernel<.., NQT = 1, ..>: the 32-token query tile this launch scores (queries longer than
   int acc;                  // 32 tokens take one launch per tile); acc = continue the q-ordered sum from exact[] (tiles > 0)
   float pad_ss;             // (DIM - file dim) * wlut[0]^2: what the padding of a stored row adds to an inline sum of squares
-  int prio;                 // exact_qcl_kernel: 1 = the MFMAs of a k-step issue at raised priority, 2 = its LUT expansion does
 };                          // (pad centroid values are 0 and pad residual bytes are 0, so every pad dim reads exactly wlut[0]; the
                             //  products themselves vanish against the zero-padded query).  0 for an unpadded index.
 
@@ -4647,7 +4642,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   if (qt0 > 0 && Lq == 0) return;
   const __bf16* qh = &sQh[li * QS + kk * (DIM / 2)];
   const __bf16* ql = &sQl[SPLIT == 3 ? li * QS + kk * (DIM / 2) : 0];
-  const int prio = __builtin_amdgcn_readfirstlane(p.prio);
   const char* QCb = reinterpret_cast<const char*>(p.QCT + (int64_t)b * p.KP * LQP) + 128 * qt0 + 16 * kk;
   const uint32_t row_bytes = (uint32_t)LQP * 4u;
   for (int dd = 0; dd < NP_EXACT_DPW; ++dd) {
@@ -4754,8 +4748,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 vh = {wh[0], wh[1], wh[2], wh[3]};
         const bf16x8 ah = __builtin_bit_cast(bf16x8, vh);
-        if (prio == 1) __builtin_amdgcn_s_setprio(1);
-        else if (prio == 2) __builtin_amdgcn_s_setprio(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_c, ah, acc, 0, 0, 0);   // rows = q, cols = tokens
         if constexpr (SPLIT == 3) {
           const u32x4 vl = {wl[0], wl[1], wl[2], wl[3]};
@@ -4763,8 +4755,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_c, al, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl_c, ah, acc, 0, 0, 0);
         }
-        if (prio == 1) __builtin_amdgcn_s_setprio(0);
-        else if (prio == 2) __builtin_amdgcn_s_setprio(1);
+        // (round 5, measured and removed: s_setprio 1 around these MFMAs, or around the LUT expansion instead: 0.60 / 0.61 ms
+        // against 0.575 without the scalar branches that selected them)
         __builtin_amdgcn_sched_barrier(0);
         bh_c = bh_n;
         bl_c = bl_n;

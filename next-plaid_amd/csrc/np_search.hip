@@ -241,12 +241,10 @@ static void launch_gemm(hipStream_t st, const DeviceIndex* ix, const float* Qt, 
   // epilogue (stores, key maxima) hides under another wave's MFMAs.  KP is a multiple of 64.
   if (ix->tune.gemm_cpw == 2) {
     const unsigned blocks = (unsigned)((ix->KP / 64 + 3) / 4);
-    qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, RB, qinv, qoff,
-                                                   ix->tune.gemm_prio);
+    qc_gemm_kernel<DIM, 2><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, RB, qinv, qoff);
   } else {
     const unsigned blocks = (unsigned)((ix->KP / 32 + 3) / 4);
-    qc_gemm_kernel<DIM, 1><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, RB, qinv, qoff,
-                                                   ix->tune.gemm_prio);
+    qc_gemm_kernel<DIM, 1><<<blocks, 256, 0, st>>>(ix->d_centroids, ix->K, ix->KP, Qt, B, LQP, QCT, gmax, QCU, RB, qinv, qoff);
   }
 }
 
@@ -1072,7 +1070,6 @@ static int phase_b(const DeviceIndex* ix, CallState* cs, const int32_t* d_qoff, 
     ep.qt0 = 0;
     ep.acc = 0;
     ep.pad_ss = ix->pad_ss;
-    ep.prio = ix->tune.s6_prio;
     switch (ix->dim) {
       case 32: NP_TRY((launch_exact_nb<32>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
       case 64: NP_TRY((launch_exact_nb<64>(st, ix, ep, B, cs->prm.precision, ix->nbits))); break;
