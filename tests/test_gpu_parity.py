@@ -257,7 +257,8 @@ def test_rerank_window_up_to_16384_documents(mid):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"n_sel 16384 q{i}")
         assert g.passage_ids[0] == src[i]
     with pytest.raises(npa.SearchError):
-        hx.search_batch(qs[:1], P(n_full_scores=65540, top_k=10, n_ivf_probe=8))
+        hx.search_batch(qs[:1], P(n_full_scores=65540, top_k=10, n_ivf_probe=8), parallel=False)
+    assert all(r.passage_ids.size == 0 for r in hx.search_batch(qs[:2], P(n_full_scores=65540, top_k=10, n_ivf_probe=8)))   # search.rs:656-660
 
 
 def test_huge_norm_query_keeps_reference_semantics(mid):
