@@ -565,6 +565,7 @@ def main():
                                                    if g.passage_ids.size and s < cdocs))
             del ox, e
         except Exception as ex:  # report, do not fail the bench
+            print(f"bench.py: CPU baseline / parity leg failed: {type(ex).__name__}: {ex}", file=sys.stderr)
             cpu = cpu or dict(value=None, unit="queries/s", cores=None, kind="port", sample=f"skipped: {type(ex).__name__}: {ex}")
 
     k2 = int(round(np.log2(a.centroids)))

@@ -407,7 +407,7 @@ static void launch_matvec(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
 
 // S1..S5 for queries [0,B) whose rows live in d_q (absolute offsets d_qoff/h_qoff).
 static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
-                        const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len);
+                        const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len, bool allow_grow);
 
 // A reservation that fails under the DEFAULT budget (another index or an encoder took the memory since open) is retried
 // with the pool released and the budget halved -- more candidate-pool rounds instead of OutOfMemory.  Every reservation of
@@ -415,7 +415,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
 static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
                    const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len) {
   for (int attempt = 0;; ++attempt) {
-    const int rc = phase_a_once(ix, cs, d_q, d_qoff, h_qoff, d_subset, subset_len);
+    // (a retry never lets the budget grow back: the pass that just failed WAS the planned size)
+    const int rc = phase_a_once(ix, cs, d_q, d_qoff, h_qoff, d_subset, subset_len, attempt == 0);
     if (rc != NP_ERR_OUT_OF_MEMORY || !ix->ws_auto || attempt >= 4) return rc;
     const int64_t b = ix->ws_budget.load(std::memory_order_relaxed);
     if (b <= ((int64_t)256 << 20)) return rc;
@@ -427,7 +428,7 @@ static int phase_a(const DeviceIndex* ix, CallState* cs, const float* d_q, const
 }
 
 static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, const int32_t* d_qoff,
-                        const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len) {
+                        const int32_t* h_qoff, const int64_t* d_subset, int64_t subset_len, bool allow_grow) {
   Workspace& w = *cs->ctx->ws;
   hipStream_t st = cs->stream;
   const int B = cs->B;
@@ -469,19 +470,24 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   if (ix->ws_auto) {
     // The default budget was what the device had free at open.  Before a pool GROWS, and whenever the budget stands below
     // its value at open, look at what is free now: the budget covers this context's scratch AND pool, so what this context
-    // could hold in total is the free memory plus everything it already holds (minus a margin for the other contexts'
-    // small buffers).  It shrinks when the batch would not fit (another tenant took the memory since open: more rounds, not
-    // OutOfMemory) and grows back towards the open value once the tenant is gone.
+    // could hold in total is the free memory plus everything it already holds, minus a GiB for the other contexts' small
+    // buffers and the allocator's granularity.  The budget shrinks when the batch would not fit (another tenant took the
+    // memory since open: more rounds, not OutOfMemory) and grows back towards the open value once there is clearly room again
+    // (a quarter more than the current budget: a context that just failed to reserve its plan must not talk itself back
+    // into the same plan on the retry -- a 12.5 M-document shard leaves three contexts ~12 GiB each and nothing to spare).
     const int64_t want = std::min<int64_t>(plan.pool, (int64_t)std::max(B, 1) * std::max<int64_t>(ix->n_docs, 1));
     const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
-    if ((int64_t)w.cand.cap < want * 4 || budget < ix->ws_budget_open) {
+    const bool below = allow_grow && budget < ix->ws_budget_open;
+    if ((int64_t)w.cand.cap < want * 4 || below) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const int64_t held = (int64_t)w.total_bytes();
-        const int64_t avail = (int64_t)free_b + held - ((int64_t)512 << 20);
-        const int64_t nb = std::min<int64_t>(ix->ws_budget_open, std::max<int64_t>(avail, (int64_t)256 << 20));
-        if ((nb < budget && plan.S * per_query_bytes(ix, LQP, n_sel_of(&prm), prm.top_k) + want * NP_POOL_ENTRY > avail) ||
-            nb > budget) {
+        const int64_t avail = (int64_t)free_b + held - ((int64_t)1 << 30);
+        const int64_t need = plan.S * per_query_bytes(ix, LQP, n_sel_of(&prm), prm.top_k) + want * NP_POOL_ENTRY;
+        int64_t nb = budget;
+        if (avail < budget && need > avail) nb = std::max<int64_t>(avail, (int64_t)256 << 20);
+        else if (below && avail >= budget + budget / 4) nb = std::min<int64_t>(ix->ws_budget_open, avail);
+        if (nb != budget) {
           ix->ws_budget.store(nb, std::memory_order_relaxed);
           plan = plan_workspace(ix, B, LQP, &prm);
         }
