@@ -472,9 +472,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     // its value at open, look at what is free now: the budget covers this context's scratch AND pool, so what this context
     // could hold in total is the free memory plus everything it already holds, minus a GiB for the other contexts' small
     // buffers and the allocator's granularity.  The budget shrinks when the batch would not fit (another tenant took the
-    // memory since open: more rounds, not OutOfMemory) and grows back towards the open value once there is clearly room again
-    // (a quarter more than the current budget: a context that just failed to reserve its plan must not talk itself back
-    // into the same plan on the retry -- a 12.5 M-document shard leaves three contexts ~12 GiB each and nothing to spare).
+    // memory since open: more rounds, not OutOfMemory) and returns to the open value only when a whole budget is FREE on the
+    // device again, whatever this context holds (never on the retry of a pass that just failed to reserve its plan).  A looser
+    // rule -- "a quarter more than the current budget is reachable" -- made the three contexts of a 12.5 M-document shard,
+    // which share ~36 GiB with nothing to spare, take turns shrinking and regrowing the shared budget and reallocating their
+    // pools: 466 instead of ~15 000 queries/s.
     const int64_t want = std::min<int64_t>(plan.pool, (int64_t)std::max(B, 1) * std::max<int64_t>(ix->n_docs, 1));
     const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
     const bool below = allow_grow && budget < ix->ws_budget_open;
@@ -486,7 +488,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
         const int64_t need = plan.S * per_query_bytes(ix, LQP, n_sel_of(&prm), prm.top_k) + want * NP_POOL_ENTRY;
         int64_t nb = budget;
         if (avail < budget && need > avail) nb = std::max<int64_t>(avail, (int64_t)256 << 20);
-        else if (below && avail >= budget + budget / 4) nb = std::min<int64_t>(ix->ws_budget_open, avail);
+        else if (below && (int64_t)free_b >= ix->ws_budget_open + ((int64_t)1 << 30)) nb = ix->ws_budget_open;
         if (nb != budget) {
           ix->ws_budget.store(nb, std::memory_order_relaxed);
           plan = plan_workspace(ix, B, LQP, &prm);
