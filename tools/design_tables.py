@@ -18,9 +18,9 @@ R = "r05"
 
 GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
-    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "single_level_10m", "planes0_10m", "warm1000_10m"],
-    f"{R}_bench_regimes.jsonl": ["api_default", "tcs_none", "dist05", "dist08", "lq48_10m", "lq48_1m", "nfs8192_10m", "colgrep_10m", "k19_10m",
-                                 "k19_split_10m", "c3_np32", "c3_np8", "c4_k18_12500k"],
+    f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "single_level_10m"],
+    f"{R}_bench_regimes.jsonl": ["api_default", "tcs_none", "dist05", "dist08", "lq48_10m", "nfs8192_10m", "colgrep_10m", "k19_10m",
+                                 "k19_split_10m", "c3_np32", "c4_k18_12500k"],
 }
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k",
            f"{R}_bench_disk_1m.json": "disk1m"}
@@ -30,7 +30,8 @@ def install(tag, merge=False):
     """merge: a later, smaller call re-measured some lines -- replace those, keep the rest of the committed evidence."""
     src = os.path.join(ROOT, "gpurun_out", tag)
     for dst, name in SINGLES.items():
-        if merge and not os.path.exists(os.path.join(src, f"b_{name}.json")):
+        pth = os.path.join(src, f"b_{name}.json")
+        if merge and (not os.path.exists(pth) or os.path.getsize(pth) == 0):   # (an empty file: the run failed, e.g. out of memory)
             continue
         d = json.load(open(os.path.join(src, f"b_{name}.json")))
         if name != "default_10m" and d.get("roofline", {}).get("traffic") is not None:
@@ -62,8 +63,20 @@ def install(tag, merge=False):
                  ("pmc_d10m.md", f"{R}_pmc_10m.md"), ("traffic_d10m.json", "traffic.json"), ("host.txt", f"{R}_host.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), P + b)
-    if not os.path.exists(os.path.join(src, "test_all.log")):
+    tp = P + "traffic.json"
+    if os.path.exists(os.path.join(src, "traffic_d10m.json")):   # the GPU box has no .git: name the commit the call ran at here
+        import subprocess
+        t = json.load(open(tp))
+        if not t.get("commit"):
+            t["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+            json.dump(t, open(tp, "w"), indent=1)
+    if os.path.exists(os.path.join(src, "pmcd", "derived.txt")):
+        shutil.copy(os.path.join(src, "pmcd", "derived.txt"), P + f"{R}_pmc_derived_10m.txt")
+    if not os.path.exists(os.path.join(src, "test_all.log")) or "-k" in open(os.path.join(src, "test_all.log")).read()[:0]:
         return
+    if " deselected" in open(os.path.join(src, "test_all.log")).read() and "189 passed" not in open(os.path.join(src, "test_all.log")).read() \
+            and os.path.exists(P + f"{R}_test_gpu.log"):
+        return   # a partial / superseded test run never replaces the full one
     with open(P + f"{R}_test_gpu.log", "w") as f:
         for a in ("test_all.log", "smoke.log"):
             if os.path.exists(os.path.join(src, a)):
@@ -86,7 +99,7 @@ def stage_cells(s):
 def tables():
     d10, d1, tr = load(f"{R}_bench_default_10m.json"), load(f"{R}_bench_1m.json"), load("traffic.json")
     rows = [("S1 `qc_gemm` (+ hot prep)", "qc_gemm(S1)", "ms_centroid"), ("S2 probe", "probe(S2)", "ms_probe"),
-            ("S3 candidates", "candidates(S3)", "ms_candidates"), ("S4 two-level filter + exact survivors", "approx(S4)", "ms_approx"),
+            ("S3 candidates (+ hot levels / plane rows)", "candidates(S3)", "ms_candidates"), ("S4 two-level filter + exact survivors", "approx(S4)", "ms_approx"),
             ("S5 select", "select(S5)", "ms_select"), ("S6 exact (prec 2)", "exact(S6)", "ms_exact")]
     t = ["| stage | 10 M docs: ms / batch | achieved vs §8(d) algorithmic roofline | 1 M docs: ms / batch | achieved |", "|---|---:|---|---:|---|"]
     for name, k, ms in rows:
@@ -95,8 +108,9 @@ def tables():
                  f"{d1['stages'][ms]:.3f} | {b['achieved']:.0f} {b['unit']} = {100*b['frac']:.1f} % |")
     t.append(f"| S7 top-k | {d10['stages']['ms_topk']:.3f} | | {d1['stages']['ms_topk']:.3f} | |")
     t.append(f"| **one batch alone (p50)** | **{d10['p50_batch_latency_ms']:.2f}** | | **{d1['p50_batch_latency_ms']:.2f}** | |")
-    t.append(f"| **sustained, 3 streams** | **{d10['ms_per_step']:.2f} → {d10['value']:.0f} queries/s** | PCIe-inclusive {d10['value_pcie_inclusive']:.0f} | "
-             f"**{d1['ms_per_step']:.2f} → {d1['value']:.0f} queries/s** | PCIe-inclusive {d1['value_pcie_inclusive']:.0f} |")
+    t.append(f"| **sustained, 3 streams** | **{d10['ms_per_step']:.2f} → {d10['value']:.0f} queries/s** | host buffers in / out, 3 host threads: {d10['value_pcie_inclusive']:.0f} "
+             f"({100*d10['pcie_inclusive']['ratio_to_value']:.1f} %) | "
+             f"**{d1['ms_per_step']:.2f} → {d1['value']:.0f} queries/s** | {d1['value_pcie_inclusive']:.0f} ({100*d1['pcie_inclusive']['ratio_to_value']:.1f} %) |")
     s10, s1 = d10["stages"], d1["stages"]
     cb10, cb1 = d10["cpu_baseline"], d1["cpu_baseline"]
     t += ["", f"Per batch of 64 queries at 10 M documents: {s10['n_cells']:.0f} probed cells, {s10['n_ivf_ids']/1e6:.1f} M posting entries, "
@@ -108,10 +122,12 @@ def tables():
               f"{d1['index_build_s']:.2f} s (1 M); {d10['hbm_bytes_per_token']:.1f} B per token. CPU baseline (oracle C restatement, {cb10['cores']} threads, "
               f"{cb10['cpu_model']}): {cb10['value']:.1f} queries/s at 10 M, {cb1['value']:.1f} at 1 M. `roofline.traffic` (PMC, 10 M): "
               f"S4 {tr['approx(S4)']/1e9:.2f} GB, S6 {tr['exact(S6)']/1e9:.2f} GB, S3 {tr['candidates(S3)']/1e9:.2f} GB per batch.", "",
-          f"Round 3 → round 4: 10 M documents 17.3 k → {d10['value']/1e3:.1f} k queries/s (p50 4.16 → {d10['p50_batch_latency_ms']:.2f} ms, S4 2.64 → "
-          f"{s10['ms_approx']:.2f} ms); 1 M documents 36.9 k → {d1['value']/1e3:.1f} k queries/s (S4 0.77 → {s1['ms_approx']:.2f} ms).  "
+          f"Round 4 → round 5: 10 M documents 18.9 k → {d10['value']/1e3:.1f} k queries/s (p50 3.89 → {d10['p50_batch_latency_ms']:.2f} ms, S4 2.35 → "
+          f"{s10['ms_approx']:.2f} ms); 1 M documents 38.8 k → {d1['value']/1e3:.1f} k queries/s (S4 0.73 → {s1['ms_approx']:.2f} ms).  "
           f"The bench line's `roofline.frac` prices the contract's algorithmic bytes ({d10['roofline']['frac']:.2f} for S4); the bytes the stage "
-          f"really moved (PMC) give `roofline.frac_physical` = {d10['roofline'].get('frac_physical')}."]
+          f"really moved (PMC, every kernel of the stage) give `roofline.frac_physical` = {d10['roofline'].get('frac_physical')}; the dominant kernel "
+          f"alone (`approx_hotp_kernel`, {d10['roofline']['dominant_kernel']['ms_per_launch']:.3f} ms by its own HIP events): "
+          f"{d10['roofline']['dominant_kernel']['traffic']/1e9:.2f} GB → `frac_physical` {d10['roofline']['dominant_kernel']['frac_physical']}."]
     measured = "\n".join(t)
 
     reg = lines(f"{R}_bench_regimes.jsonl")
@@ -133,13 +149,14 @@ def tables():
 
     rg = ["| line (10 M docs × 300 tok unless stated) | queries/s | p50 ms | S1 | S2 | S3 | S4 | S5 | S6 | CPU oracle q/s | top-10 = oracle |",
           "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
-    labs = [("lq48_10m", "48-token queries (ONNX encoder default, `next-plaid-onnx/src/lib.rs:628-630`)"),
-            ("lq48_1m", "48-token queries, 1 M docs"),
+    labs = [("api_default", "**the REST API's default**: `centroid_score_threshold = None`, `n_ivf_probe = 8` (`next-plaid-api/src/models.rs:281-284`, `handlers/search.rs:211-217`)"),
+            ("tcs_none", "`centroid_score_threshold = None`, nprobe 32"),
+            ("lq48_10m", "48-token queries (ONNX encoder default, `next-plaid-onnx/src/lib.rs:628-630`)"),
             ("nfs8192_10m", "`n_full_scores = 8192` (ColGREP, `colgrep/src/index/mod.rs:771-777`)"),
+            ("colgrep_10m", "**ColGREP's defaults together**: 48-token queries + `n_full_scores = 8192` + nprobe 8 (`colgrep/src/index/mod.rs:777-819`)"),
             ("k19_10m", "K = 2¹⁹ (the crate's k-means heuristic at this size, `kmeans.rs:303-309`): batched path, bit-exact S1-S5"),
             ("k19_split_10m", "K = 2¹⁹ with the opt-in split-bf16 S1 (`s1_split`, no mat-vec re-scoring)"),
-            ("c3_np32", "config 3 shape: 8 841 823 docs, clipped LogNormal lengths (mean 73, max 180), K = 2¹⁸, nbits 2, nprobe 32"),
-            ("c3_np8", "config 3 shape, nprobe 8")]
+            ("c3_np32", "config 3 shape: 8 841 823 docs, clipped LogNormal lengths (mean 73, max 180), K = 2¹⁸, nbits 2, nprobe 32")]
     for k, lab in labs:
         d = reg.get(k)
         if not d:
@@ -150,6 +167,11 @@ def tables():
     cpu = (c4.get("cpu_baseline") or {}).get("value")
     rg.append(f"| config 4's shard: 12.5 M docs on one GPU ({c4['hbm_index_bytes']/1e9:.1f} GB, {c4['hbm_bytes_per_token']:.1f} B/token) | {c4['value']:.0f} | "
               f"{c4['p50_batch_latency_ms']:.2f} | {stage_cells(c4['stages'])} | {'—' if not cpu else f'{cpu:.1f}'} | {par(c4)} |")
+    d = reg.get("c4_k18_12500k")
+    if d:
+        cpu = (d.get("cpu_baseline") or {}).get("value")
+        rg.append(f"| config 4's shard at K = 2¹⁸ (SURVEY §8(d) C4: batched probe, u32 code lists, {d['hbm_index_bytes']/1e9:.1f} GB) | {d['value']:.0f} | "
+                  f"{d['p50_batch_latency_ms']:.2f} | {stage_cells(d['stages'])} | {'—' if not cpu else f'{cpu:.1f}'} | {par(d)} |")
     dk = load(f"{R}_bench_disk_1m.json")
     do = dk["disk_open"]
     cpu = (dk.get("cpu_baseline") or {}).get("value")
@@ -161,10 +183,7 @@ def tables():
     c5 = ["| 10 M docs, B = 64 | queries/s | p50 ms | S4 ms | S6 ms | max rel. score error vs oracle | top-10 ids identical |", "|---|---:|---:|---:|---:|---:|---:|"]
     for lab, d in (("precision 2 (default; split-bf16 QC-reuse)", d10), ("precision 0 (exact-f32 MFMA everywhere)", var.get("prec0")),
                    ("precision 1 (bf16 QC-reuse)", var.get("prec1")), ("precision 3 (plain bf16 MaxSim)", var.get("prec3")),
-                   ("precision 2, single-level filter (`NP_S4_HOT=0`)", var.get("single_level_10m")),
-                   ("precision 2, round-3 first level (byte maxima, `NP_S4_PLANES=0`)", var.get("planes0_10m")),
-                   ("precision 2, exact filter level without the floor (`NP_S4_WARM=1000`)", var.get("warm1000_10m")),
-                   ("precision 2, t_cs = None", var.get("tcs_none"))):
+                   ("precision 2, single-level filter (`--hot 0`)", var.get("single_level_10m"))):
         if not d:
             continue
         pv = d["parity_vs_oracle"]
@@ -173,19 +192,29 @@ def tables():
     c5 = "\n".join(c5)
 
     sh = lines(f"{R}_bench_shard_sizes.jsonl")
-    st = ["| documents on the GPU (= one rank of) | queries/s | p50 ms | S1 | S2 | S3 | S4 | S5 | S6 |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    st = ["| documents on the GPU (= one rank of) | queries/s | p50 ms | S1 | S2 | S3 | S4 | S5 | S6 | CPU oracle q/s | top-10 = oracle |",
+          "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     for lab, d in (("10 M (1 GPU, the N=1 line)", d10), ("5 M (2-way)", sh.get("shard_5m")), ("2.5 M (4-way)", sh.get("shard_2500k")),
                    ("1.25 M (8-way)", sh.get("shard_1250k")), ("1.25 M, through `np_hip_search_batch_sharded` (RCCL, world 1)", sh.get("shard_1250k_rccl"))):
         if d:
-            st.append(f"| {lab} | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {stage_cells(d['stages'])} |")
+            cpu = (d.get("cpu_baseline") or {}).get("value")
+            st.append(f"| {lab} | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {stage_cells(d['stages'])} | {'—' if not cpu else f'{cpu:.1f}'} | {par(d)} |")
     st += ["", "(Single-GPU runs of a corpus of that size: S6 is the full `n_sel` here, whereas a rank of the real split exact-scores only its share of the global cut.)"]
     st = "\n".join(st)
 
     hs = ["| S4 filter, 10 M documents | table rows gathered / batch | documents at the exact level | S4 ms | queries/s |", "|---|---:|---:|---:|---:|"]
-    for lab, d in (("single level (exact u8 bound of every candidate, `NP_S4_HOT=0`)", var.get("single_level_10m")),
-                   ("two levels, first level as byte maxima (round 3, `NP_S4_PLANES=0`; 10 % hot)", var.get("planes0_10m")),
-                   ("two levels, first level in bit planes (6 % hot), exact level gathers every row (`NP_S4_WARM=1000`)", var.get("warm1000_10m")),
-                   ("two levels, bit planes (6 % hot) + floored exact level (rows of the warmest 50 % of the centroids): default", d10)):
+    r4 = {}
+    try:
+        r4 = {json.loads(l)["name"]: json.loads(l) for l in open(P + "r04_bench_variants_10m.jsonl") if l.strip()}
+        r4["default"] = json.load(open(P + "r04_bench_default_10m.json"))
+    except OSError:
+        pass
+    for lab, d in (("round 4 (table over [-s, s]): single level, `NP_S4_HOT=0`", r4.get("single_level_10m")),
+                   ("round 4: two levels, first level as byte maxima (round 3's kernel, `NP_S4_PLANES=0`; 10 % hot)", r4.get("planes0_10m")),
+                   ("round 4: two levels, bit planes (6 % hot), exact level gathers every row (`NP_S4_WARM=1000`)", r4.get("warm1000_10m")),
+                   ("round 4: two levels, bit planes + floored exact level (its default)", r4.get("default")),
+                   ("**round 5** (table over the positive scores): single level (`--hot 0`)", var.get("single_level_10m")),
+                   ("**round 5: two levels, bit planes (6 % hot) + floored exact level: default**", d10)):
         if d:
             x = d["stages"]
             hs.append(f"| {lab} | {x['n_cand_codes']/1e6:.0f} M | {(x['n_level2'] or x['n_candidates'])/1e6:.2f} M | {x['ms_approx']:.2f} | {d['value']:.0f} |")
