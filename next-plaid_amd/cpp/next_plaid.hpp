@@ -198,6 +198,8 @@ class MmapIndex {
       check(rc);
     }
     for (size_t i = 0; i < n; ++i) {
+      // ABI v5: a negative count (NP_COUNT_ABANDONED) marks a batch a sharded peer abandoned -- never a length
+      if (cnt[i] < 0) throw Error(NP_ERR_SEARCH, "Search failed: the batch was abandoned (a peer shard failed)");
       out[i].passage_ids.assign(ids.begin() + i * k, ids.begin() + i * k + cnt[i]);
       out[i].scores.assign(sc.begin() + i * k, sc.begin() + i * k + cnt[i]);
     }

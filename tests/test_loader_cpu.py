@@ -71,6 +71,13 @@ def test_metadata_counts_are_inferred_when_zero(index_dir):
     assert abs(info.avg_doclen - a["doc_lengths"].mean()) < 1e-9
 
 
+def test_probe_reports_the_abi_version(index_dir):
+    """np_info of ABI v5: abi_version 5, workspace_bytes (the live scratch budget) 0 for a host-only probe."""
+    p, a = index_dir
+    info = npa.probe_index_dir(p)
+    assert info.abi_version == 5 and info.workspace_bytes == 0 and info.device == -1
+
+
 def test_merged_cache_and_extra_files_are_ignored(index_dir):
     p, a = index_dir
     np.save(os.path.join(p, "merged_codes.npy"), np.zeros(7, "<i8"))             # derived cache: never read
