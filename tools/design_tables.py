@@ -20,7 +20,7 @@ GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
     f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "single_level_10m"],
     f"{R}_bench_regimes.jsonl": ["api_default", "tcs_none", "dist05", "dist08", "lq48_10m", "nfs8192_10m", "colgrep_10m", "k19_10m",
-                                 "k19_split_10m", "c3_np32", "c4_k18_12500k"],
+                                 "k19_split_10m", "c3_np32", "c4_k18_12500k", "k20_2500k"],
 }
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k",
            f"{R}_bench_disk_1m.json": "disk1m"}
@@ -172,6 +172,12 @@ def tables():
         cpu = (d.get("cpu_baseline") or {}).get("value")
         rg.append(f"| config 4's shard at K = 2¹⁸ (SURVEY §8(d) C4: batched probe, u32 code lists, {d['hbm_index_bytes']/1e9:.1f} GB) | {d['value']:.0f} | "
                   f"{d['p50_batch_latency_ms']:.2f} | {stage_cells(d['stages'])} | {'—' if not cpu else f'{cpu:.1f}'} | {par(d)} |")
+    d = reg.get("k20_2500k")
+    if d:
+        cpu = (d.get("cpu_baseline") or {}).get("value")
+        rg.append(f"| K = 2²⁰ on 2.5 M docs (config 4's K range on a corpus that leaves room for the 8.6 GB of f32 scores per batch; single-level filter: "
+                  f"the hot bitmap of K > 2¹⁹ does not fit LDS) | {d['value']:.0f} | {d['p50_batch_latency_ms']:.2f} | {stage_cells(d['stages'])} | "
+                  f"{'—' if not cpu else f'{cpu:.1f}'} | {par(d)} |")
     dk = load(f"{R}_bench_disk_1m.json")
     do = dk["disk_open"]
     cpu = (dk.get("cpu_baseline") or {}).get("value")
