@@ -122,3 +122,26 @@ def test_stage_traffic_is_the_sum_over_all_kernels_of_the_stage():
 def test_bench_argument_parsing_needs_no_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+def test_make_traffic_refuses_a_kernel_without_a_stage(tmp_path):
+    """The failure of round 4, as a test: a library kernel that moves more than 1 % of a batch's bytes and has no stage in
+    tools/stage_map.py makes tools/make_traffic.py fail instead of silently dropping out of the roofline."""
+    def write(pass_dir, counter, rows):
+        os.makedirs(pass_dir)
+        with open(os.path.join(pass_dir, "p_counter_collection.csv"), "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for k, v in rows:
+                f.write(f'"void np::{k}<32>(int)",{counter},{v}\n')
+    rows = [("prep_queries_kernel", 100), ("qc_gemm_kernel", 1000), ("approx_hotp_kernel", 5000), ("approx_hotq_kernel", 4000)]
+    write(str(tmp_path / "bad" / "p1"), "FETCH_SIZE", rows)
+    write(str(tmp_path / "bad" / "p2"), "WRITE_SIZE", rows)
+    tool = os.path.join(ROOT, "tools", "make_traffic.py")
+    out = subprocess.run([sys.executable, tool, str(tmp_path / "bad"), "10000000", str(tmp_path / "t.json")], capture_output=True, text=True)
+    assert out.returncode == 2 and "approx_hotq_kernel" in out.stderr, (out.returncode, out.stderr[-400:])
+    write(str(tmp_path / "good" / "p1"), "FETCH_SIZE", rows[:3])
+    write(str(tmp_path / "good" / "p2"), "WRITE_SIZE", rows[:3])
+    out = subprocess.run([sys.executable, tool, str(tmp_path / "good"), "10000000", str(tmp_path / "t.json")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-400:]
+    t = json.load(open(tmp_path / "t.json"))
+    assert t["approx(S4)"] == (2 * 5000 + 5000) * 1024 and t["qc_gemm(S1)"] == (2 * 1000 + 1000 + 2 * 100 + 100) * 1024

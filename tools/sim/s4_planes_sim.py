@@ -1,4 +1,8 @@
 #!/usr/bin/env python3
+# NOTE (round 5): this simulation models the u8 table of rounds 2-4, u = floor((x / s + 1) * 127.5) + 1 over [-s, s] -- the table the
+# committed outputs under profiles/r03_sim_* / r04_sim_* were produced with.  The shipped table now spans the positive scores only
+# (u = floor(max(x, 0) / s * 254) + 1, np_kernels.h): shares and level spacings carry over (they are ratios of the per-centroid
+# maxima), absolute thresholds and survivor counts do not (the slack is half as wide in score units).
 """CPU simulation of a bit-PLANE form of the S4 hot bound (design aid, not product code).
 
 The hot bound U'(d) = sum_q max(Lambda, max_{c in codes(d), c hot} u[q,c]) folds 32 byte maxima per table row.  If the
