@@ -362,6 +362,10 @@ def main():
         step(i)
         torch.cuda.synchronize(dev)
         lat.append((time.perf_counter() - t1) * 1e3)
+        if use_shards and dist_impl == "c":   # per batch here (the batch is synchronised anyway): a peer's failure shows at once
+            fr, code = comms[i % nstr].status()
+            if code:
+                raise SystemExit(f"bench.py: shard {fr} failed with np_status {code} in a latency batch")
     p50 = float(np.median(lat)) if lat else None
 
     # ---- per-stage durations (HIP events on the call's stream) + work counters; the same calls, timed on the host
