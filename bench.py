@@ -69,7 +69,10 @@ def parse():
     ap.add_argument("--precision", type=int, default=2,
                     help="exact MaxSim arithmetic: 2 QC-reuse split-bf16 (f32-class, the library default), 0 exact-f32 MFMA, "
                          "1 QC-reuse bf16, 3 plain bf16")
-    ap.add_argument("--cpu-queries", type=int, default=16, help="queries per repeat of the CPU-oracle leg (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=64,
+                    help="queries per repeat of the CPU-oracle leg (0 = skip).  64 = one batch, BASELINE.md section 3: the oracle's outer "
+                         "OpenMP level runs min(queries, threads) queries at once like the reference's rayon par_iter (search.rs:650-664), "
+                         "so a batch of 64 fills a 128-thread box with 2 inner threads each; 16 queries left the inner level to do it")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--parity-queries", type=int, default=64, help="queries compared with the oracle at full size")
     ap.add_argument("--cpu-docs", type=int, default=0,
@@ -121,8 +124,34 @@ def cpu_model():
     return "unknown"
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1) and pass rank 0's JSON line through.  Fails loudly when the box has fewer than N GPUs (unless --hosted: N ranks
+    that share GPU 0) -- a silent one-rank run labelled n_gpus: 1 is what this replaces."""
+    import socket
+    import subprocess
+    if not a.hosted:
+        import next_plaid_amd as npa
+        have = npa.device_count()
+        if have < a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but this box has {have} gfx950 device(s) "
+                             f"(--hosted runs {a.gpus} ranks on GPU 0 over the hosted transport: a control-flow run, not a scaling one)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_PORT"] = str(port)          # main() only setdefault()s these: torchrun's values win inside the ranks
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher in the environment (WORLD_SIZE unset): starting the ranks with\n  " + " ".join(cmd), file=sys.stderr)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     # stdout carries exactly ONE line, the JSON: everything else this process (or a C library inside it -- RCCL prints
     # a version banner through C stdio) writes to fd 1 goes to stderr
     json_fd = os.dup(1)
@@ -134,7 +163,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if npa.device_count() < 1:
         raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
@@ -296,7 +325,9 @@ def main():
             print("bench.py:" + dist_note, file=sys.stderr)
         elif err:
             raise SystemExit(f"bench.py: the RCCL communicator could not be created: {err}")
+    comm_info = None
     if use_shards and dist_impl == "c":
+        comm_info = comms[0].info()
         sss = [CShardedSearcher(ix, comms[s], stream=streams[s]) for s in range(nstr)]
         ss = sss[0]
 
@@ -549,9 +580,10 @@ def main():
                 tc = float(np.median(reps))
                 cpu = dict(value=round(nc / tc, 3), unit="queries/s", cores=O.num_threads(), kind="port",
                            cpu_model=cpu_model(), repeats=len(reps), seconds=[round(x, 2) for x in reps],
-                           sample=f"{nc} queries x {len(reps)} repeats (median) on {cdocs} of the {a.docs} docs, same parameters; "
-                                  f"oracle C restatement of next-plaid 1.6.1 search.rs, OpenMP over queries/candidates like the "
-                                  f"reference's rayon structure")
+                           threads_outer=min(nc, O.num_threads()), threads_inner=max(1, O.num_threads() // max(1, min(nc, O.num_threads()))),
+                           sample=f"{nc} queries (one batch) x {len(reps)} repeats (median) on {cdocs} of the {a.docs} docs, same parameters; "
+                                  f"oracle C restatement of next-plaid 1.6.1 search.rs, OpenMP over queries (outer) / candidates (inner) "
+                                  f"like the reference's nested rayon structure")
             if a.parity_queries > 0:
                 npq = min(a.parity_queries, nq)
                 ref = ox.search_batch(qs[:npq], po)
@@ -579,6 +611,10 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 4), "p50_batch_latency_ms": None if p50 is None else round(p50, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "hosted": bool(a.hosted),
+        # what the communicator of rank 0's replica group really is (np_hip_comm_info): transport "rccl" with rccl_ranks_seen =
+        # ncclCommCount == shards on a healthy multi-GPU run; "hosted" = gloo on one GPU; None = no sharded protocol in this run
+        "transport": (comm_info or {}).get("transport") if use_shards and dist_impl == "c" else ("torch.distributed" if use_shards else None),
+        "rccl_ranks_seen": (comm_info or {}).get("rccl_ranks"),
         "hosted_note": ("all %d ranks share GPU 0 and the collectives run over the hosted (gloo) transport: a run of the multi-rank "
                         "control flow, NOT a scaling measurement (RCCL refuses two ranks on one device)" % world) if a.hosted else None,
         "dtype": {0: "f32", 1: "f32 (bf16 MFMA on the residual term of MaxSim)",

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NP_ABI_VERSION 5
+#define NP_ABI_VERSION 6
 
 typedef enum np_status {
   NP_OK = 0,
@@ -96,7 +96,9 @@ typedef struct np_stats {
   float ms_total;        /* first launch -> results ready */
   float ms_centroid;     /* S1  Q.C^T (MFMA) + group maxima */
   float ms_probe;        /* S2  top-nprobe per token, threshold, cell list */
-  float ms_candidates;   /* S3  posting-list union (bitmap) + compaction */
+  float ms_candidates;   /* S3  posting-list union (bitmap) + compaction; since round 5 also the hot level's thresholds and plane
+                            rows (they follow the candidate count), since round 6 the zeroth filter level (three sweeps of the
+                            posting lists + the exact bound of its S0 list) */
   float ms_approx;       /* S4  approximate scores (codes x QC gather) */
   float ms_select;       /* S5  top n_full_scores/4 by approximate score */
   float ms_exact;        /* S6  decompress + MaxSim (MFMA) */
@@ -116,6 +118,8 @@ typedef struct np_stats {
   float ms_hot_level;    /* ABI v5: the first filter level's launch alone (approx_hotp_kernel / approx_hot_kernel of round 0;
                             part of ms_approx; 0 when the two-level filter does not apply) */
   int32_t reserved0;
+  int64_t n_level0;      /* ABI v6: candidates the zeroth filter level (per-document sums of the probed cells' gains, S3) handed to
+                            the filter; n_candidates stays the size of the posting-list union; 0 when the level did not run */
 } np_stats;
 
 /* ---- runtime ------------------------------------------------------------------------------ */
@@ -126,6 +130,14 @@ int np_hip_device_count(void);
 
 /* Thread-local description of the last error on this thread ("" if none). */
 const char* np_hip_last_error(void);
+
+/* ABI v6: the library's NP_ABI_VERSION, readable BEFORE any struct crosses the boundary.  np_info and np_stats are
+ * caller-allocated and have grown (v5: np_info.workspace_bytes, np_stats.ms_hot_level): a host compiled against an older
+ * header would have bytes written past its structs before it could read np_info.abi_version.  A host binds this first and
+ * refuses a library whose version differs from the header it was built with; np_hip_struct_size lets it check the two
+ * layouts it allocates (which: 0 = np_info, 1 = np_stats, 2 = np_search_params, 3 = np_open_opts; -1 for an unknown id). */
+int np_hip_abi_version(void);
+int64_t np_hip_struct_size(int32_t which);
 
 /* ---- index lifecycle ------------------------------------------------------------------------ */
 
@@ -200,8 +212,11 @@ int np_hip_index_write_dir(const char* index_dir, const np_index_arrays* arrays,
  * both paths clamp through one table.  Knobs: "s4_mode" 0..8, "s4_minb" >= 1, "s4_nbx" 8..512, "s4_swz" 0/1,
  * "s4_filter" 0/1, "s4_hot" 0..500 (per-mille of hot centroids in the first filter level; 0 = single-level filter),
  * "s4_planes" 0/1 (first level in bit planes; read at open too: it sets the list-block cap), "s4_pexp" 5..40, "s4_lpd" 2/4,
- * "s4_qm" 0/1, "s4_pnbx" 8..512, "s4_warm" 1..1000 (per-mille of centroids whose rows the exact filter level still gathers
- * for the S2 lists; 1000 = every row), "s1_split" 0/1 (the only knob that changes values: see INTEGRATION.md),
+ * "s4_qm" 0/1, "s4_pnbx" 8..512, "s4_warm" 0..1000 (per-mille of centroids whose rows the exact filter level still gathers
+ * for the S2 lists; 1000 = every row; 0 = the default: by query length and mean distinct-code count), "s4_hot_auto" >= 0 (candidates
+ * per query up to which "s4_hot" applies as given; beyond it the share falls with the count^(-1/3); 0 = always as given),
+ * "ub_ncut" 1..512, "s3_bisect" 0/1, "s3_gain" 0/1 (zeroth filter level; read at open too: 0 = its range table is not built),
+ * "s3_gain_mult" 1..16, "s3_gain_direct" 0..64, "s1_split" 0/1 (the only knob that changes values: see INTEGRATION.md),
  * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "ub_direct" 0..16, "ub_static" 0/1, "hot_static" 0/1, "s6_xcd" 0/1, "s6_tiles" 0/1, "s6_lds" 0..2, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
  * Results are identical for every setting except "s1_split"; not synchronised with concurrent searches.  Unknown name:
  * NP_ERR_INVALID_ARGUMENT.  (A library built with -DNP_DIAGNOSTICS also accepts "s4_probe" 0..7, a phase-skipping timing
@@ -314,6 +329,15 @@ void np_hip_comm_destroy(np_comm* comm);
 /* Reads and clears the failure word of the communicator's last batches: *failed_rank = -1 and *code = 0 if every batch
  * since the last call was healthy, else the first failed rank and its np_status.  Call after synchronising the stream. */
 int np_hip_comm_status(np_comm* comm, int32_t* failed_rank, int32_t* code);
+/* ABI v6: what a communicator really is, for a bench line or a health endpoint.  *transport = NP_COMM_LOCAL (one rank, no
+ * collective library at all), NP_COMM_RCCL (ncclCommInitRank succeeded) or NP_COMM_HOSTED; *nranks = the size the
+ * communicator was created with; *rccl_ranks = ncclCommCount of the RCCL communicator (the number of ranks RCCL itself
+ * sees: equals nranks on a healthy communicator), 0 for the other transports or a librccl without ncclCommCount.  Any
+ * pointer may be NULL. */
+#define NP_COMM_LOCAL 0
+#define NP_COMM_RCCL 1
+#define NP_COMM_HOSTED 2
+int np_hip_comm_info(np_comm* comm, int32_t* transport, int32_t* nranks, int32_t* rccl_ranks);
 /* The same protocol over a transport the HOST brings (MPI, gloo, shared memory, the crate's own RPC) instead of RCCL:
  * for hosts without librccl, for ranks that share one GPU (RCCL refuses two ranks on a device), and for the tests that
  * run the shipped multi-rank code path on a one-GPU box.  `all_gather(ctx, send, recv, bytes)` is called on the calling

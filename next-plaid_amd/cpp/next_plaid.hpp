@@ -123,6 +123,7 @@ class MmapIndex {
   // CPU hook); a device failure raises the flag and falls back unless FORCE_GPU; every other error is the caller's.
   static MmapIndex load(const std::string& index_path, const np_open_opts* opts = nullptr) {
     if ((is_force_cpu() || (is_hip_broken() && !is_force_gpu())) && cpu_fallback()) return MmapIndex(nullptr, index_path);
+    check_abi();
     np_index* h = nullptr;
     const int rc = np_hip_index_open(index_path.c_str(), opts, &h);
     if (is_device_failure(rc)) {
@@ -135,6 +136,14 @@ class MmapIndex {
     }
     check(rc);
     return MmapIndex(h, index_path);
+  }
+  // The library this binary RUNS against must speak the header it was COMPILED against: np_info / np_stats are allocated here and
+  // have grown between ABI versions (np_hip_abi_version exists since v6; an older library fails at link / load time already).
+  static void check_abi() {
+    if (np_hip_abi_version() != NP_ABI_VERSION || np_hip_struct_size(0) != (int64_t)sizeof(np_info) ||
+        np_hip_struct_size(1) != (int64_t)sizeof(np_stats))
+      throw std::runtime_error("libnextplaid_hip speaks ABI v" + std::to_string(np_hip_abi_version()) + ", this host was built against v" +
+                               std::to_string(NP_ABI_VERSION));
   }
   // MmapIndex::reload (index.rs:1767-1775): after delete / update rewrote the directory.  The crate releases its maps before
   // it loads again; here the device copy is dropped first for the same reason (two copies of a 200 GB index do not fit).

@@ -41,6 +41,7 @@ struct NcclApi {
   int (*CommDestroy)(NcclComm) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(NcclComm, int*) = nullptr;   // optional
   std::string err;
 };
 
@@ -62,6 +63,7 @@ static NcclApi* nccl_api() {
     api.CommDestroy = (int (*)(NcclComm))dlsym(api.lib, "ncclCommDestroy");
     api.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(api.lib, "ncclAllGather");
     api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+    api.CommCount = (int (*)(NcclComm, int*))dlsym(api.lib, "ncclCommCount");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
       api.err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
       api.lib = nullptr;
@@ -214,6 +216,19 @@ int np_hip_comm_status(np_comm* c, int32_t* failed_rank, int32_t* code) {
   const uint64_t w = __atomic_exchange_n(c->h_status, 0ull, __ATOMIC_ACQ_REL);
   if (failed_rank) *failed_rank = w ? (int32_t)(w >> 32) - 1 : -1;
   if (code) *code = (int32_t)(w & 0xffffffffu);
+  return NP_OK;
+}
+
+int np_hip_comm_info(np_comm* c, int32_t* transport, int32_t* nranks, int32_t* rccl_ranks) {
+  if (!c) return NP_ERR_INVALID_ARGUMENT;
+  if (transport) *transport = c->host_fn ? NP_COMM_HOSTED : (c->comm ? NP_COMM_RCCL : NP_COMM_LOCAL);
+  if (nranks) *nranks = c->nranks;
+  if (rccl_ranks) {
+    int n = 0;
+    NcclApi* a = c->comm ? nccl_api() : nullptr;
+    if (a && a->CommCount && a->CommCount(c->comm, &n) != kNcclSuccess) n = 0;
+    *rccl_ranks = n;
+  }
   return NP_OK;
 }
 

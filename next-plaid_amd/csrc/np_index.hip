@@ -83,6 +83,9 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "s4_warm") t->s4_warm = clamp(value, 0, 1000);
   else if (n == "ub_ncut") t->ub_ncut = clamp(value, 1, 512);
   else if (n == "s3_bisect") t->s3_bisect = clamp(value, 0, 1);
+  else if (n == "s3_gain") t->s3_gain = clamp(value, 0, 1);
+  else if (n == "s3_gain_mult") t->s3_gain_mult = clamp(value, 1, 16);
+  else if (n == "s3_gain_direct") t->s3_gain_direct = clamp(value, 0, 64);
   else if (n == "s4_hot_auto") t->s4_hot_auto = clamp(value, 0, 0x7fffffff);
   else if (n == "ub_nt") t->ub_nt = value < 0 || value > 2 ? 0 : value;
   else if (n == "ub_steal") t->ub_steal = value < 1 ? 1 : value;
@@ -106,7 +109,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
 void read_tuning_env(Tuning* t) {
   static const char* const knobs[][2] = {
       {"NP_S4_MODE", "s4_mode"}, {"NP_S4_MINB", "s4_minb"}, {"NP_S4_NBX", "s4_nbx"}, {"NP_S4_SWZ", "s4_swz"},
-      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S4_LPD", "s4_lpd"}, {"NP_S4_QM", "s4_qm"}, {"NP_S4_PNBX", "s4_pnbx"}, {"NP_S4_WARM", "s4_warm"}, {"NP_UB_NCUT", "ub_ncut"}, {"NP_S3_BISECT", "s3_bisect"}, {"NP_S4_HOT_AUTO", "s4_hot_auto"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
+      {"NP_S4_FILTER", "s4_filter"}, {"NP_S4_HOT", "s4_hot"}, {"NP_S4_PLANES", "s4_planes"}, {"NP_S4_PEXP", "s4_pexp"}, {"NP_S4_LPD", "s4_lpd"}, {"NP_S4_QM", "s4_qm"}, {"NP_S4_PNBX", "s4_pnbx"}, {"NP_S4_WARM", "s4_warm"}, {"NP_UB_NCUT", "ub_ncut"}, {"NP_S3_BISECT", "s3_bisect"}, {"NP_S3_GAIN", "s3_gain"}, {"NP_S3_GAIN_MULT", "s3_gain_mult"}, {"NP_S3_GAIN_DIRECT", "s3_gain_direct"}, {"NP_S4_HOT_AUTO", "s4_hot_auto"}, {"NP_S3_SLICES", "s3_slices"}, {"NP_UB_NT", "ub_nt"},
       {"NP_UB_STEAL", "ub_steal"}, {"NP_UB_NBX", "ub_nbx"}, {"NP_UB_DIRECT", "ub_direct"}, {"NP_UB_STATIC", "ub_static"}, {"NP_HOT_STATIC", "hot_static"}, {"NP_S6_XCD", "s6_xcd"}, {"NP_S6_TILES", "s6_tiles"}, {"NP_S6_LDS", "s6_lds"}, {"NP_GEMM_CPW", "gemm_cpw"}, {"NP_S1_SPLIT", "s1_split"},
       {"NP_EXACT_ROWMAX", "exact_rowmax"}};
   for (const auto& k : knobs) {
@@ -183,6 +186,7 @@ void destroy_device_index(DeviceIndex* ix) {
   (void)hipFree(ix->d_doc_offsets);
   (void)hipFree(ix->d_ivf);
   (void)hipFree(ix->d_ivf_offsets);
+  (void)hipFree(ix->d_ivf_split);
 }
 
 static uint32_t bitrev(uint32_t v, int nbits) {
@@ -506,6 +510,44 @@ __global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim /* row
     if (lane == i) mine = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
   }
   if (t0 + lane < T) inv_norm[t0 + lane] = mine;
+}
+
+// ivf_split[c][r] = number of entries of posting list c with id < r * 32768 (r = 0 .. n_ranges): the zeroth filter level
+// (gain_sweep_kernel, np_kernels.h) holds the accumulators of one 32768-document range per block and reads exactly its part of
+// every probed list.  One thread per (list, boundary), a bisection each; ascending lists only.
+#define NP_SPLIT_RANGE 32768
+__global__ void __launch_bounds__(256) ivf_split_kernel(const uint32_t* __restrict__ ivf, const int64_t* __restrict__ ivf_off,
+                                                        int64_t K, int R1, uint32_t* __restrict__ split) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * R1) return;
+  const int64_t c = i / R1;
+  const int r = (int)(i - c * R1);
+  const int64_t s0 = ivf_off[c];
+  const uint32_t len = (uint32_t)(ivf_off[c + 1] - s0);
+  const uint64_t bound = (uint64_t)r * NP_SPLIT_RANGE;
+  const uint32_t* L = ivf + s0;
+  uint32_t a = 0, z = len;
+  while (a < z) {
+    const uint32_t mid = (a + z) >> 1;
+    if ((uint64_t)L[mid] < bound) a = mid + 1;
+    else z = mid;
+  }
+  split[i] = a;
+}
+
+static int build_ivf_split(DeviceIndex* ix) {
+  ix->d_ivf_split = nullptr;
+  ix->n_ranges = 0;
+  if (!ix->tune.s3_gain || !ix->tune.s4_planes || !ix->ivf_sorted || ix->n_docs <= 0 || ix->K <= 0 || ix->ublock_stride <= 0) return NP_OK;
+  const int R = (int)((ix->n_docs + NP_SPLIT_RANGE - 1) / NP_SPLIT_RANGE), R1 = R + 1;
+  const size_t n = (size_t)ix->K * (size_t)R1;
+  if (n * 4 > ((size_t)2 << 30)) return NP_OK;   // a table beyond 2 GiB (K x n_docs both huge) is not worth its HBM: the level stays off
+  NP_TRY(dev_alloc(&ix->d_ivf_split, n, &ix->device_bytes));
+  ivf_split_kernel<<<(unsigned)((n + 255) / 256), 256>>>(ix->d_ivf, ix->d_ivf_offsets, ix->K, R1, ix->d_ivf_split);
+  NP_HIP(hipGetLastError());
+  NP_HIP(hipDeviceSynchronize());
+  ix->n_ranges = R;
+  return NP_OK;
 }
 
 static int build_inv_norm(DeviceIndex* ix) {
@@ -1100,6 +1142,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     NP_TRY(rc);
   }
   trace.mark("distinct-code blocks");
+  NP_TRY(build_ivf_split(ix));
   NP_TRY(build_inv_norm(ix));
   trace.mark("inverse norms");
   default_workspace(ix);
@@ -1472,6 +1515,7 @@ static int synth_build(const np_synth_spec* s, const np_open_opts* opts_in, Devi
     (void)hipFree(d_uoff);
     NP_TRY(rc);
   }
+  NP_TRY(build_ivf_split(ix));
   NP_TRY(build_inv_norm(ix));
   default_workspace(ix);
   cleanup.p = nullptr;
@@ -1485,6 +1529,18 @@ using namespace np;
 
 // =================================== C ABI ====================================================
 extern "C" {
+
+int np_hip_abi_version(void) { return NP_ABI_VERSION; }
+
+int64_t np_hip_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(np_info);
+    case 1: return (int64_t)sizeof(np_stats);
+    case 2: return (int64_t)sizeof(np_search_params);
+    case 3: return (int64_t)sizeof(np_open_opts);
+    default: return -1;
+  }
+}
 
 int np_hip_device_count(void) {
   int n = 0;

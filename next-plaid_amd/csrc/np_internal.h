@@ -124,6 +124,12 @@ struct Tuning {
   int s4_swz = 1;        // ds_swizzle vs ds_bpermute code broadcast
   int s3_bisect = 1;     // S3: a bitmap range reads only its part of every (ascending) posting list instead of sweeping all of it
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
+  int s3_gain = 1;       // zeroth filter level (gain_sweep_kernel): per-document sums of the probed cells' gains prune the candidates
+                         // before any list block is read -- where no centroid_score_threshold is set (with one, the removed cells
+                         // lift the bound's floor above the cut: tools/sim/s3_gain_sim.py).  Read at OPEN too (0: the range table of
+                         // the posting lists is not built)
+  int s3_gain_mult = 3;  // ... S0 = the s3_gain_mult x n_sel candidates with the largest bound take the exact bound first (tau0)
+  int s3_gain_direct = 16;   // ... workgroups per query of that launch (0 = one query per XCD at a time, like the S2 list)
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
   int s4_hot = 60;       // per-mille of the centroids that are "hot" for a query in the first filter level (0 = single-level
                          // filter).  More hot centroids: fewer documents left to the exact bound (S1 + S2: 2.79 M / 2.20 M / 1.81 M of
@@ -201,6 +207,9 @@ struct DeviceIndex {
   int64_t* d_ivf_offsets = nullptr;
   int64_t ivf_size = 0;
   bool ivf_sorted = false;        // every posting list ascends (what the crate writes): S3 may bisect a list for a document range
+  uint32_t* d_ivf_split = nullptr;   // [K][n_ranges + 1] (derived, ascending lists only): entries of list c with id < 32768 r -- the
+                                  // zeroth filter level's blocks read their range's part of a posting list without a bisection
+  int n_ranges = 0;               // ceil(n_docs / 32768)
   size_t device_bytes = 0;
   np_open_opts opts{};
   // per-context scratch budget the planner uses.  A caller-given workspace_bytes is kept as it is; the default (what the device

@@ -68,6 +68,7 @@ struct Counters {  // per-call work counters (np_stats)
   unsigned long long n_survivors;  // candidates that passed the S4 upper-bound filter (= n_candidates when it is off)
   unsigned long long n_cand_dcodes;  // distinct (document, code) pairs of the candidates (the hot level scans these)
   unsigned long long n_level2;       // two-level filter: documents that took the exact u8 bound (S1 + S2)
+  unsigned long long n_level0;       // zeroth level (gain_sweep_kernel): candidates it handed to the filter (0 = level not run)
 };
 
 // One launch instead of a dozen hipMemsetAsync calls per batch (each ~3.6 us on the stream: 50 us per batch at 1 M
@@ -1164,11 +1165,16 @@ struct RoundPlan {
 };
 
 __global__ void __launch_bounds__(256) plan_rounds_kernel(const int32_t* __restrict__ chunk_counts, int nchunks, int B,
-                                                          int64_t pool, int max_rounds, RoundPlan rp, Counters* ctr) {
+                                                          int64_t pool, int max_rounds, RoundPlan rp, Counters* ctr,
+                                                          const int32_t* __restrict__ n_direct = nullptr /* [B]: the queries' candidate
+                                                              counts as they are (the zeroth level has counted -- and charged --
+                                                              them: gain_count_kernel) instead of sums of chunk populations */) {
   __shared__ int s_n[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int b = wave; b < B; b += 4) {
     int c = 0;
+    if (n_direct) c = lane == 0 ? n_direct[b] : 0;
+    else
     for (int j = lane; j < nchunks; j += 64) c += chunk_counts[(int64_t)b * nchunks + j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
@@ -1197,7 +1203,7 @@ __global__ void __launch_bounds__(256) plan_rounds_kernel(const int32_t* __restr
     }
     rp.round_tab[2 * r + 1] = B;
     rp.round_tab[2 * max_rounds] = r + 1;
-    atomicAdd(&ctr->n_candidates, total);
+    if (!n_direct) atomicAdd(&ctr->n_candidates, total);
     atomicMax(&ctr->n_rounds, (unsigned long long)(r + 1));
   }
   __syncthreads();
@@ -1301,6 +1307,376 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
       }                            // writes the records itself), the unfiltered selection, the debug trace
       ++pos;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S3, ZEROTH filter level (round 6): an upper bound of a candidate's approximate score from the probed cells alone -- from
+// what S3 sees while it unions the posting lists, before any list block is read.
+//   top(q)  = token q's top-n_probe centroids (search.rs:388-414); theta_q = its n_probe-th best score (tauq, S2)
+//   P       = the probed cells = union of top(q).  Without a centroid_score_threshold every probed cell is kept, and a centroid
+//             OUTSIDE P is in no token's top-n_probe: QC[q, c] <= theta_q for every token q
+//   in table units (u = S1's monotone u8 table):  ut_q = u(theta_q),   G(c) = sum_q max(0, u[q, c] - ut_q)   for c in P
+//   U0(d)   = sum_q ut_q + sum_{c in P, d in list(c)} (G(c) + 1)
+//          >= sum_q max(ut_q, max_{c in P & codes(d)} u[q, c])  >=  sum_q max_{c in codes(d)} u[q, c] = U(d)
+// (a sum over the document's probed cells instead of a per-token maximum: ONE accumulator per document; the +1 marks the
+// document as a candidate whatever its cells' gains).  d is in list(c) exactly when c is one of its codes, so the accumulator
+// is a scatter-add of G(c) + 1 over the probed posting lists -- what mark_slices_kernel does with one bit.  U0 is an upper
+// bound of the exact integer bound U, so it may stand in front of the existing cuts: with tau0 = the n_sel-th largest LOWER
+// bound L among ANY set S0 of candidates (approx_ub_kernel on the ~3 n_sel documents with the largest U0), a document with
+// U0 < tau0 - slack cannot be among the n_sel best (np_kernels.h "S4, upper-bound filter": the same argument with U0 >= U).
+// CPU simulation on the metric corpus first (tools/sim/s3_gain_sim.py, profiles/r06_sim_s3_gain_*.txt): with t_cs = None the
+// bound keeps 0.2-2 % of the 6.1 M candidates per query at nprobe 32 (every query) and 1-9 % of the 2.06 M at nprobe 8 for
+// three queries in four (no pruning for the fourth: sum_q theta_q reaches its tau); with the default threshold 0.4 the ~900
+// REMOVED cells of a query (search.rs:417-425) would have to enter theta (their scores reach 0.4) and sum theta' = 11.5
+// exceeds tau ~ 10-12: nothing to gain there, so the level runs only where no threshold is set.
+//
+// Three sweeps over the probed posting lists, each block (range r, query b) holding the u16 accumulators of 32768 documents
+// in LDS (two per dword, ds_add_u32; the gains are scaled so that the sum over ALL probed cells fits 16 bits: no carry into
+// the neighbour): 0 = histogram of U0 + candidate count, 1 = emit S0 (records for the exact bound), 2 = emit the candidates
+// that pass the cut (bare ids, in blocks of ascending ids: the hot level takes claims in any order).  A range's part of a
+// posting list comes from a static table built at open (ivf_split[c][r] = first entry of list c with id >= 32768 r).
+// ---------------------------------------------------------------------------------------------
+#define NP_UB_BINS 2048    // histogram bins of the integer bounds: bin = U >> hshift, hshift = log2(ROWB / 32) + 2 (U <= 255 * ROWB);
+                           // u32 counters in LDS (8 KB): a workgroup's share of a query's documents is unbounded
+#define NP_GAIN_RANGE 32768      // documents per accumulator range
+#define NP_GAIN_CELLS 256        // probed cells staged per pass
+#define NP_GAIN_ITEM 32          // posting entries per work item (half a wave)
+
+// per query: ut_q, base = sum ut_q, G(c) + 1 per probed cell (scaled by 2^-shift, rounded up, when their sum would not fit
+// 16 bits), and the trivial round plan of the S0 exact-bound launch (one round, identity order, fixed-size slices)
+template <int RB>
+__global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restrict__ QCU, int64_t KP,
+                                                        const uint32_t* __restrict__ cells, const int32_t* __restrict__ n_cells,
+                                                        const uint32_t* __restrict__ tauq, int LQP, const float* __restrict__ qinv,
+                                                        const int32_t* __restrict__ qoff, uint16_t* __restrict__ gain /* [B][KP] */,
+                                                        uint32_t* __restrict__ gbase /* [B][2]: base, shift */, int B, int s0cap,
+                                                        RoundPlan rp0) {
+  static_assert(RB == 32 || RB == 64, "rows of 32 or 64 query tokens");
+  __shared__ uint32_t s_ut[RB];
+  __shared__ uint32_t s_red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Lq = qoff[b + 1] - qoff[b];
+  const float inv = qinv[b];
+  if (tid < RB) {
+    uint32_t u = 0;
+    if (tid < Lq) {
+      const uint32_t tau = tauq[(int64_t)b * LQP + tid];
+      const float x = tau ? unkey(tau) : 0.f;     // 0: fewer than n_probe scored centroids (every one is probed)
+      u = min((uint32_t)(fmaxf(x * inv, 0.f) * 254.0f) + 1u, 255u);   // the table's own rounding (qc_gemm_kernel)
+    }
+    s_ut[tid] = u;
+  }
+  if (tid == 0) {
+    rp0.cand_base[b] = (int64_t)b * s0cap;
+    rp0.round_of[b] = 0;
+    rp0.order[b] = b;
+    if (b == 0) {
+      rp0.round_tab[0] = 0;
+      rp0.round_tab[1] = B;
+      rp0.round_tab[2] = 1;
+    }
+  }
+  __syncthreads();
+  const int nc = n_cells[b];
+  uint16_t* gb = gain + (int64_t)b * KP;
+  uint32_t tot = 0;
+  for (int i = tid; i < nc; i += 256) {
+    const uint32_t c = cells[(int64_t)b * KP + i];
+    const uint4* row = reinterpret_cast<const uint4*>(QCU + ((int64_t)b * KP + c) * RB);
+    uint32_t g = 0;
+#pragma unroll
+    for (int j = 0; j < RB / 16; ++j) {
+      const uint4 v = row[j];
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t u = (w4[e] >> (8 * k)) & 0xFFu, t = s_ut[16 * j + 4 * e + k];
+          g += max(u, t) - t;                      // padding tokens: u = t = 0
+        }
+    }
+    gb[i] = (uint16_t)(g + 1u);                    // <= 254 * 64 + 1
+    tot += g + 1u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o);
+  if (lane == 0) s_red[wave] = tot;
+  __syncthreads();
+  tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  uint32_t sh = 0;
+  while ((tot >> sh) + (uint32_t)nc > 65535u) ++sh;   // sum of ceil(g / 2^sh) <= tot / 2^sh + nc
+  if (sh)
+    for (int i = tid; i < nc; i += 256) gb[i] = (uint16_t)(((uint32_t)gb[i] + (1u << sh) - 1u) >> sh);
+  if (tid == 0) {
+    uint32_t base = 0;
+    for (int q = 0; q < RB; ++q) base += s_ut[q];
+    gbase[2 * b] = base;
+    gbase[2 * b + 1] = sh;
+  }
+}
+
+struct GainP {
+  const uint32_t* cells;      // [B][KP] probed cells (S2)
+  const int32_t* n_cells;     // [B]
+  int64_t KP;
+  const int64_t* ivf_off;     // [K + 1]
+  const uint32_t* ivf;
+  const uint32_t* split;      // [K][R1]: split[c * R1 + r] = entries of list c with id < r * NP_GAIN_RANGE
+  int R1;
+  const uint16_t* gain;       // [B][KP] by cell position
+  const uint32_t* gbase;      // [B][2]
+  int hshift;
+  int64_t n_docs;
+  uint32_t* hist0;            // [B][NP_UB_BINS] (mode 0)
+  int32_t* n_raw;             // [B] candidates (mode 0)
+  const uint32_t* thr;        // [B] mode 1: bin threshold of S0 (0 = no S0); mode 2: bin of the cut (0 = keep every candidate)
+  uint4* s0_meta;             // mode 1: [B][s0cap] records
+  int32_t* n_s0;              // [B] zeroed
+  int s0cap;
+  const void* ucodes;         // list blocks (headers): mode 1 builds the records itself
+  int code_wide, ublock_stride;
+  int64_t ovf_base;
+  uint32_t* cand;             // mode 2: [pool] ids at cand_base[b]
+  int32_t* n_emit;            // [B] zeroed
+  RoundPlan rp;
+  Counters* ctr;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p, int round) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_acc[];   // NP_GAIN_RANGE / 2 words: two u16 accumulators each
+  __shared__ int64_t s_start[NP_GAIN_CELLS];
+  __shared__ uint32_t s_len[NP_GAIN_CELLS], s_g[NP_GAIN_CELLS], s_items[NP_GAIN_CELLS + 1];
+  __shared__ uint32_t s_wsum[16];
+  __shared__ uint32_t s_hist[MODE == 0 ? NP_UB_BINS : 1];
+  __shared__ uint32_t s_out;
+  const int b = blockIdx.y, r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (MODE == 2 && p.rp.round_of[b] != round) return;
+  const uint32_t thr = MODE == 0 ? 0u : p.thr[b];
+  if (MODE == 1 && thr == 0u) return;
+  const int nc = p.n_cells[b];
+  const uint32_t lo = (uint32_t)r * NP_GAIN_RANGE;
+  {
+    uint4* a4 = reinterpret_cast<uint4*>(s_acc);
+    for (int i = tid; i < NP_GAIN_RANGE / 8; i += 1024) a4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (MODE == 0)
+      for (int i = tid; i < NP_UB_BINS; i += 1024) s_hist[i] = 0;
+  }
+  unsigned long long ids = 0;
+  for (int c0 = 0; c0 < nc; c0 += NP_GAIN_CELLS) {
+    __syncthreads();   // accumulators zeroed / the previous pass's tables consumed
+    const int m = min(NP_GAIN_CELLS, nc - c0);
+    uint32_t items = 0, incl = 0;
+    if (tid < NP_GAIN_CELLS) {
+      if (tid < m) {
+        const uint32_t c = p.cells[(int64_t)b * p.KP + c0 + tid];
+        const uint32_t* sp = p.split + (int64_t)c * p.R1 + r;
+        const uint32_t s = sp[0], e = sp[1];
+        const int64_t o0 = p.ivf_off[c];
+        s_start[tid] = o0 + s;
+        s_len[tid] = e - s;
+        s_g[tid] = (uint32_t)p.gain[(int64_t)b * p.KP + c0 + tid];
+        items = (e - s + NP_GAIN_ITEM - 1) / NP_GAIN_ITEM;
+        if (MODE == 0 && r == 0) ids += (unsigned long long)(p.ivf_off[c + 1] - o0);
+      }
+      incl = items;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) s_wsum[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < NP_GAIN_CELLS) {
+      uint32_t woff = 0;
+      for (int k = 0; k < wave; ++k) woff += s_wsum[k];
+      s_items[tid] = woff + incl - items;
+      if (tid == NP_GAIN_CELLS - 1) s_items[NP_GAIN_CELLS] = woff + incl;
+    }
+    __syncthreads();
+    const uint32_t total = s_items[NP_GAIN_CELLS];
+    const uint32_t hw = (uint32_t)tid >> 5, hl = (uint32_t)tid & 31u;
+    auto find = [&](uint32_t it) {   // the list item `it` belongs to: largest t < m with s_items[t] <= it
+      int a = 0, z = m;
+      while (z - a > 1) {
+        const int mid = (a + z) >> 1;
+        if (s_items[mid] <= it) a = mid;
+        else z = mid;
+      }
+      return a;
+    };
+    for (uint32_t it = hw; it < total; it += 64) {   // two items per half-wave and step: both loads in flight before the adds
+      const uint32_t it2 = it + 32;
+      const int a0 = find(it), a1 = it2 < total ? find(it2) : a0;
+      const uint32_t off0 = (it - s_items[a0]) * NP_GAIN_ITEM + hl;
+      const uint32_t off1 = it2 < total ? (it2 - s_items[a1]) * NP_GAIN_ITEM + hl : 0xFFFFFFFFu;
+      const bool v0 = off0 < s_len[a0], v1 = off1 < s_len[a1] && it2 < total;
+      uint32_t d0 = lo, d1 = lo;
+      if (v0) d0 = p.ivf[s_start[a0] + off0];
+      if (v1) d1 = p.ivf[s_start[a1] + off1];
+      if (v0) {
+        const uint32_t rel = d0 - lo;
+        atomicAdd(&s_acc[rel >> 1], s_g[a0] << ((rel & 1u) * 16u));
+      }
+      if (v1) {
+        const uint32_t rel = d1 - lo;
+        atomicAdd(&s_acc[rel >> 1], s_g[a1] << ((rel & 1u) * 16u));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- scan: thread t owns documents [32 t, 32 t + 32) of the range
+  const uint32_t base = p.gbase[2 * b], sh = p.gbase[2 * b + 1];
+  uint32_t w[16];
+  {
+    const uint4* a4 = reinterpret_cast<const uint4*>(s_acc) + 4 * tid;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint4 v = a4[k];
+      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+  }
+  uint32_t mask = 0;   // bit j: document 32 t + j is kept (mode 0: is a candidate)
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t a = (w[k] >> (16 * h)) & 0xFFFFu;
+      if (a) {
+        const uint32_t bin = min((base + (a << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
+        if constexpr (MODE == 0) {
+          atomicAdd(&s_hist[bin], 1u);
+          mask |= 1u << (2 * k + h);
+        } else if (thr == 0u || bin >= thr) {
+          mask |= 1u << (2 * k + h);
+        }
+      }
+    }
+  // block-wide exclusive scan of the kept counts
+  const uint32_t cnt = (uint32_t)__popc(mask);
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+  for (int k = 0; k < 16; ++k) {
+    if (k < wave) woff += s_wsum[k];
+    tot += s_wsum[k];
+  }
+  if constexpr (MODE == 0) {
+    if (tid == 0 && tot) atomicAdd(&p.n_raw[b], (int32_t)tot);
+    for (int i = tid; i < NP_UB_BINS; i += 1024) {
+      const uint32_t v = s_hist[i];
+      if (v) atomicAdd(&p.hist0[(int64_t)b * NP_UB_BINS + i], v);
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ids += __shfl_xor(ids, o);
+      if (lane == 0 && ids) atomicAdd(&p.ctr->n_ivf_ids, ids);
+    }
+  } else {
+    if (tot == 0) return;   // block-uniform
+    if (tid == 0) s_out = (uint32_t)atomicAdd(MODE == 1 ? &p.n_s0[b] : &p.n_emit[b], (int32_t)tot);
+    __syncthreads();
+    uint32_t pos = s_out + woff + incl - cnt;
+    if constexpr (MODE == 1) {
+      const int cb = p.code_wide ? 4 : 2, hdr = 16 / cb, fit = p.ublock_stride - hdr;
+      uint4* out = p.s0_meta + (int64_t)b * p.s0cap;
+      while (mask) {
+        const int j = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        const uint32_t d = lo + 32u * (uint32_t)tid + (uint32_t)j;
+        if (pos < (uint32_t)p.s0cap) {
+          const uint4 hd = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.ucodes) + (int64_t)d * p.ublock_stride * cb);
+          const int64_t cl = (int)hd.x > fit ? p.ovf_base + (int64_t)hd.z * 4 : (int64_t)d * p.ublock_stride + hdr;
+          out[pos] = make_uint4(d, hd.x, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
+        }
+        ++pos;
+      }
+    } else {
+      uint32_t* out = p.cand + p.rp.cand_base[b];
+      const uint32_t limit = (uint32_t)p.rp.n_cand[b];
+      while (mask) {
+        const int j = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        if (pos < limit) out[pos] = lo + 32u * (uint32_t)tid + (uint32_t)j;
+        ++pos;
+      }
+    }
+  }
+}
+
+// S0 = the ~target documents with the largest U0 (whole histogram bins, at most `cap`): thr[b] = its lowest bin, 0 = no S0
+// (flagged query, fewer candidates than the target, a cut that would reach bin 0, or no bin set between n_sel and cap)
+__global__ void __launch_bounds__(256) gain_thr_kernel(const uint32_t* __restrict__ hist, int target, int n_sel, int cap,
+                                                       const int32_t* __restrict__ n_raw, const uint32_t* __restrict__ qflag,
+                                                       uint32_t* __restrict__ thr) {
+  __shared__ uint32_t s_part[256];
+  constexpr int BPT = NP_UB_BINS / 256;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (qflag[b] != 0 || n_raw[b] <= target) {
+    if (tid == 0) thr[b] = 0;
+    return;
+  }
+  const uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
+  const int top = (255 - tid) * BPT;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < BPT; ++k) mine += hb[top + k];
+  s_part[tid] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t cum = 0;
+    int t = 0;
+    for (; t < 255; ++t) {
+      if (cum + s_part[t] >= (uint32_t)target) break;
+      cum += s_part[t];
+    }
+    int bin = (255 - t) * BPT + BPT - 1;
+    for (; bin > (255 - t) * BPT; --bin) {
+      if (cum + hb[bin] >= (uint32_t)target) break;
+      cum += hb[bin];
+    }
+    // documents in bins >= bin: cum + hb[bin]; too many for the S0 slice: drop the marginal bin if what is above still
+    // holds n_sel documents (any n_sel lower bounds give a valid threshold)
+    if (cum + hb[bin] > (uint32_t)cap) {
+      if (cum >= (uint32_t)n_sel && cum <= (uint32_t)cap) ++bin;
+      else bin = 0;
+    }
+    thr[b] = (uint32_t)max(bin, 0);
+  }
+}
+
+// candidates of query b after the zeroth level: the histogram's suffix sum at the cut (the sweep keeps bin >= cut), or every
+// candidate where the level does not apply
+__global__ void __launch_bounds__(256) gain_count_kernel(const uint32_t* __restrict__ hist0, const uint32_t* __restrict__ cut,
+                                                         const int32_t* __restrict__ n_raw, int32_t* __restrict__ n_out,
+                                                         Counters* ctr) {
+  __shared__ uint32_t s_red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t c = cut[b];
+  uint32_t n = 0;
+  if (c) {
+    for (int i = tid; i < NP_UB_BINS; i += 256) n += (uint32_t)i >= c ? hist0[(int64_t)b * NP_UB_BINS + i] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+    if (lane == 0) s_red[wave] = n;
+    __syncthreads();
+    n = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  } else {
+    n = (uint32_t)n_raw[b];
+  }
+  if (tid == 0) {
+    n_out[b] = (int32_t)n;
+    atomicAdd(&ctr->n_candidates, (unsigned long long)n_raw[b]);
+    atomicAdd(&ctr->n_level0, (unsigned long long)n);
   }
 }
 
@@ -1950,8 +2326,6 @@ __global__ void __launch_bounds__(256, 4) approx_stream_kernel(const float* __re
 // v_max_u32 on byte lanes.  Queries with a non-finite value (qflag) and queries with <= n_sel candidates skip
 // the filter: all their candidates survive.
 // ---------------------------------------------------------------------------------------------
-#define NP_UB_BINS 2048    // histogram bins of the integer bounds: bin = U >> hshift, hshift = log2(ROWB / 32) + 2 (U <= 255 * ROWB);
-                           // u32 counters in LDS (8 KB): a workgroup's share of a query's documents is unbounded
 #define NP_UB_NBX 96       // workgroups per XCD: 3 per CU (48 KB of LDS each)
 
 // CT = uint16_t when every code fits 16 bits (K <= 65536), else uint32_t.
@@ -3079,7 +3453,9 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
     const uint32_t* __restrict__ qflag, const int32_t* __restrict__ qoff, int n_sel, uint16_t* __restrict__ U,
     uint32_t* __restrict__ hist, int hshift, int32_t* __restrict__ slots, int32_t* __restrict__ ticket, int B, Counters* ctr,
     int slack /* spare LDS bytes behind a wave's rows: what the idle lanes of the last staging instruction overrun */,
-    int probe_arg /* NP_DIAGNOSTICS builds only (results invalid when != 0): 1 no row loads in the walk, 2 no scan, 4 no staging */) {
+    int probe_arg /* NP_DIAGNOSTICS builds only (results invalid when != 0): 1 no row loads in the walk, 2 no scan, 4 no staging */,
+    int unordered = 0 /* the candidate ids come in blocks of ascending ids in any order (gain_sweep_kernel): a claim's block
+                         offsets are taken from its smallest id instead of its first */) {
   static_assert(RB == 32 || RB == 64, "plane rows of 32 or 64 query tokens");
   static_assert(LPD == 2 || LPD == 4, "lanes per document");
 #ifdef NP_DIAGNOSTICS
@@ -3179,7 +3555,11 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
     const int sslot = lane / LPR, spiece = lane - sslot * LPR;
     auto stage = [&](uint32_t dv) {
       if (probe & 4) return;
-      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 63);
+      uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)dv, 63);
+      if (unordered) {   // shard-local ids are below 2^31
+        d1 = (uint32_t)wave_max_nonneg((int)dv);
+        d0 = 0x7FFFFFFFu - (uint32_t)wave_max_nonneg((int)(0x7FFFFFFFu - dv));
+      }
       if ((uint64_t)(d1 - d0) * (uint64_t)stride_b < 0x7FFF0000ull && d1 >= d0) {
         const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<CT*>(codes) + (int64_t)d0 * ublock_stride, 0, 0x7FFFFFFF, 0x00020000);

@@ -17,7 +17,8 @@ namespace np {
 struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, n_list2, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
-      subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2, qpad, planes, levels, hotbits;
+      subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2, qpad, planes, levels, hotbits,
+      gain, gsmall, ghist, s0_meta, s0_u;   // zeroth filter level (gain_sweep_kernel)
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
@@ -26,7 +27,8 @@ struct Workspace {
     return {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
             &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
             &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
-            &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits};
+            &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits, &gain, &gsmall, &ghist,
+            &s0_meta, &s0_u};
   }
   void release_all() {
     const std::vector<DevBuf*> all = all_bufs();
@@ -204,6 +206,7 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int to
   const int64_t nchunks = (NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS;
   return KP * LQP * 6                      // QCT (f32) + QCU (u8, rows padded to a power of two)
          + KP + 1024                       // per-centroid maxima of the u8 table + their histogram (hot level)
+         + KP * 2 + NP_UB_BINS * 8         // zeroth level: gains of the probed cells, two histograms
          + NP_UB_BINS * 8
          + G * LQP * 4 + G * 4             // gmax, cellbits
          + KP * 8                          // cells_tmp, cells
@@ -550,7 +553,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     NP_TRY(w.n_surv.reserve((size_t)B * 4));
     NP_TRY(w.ub_thr.reserve((size_t)B * 4));
     NP_TRY(w.ub_cursor.reserve((size_t)3 * B * 4));
-    NP_TRY(w.xcd_slots.reserve((size_t)max_rounds * 3 * slot_words * 4));
+    NP_TRY(w.xcd_slots.reserve(((size_t)max_rounds * 3 + 1) * slot_words * 4));   // + the zeroth level's S0 launch
   }
   if (two_level) {
     NP_TRY(w.cmaxu.reserve((size_t)B * KP));
@@ -566,6 +569,25 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       NP_TRY(w.levels.reserve((size_t)B * 16 * 4));
       NP_TRY(w.hotbits.reserve((size_t)2 * B * (KP / 32) * 4));   // hot bitmap, then the exact level's kept-centroid bitmap
     }
+  }
+  // Zeroth filter level (np_kernels.h, gain_sweep_kernel): per-document sums of the probed cells' gains prune the candidates
+  // before any list block is read.  Only where no centroid_score_threshold is set (the cells a threshold removes would lift
+  // the bound's floor above the cut: tools/sim/s3_gain_sim.py), on ascending posting lists (range table built at open), with
+  // the bit-plane first level behind it (it takes the candidate ids in any order) and without a subset.
+  const bool gain_path = two_level && use_planes && ix->d_ivf_split != nullptr && ix->tune.s3_gain && !prm.has_threshold &&
+                         subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0;
+  const int s0_target = ix->tune.s3_gain_mult * cs->n_sel;
+  // S0 takes whole histogram bins: the marginal bin may hold a few whole posting lists (documents in ONE probed cell share a bound)
+  const int s0cap = (int)std::min<int64_t>(s0_target + cs->n_sel + 4 * (ix->ivf_size / std::max<int64_t>(ix->K, 1)) + 4096, 1 << 22);
+  // u32 words of w.gsmall: [0, 2B) base / shift, then B each: n_raw, thr0, cut0, n_s0, n_emit, n_direct, round_of0, order0, cursor0;
+  // 4 words round_tab0; then (8-byte aligned) cand_base0 i64 [B]
+  const size_t gs_words = (size_t)11 * B + 4 + ((B & 1) ? 1 : 0), gs_bytes = gs_words * 4 + (size_t)B * 8;
+  if (gain_path) {
+    NP_TRY(w.gain.reserve((size_t)B * KP * 2));
+    NP_TRY(w.gsmall.reserve(gs_bytes));
+    NP_TRY(w.ghist.reserve((size_t)2 * B * NP_UB_BINS * 4));
+    NP_TRY(w.s0_meta.reserve((size_t)B * s0cap * 16));
+    NP_TRY(w.s0_u.reserve((size_t)B * s0cap * 2));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -602,7 +624,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       add(w.ub_hist.p, (size_t)B * NP_UB_BINS * 4, 0);
       add(w.n_surv.p, (size_t)B * 4, 0);
       add(w.ub_cursor.p, (size_t)3 * B * 4, 0);
-      add(w.xcd_slots.p, (size_t)max_rounds * 3 * slot_words * 4, 0xFFFFFFFFu);   // slots and tickets of every launch: -1
+      add(w.xcd_slots.p, ((size_t)max_rounds * 3 + 1) * slot_words * 4, 0xFFFFFFFFu);   // slots and tickets of every launch: -1
+    }
+    if (gain_path) {
+      add(w.gsmall.p, gs_bytes, 0);
+      add(w.ghist.p, (size_t)2 * B * NP_UB_BINS * 4, 0);
     }
     if (two_level && B > 0) {
       add(w.chist.p, (size_t)B * 256 * 4, 0);
@@ -713,6 +739,72 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));
 
+  // ---- the filter's launch helper and its loop-invariant parameters (used by the zeroth level before the round plan, and by
+  // every round)
+  const int hshift = RB == 32 ? 2 : (RB == 64 ? 3 : (RB == 128 ? 4 : 5));   // U <= 255 * RB fits NP_UB_BINS << hshift
+  const unsigned nbx = (unsigned)ix->tune.ub_nbx;
+  const bool oob = ix->tune.ub_nt == 2 && KP * RB < ((int64_t)1 << 30);   // the table behind a 32-bit buffer offset
+  // exact u8 bound of the records meta[begin[b] .. begin[b] + count[b]) -> U, histogram (optional)
+  // direct_wpq > 0: a short list per query (S1, about n_sel documents): wpq workgroups per query, every query at once,
+  // instead of one query per XCD at a time (8 hand-out steps of ~25 us each for a handful of claims)
+  // floor: the S2 list of the two-level filter with u16 codes -- rows of the centroids no query token is close to are
+  // skipped, U = the floored upper bound, the histogram counts the lower bound (approx_ub_kernel, FLOOR)
+  const bool can_floor = two_level && use_planes && oob && RB <= 64 && s4_warm < 1000;
+  auto launch_ub_at = [&](const RoundPlan& rpx, int r, int max_rounds, int32_t* sl, int32_t* tk, uint32_t* cursor, const uint4* meta,
+                          const int32_t* begin, const int32_t* count, const int32_t* n_all, uint16_t* U, uint32_t* hist,
+                          int count_tokens, int direct_wpq, bool floor_rows) {
+    const unsigned grid = direct_wpq > 0 ? (unsigned)(B * direct_wpq) : 8 * nbx;
+    if (floor_rows && can_floor) {
+#define NP_LAUNCH_UBF(ROWB, CT)                                                                                               \
+  approx_ub_kernel<ROWB, CT, 2, 1><<<grid, 256, 0, st>>>(                                                                       \
+  w.QCU.as<uint8_t>(), KP, meta, begin, count, n_all, rpx, r, max_rounds, (const CT*)ix->d_ucodes,           \
+  w.qflag.as<uint32_t>(), cs->n_sel, U, hist, hshift, cursor, sl, tk, B, ix->tune.ub_steal, w.ctr.as<Counters>(),      \
+  count_tokens, direct_wpq, ix->tune.ub_static, w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32),                           \
+  w.ub_thr2.as<uint32_t>() + 2 * B, d_qoff)
+      if (!ix->code_wide) {
+        if (RB == 32) NP_LAUNCH_UBF(32, uint16_t);
+        else NP_LAUNCH_UBF(64, uint16_t);
+      } else {
+        if (RB == 32) NP_LAUNCH_UBF(32, uint32_t);
+        else NP_LAUNCH_UBF(64, uint32_t);
+      }
+#undef NP_LAUNCH_UBF
+      return;
+    }
+#define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                        \
+  approx_ub_kernel<ROWB, CT, NT><<<grid, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, meta, begin, count, n_all,   \
+                                                   rpx, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(),   \
+                                                   cs->n_sel, U, hist, hshift, cursor, sl, tk, B,                \
+                                                   ix->tune.ub_steal, w.ctr.as<Counters>(), count_tokens, direct_wpq,   \
+                                                   ix->tune.ub_static)
+#define NP_LAUNCH_UB_RB(CT, NT)                 \
+  do {                                          \
+    if (RB == 32) NP_LAUNCH_UB(32, CT, NT);     \
+    else if (RB == 64) NP_LAUNCH_UB(64, CT, NT);   \
+    else if (RB == 128) NP_LAUNCH_UB(128, CT, NT); \
+    else NP_LAUNCH_UB(256, CT, NT);             \
+  } while (0)
+    if (!ix->code_wide) {
+      if (oob) NP_LAUNCH_UB_RB(uint16_t, 2);
+      else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint16_t, 1);
+      else NP_LAUNCH_UB_RB(uint16_t, 0);
+    } else {
+      if (oob) NP_LAUNCH_UB_RB(uint32_t, 2);
+      else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint32_t, 1);
+      else NP_LAUNCH_UB_RB(uint32_t, 0);
+    }
+#undef NP_LAUNCH_UB_RB
+#undef NP_LAUNCH_UB
+  };
+
+  // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
+  // (per query the bracket is Lq + 2 with its OWN token count: padding tokens contribute exactly 0 to both sides, so the
+  // slice's longest query bounds it -- 48-token queries in 64-token rows keep 50, not 66)
+  // (that unit count follows gcut_kernel's bound e >= |G - R| = 1.5 (152 Lq + 2 Lq^2) 2^-24 s, in table units of s / 254:
+  // below one unit up to 64 tokens, four at 256)
+  const float lqf = (float)maxLq;
+  const int slack = maxLq + 2 +
+                    (batched ? std::max(1, (int)std::ceil(1.5f * (152.0f * lqf + 2.0f * lqf * lqf) * 5.9604645e-8f * 254.0f)) : 0);
   // ---- S3: posting-list union (bitmap), per-chunk counts, round plan
   RoundPlan rp;
   rp.n_cand = w.n_cand.as<int32_t>();
@@ -721,7 +813,75 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   rp.round_tab = w.round_tab.as<int32_t>();
   rp.order = w.q_order.as<int32_t>();
   const bool have_cands = !cs->empty_subset && ix->n_docs > 0;
-  if (have_cands) {
+  GainP gp{};
+  if (have_cands && gain_path) {
+    uint32_t* gs = w.gsmall.as<uint32_t>();
+    uint32_t* g_base = gs;
+    int32_t* g_nraw = reinterpret_cast<int32_t*>(gs + 2 * B);
+    uint32_t* g_thr0 = gs + 3 * B;
+    uint32_t* g_cut0 = gs + 4 * B;
+    int32_t* g_ns0 = reinterpret_cast<int32_t*>(gs + 5 * B);
+    int32_t* g_nemit = reinterpret_cast<int32_t*>(gs + 6 * B);
+    int32_t* g_ndirect = reinterpret_cast<int32_t*>(gs + 7 * B);
+    uint32_t* g_cursor0 = gs + 10 * B;
+    RoundPlan rp0;          // the S0 launch: one round, identity order, slices of s0cap records
+    rp0.n_cand = g_ns0;
+    rp0.round_of = reinterpret_cast<int32_t*>(gs + 8 * B);
+    rp0.order = reinterpret_cast<int32_t*>(gs + 9 * B);
+    rp0.round_tab = reinterpret_cast<int32_t*>(gs + 11 * B);
+    rp0.cand_base = reinterpret_cast<int64_t*>(gs + gs_words);
+    uint32_t* hist0 = w.ghist.as<uint32_t>();
+    uint32_t* hist_s0 = hist0 + (size_t)B * NP_UB_BINS;
+    gp.cells = w.cells.as<uint32_t>();
+    gp.n_cells = w.n_cells.as<int32_t>();
+    gp.KP = KP;
+    gp.ivf_off = ix->d_ivf_offsets;
+    gp.ivf = ix->d_ivf;
+    gp.split = ix->d_ivf_split;
+    gp.R1 = ix->n_ranges + 1;
+    gp.gain = w.gain.as<uint16_t>();
+    gp.gbase = g_base;
+    gp.hshift = hshift;
+    gp.n_docs = ix->n_docs;
+    gp.hist0 = hist0;
+    gp.n_raw = g_nraw;
+    gp.thr = g_thr0;
+    gp.s0_meta = w.s0_meta.as<uint4>();
+    gp.n_s0 = g_ns0;
+    gp.s0cap = s0cap;
+    gp.ucodes = ix->d_ucodes;
+    gp.code_wide = ix->code_wide;
+    gp.ublock_stride = ix->ublock_stride;
+    gp.ovf_base = (int64_t)ix->n_docs * ix->ublock_stride;
+    gp.cand = w.cand.as<uint32_t>();
+    gp.n_emit = g_nemit;
+    gp.rp = rp;
+    gp.ctr = w.ctr.as<Counters>();
+    const size_t glds = (size_t)NP_GAIN_RANGE * 2;
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    if (RB == 32)
+      gain_prep_kernel<32><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0);
+    else
+      gain_prep_kernel<64><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0);
+    const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B);
+    gain_sweep_kernel<0><<<ggrid, 1024, glds, st>>>(gp, 0);                                   // histogram of U0, candidate counts
+    gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, cs->n_sel, s0cap, g_nraw, w.qflag.as<uint32_t>(), g_thr0);
+    gain_sweep_kernel<1><<<ggrid, 1024, glds, st>>>(gp, 0);                                   // S0: records of the best bounds
+    {
+      int32_t* sl0 = w.xcd_slots.as<int32_t>() + (size_t)max_rounds * 3 * slot_words;
+      launch_ub_at(rp0, 0, 1, sl0, sl0 + 8 * (B + 1), g_cursor0, w.s0_meta.as<uint4>(), nullptr, g_ns0, g_ns0, w.s0_u.as<uint16_t>(), hist_s0,
+                   0, ix->tune.s3_gain_direct, false);                                        // exact bounds of S0 (histogram: lower bounds)
+    }
+    ub_thr_kernel<<<B, 256, 0, st>>>(hist_s0, hshift, slack, cs->n_sel, g_ns0, rp0, 0, w.qflag.as<uint32_t>(), g_cut0);   // tau0 - slack
+    gain_count_kernel<<<B, 256, 0, st>>>(hist0, g_cut0, g_nraw, g_ndirect, w.ctr.as<Counters>());
+    plan_rounds_kernel<<<1, 256, 0, st>>>(nullptr, 0, B, pool, max_rounds, rp, w.ctr.as<Counters>(), g_ndirect);
+    gp.thr = g_cut0;
+  }
+  if (have_cands && !gain_path) {
     if (ix->tune.s3_slices) {
       // bitmap ranges in LDS (mark_slices_kernel): ranges of <= 32 chunks, enough of them to fill the chip, at most 16
       // sweeps of the posting lists per query beyond what the range size forces
@@ -749,6 +909,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     }
     plan_rounds_kernel<<<1, 256, 0, st>>>(w.chunk_counts.as<int32_t>(), nchunks, B, pool, max_rounds, rp,
                                           w.ctr.as<Counters>());
+  }
+  if (have_cands) {
     // Lambda, the thresholds of the 8 planes and the hot bitmap in one launch, then the plane rows of the hot centroids -- AFTER
     // the round plan: the hot share of a query follows its candidate count (hot_levels_kernel), which S3 has just counted
     if (two_level && use_planes) {
@@ -789,79 +951,23 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     // two-level filter: bare ids only -- the hot level finds a document's list block from the id and writes the 16-B records
     // itself (no record gather here: a 128-B line per candidate at 1.9 % density was this kernel's whole cost)
     const bool ids_only = two_level && ix->ublock_stride > 0;
+    if (gain_path)   // the candidates that pass the zeroth level's cut (every candidate where it does not apply), bare ids
+      gain_sweep_kernel<2><<<dim3((unsigned)ix->n_ranges, (unsigned)B), 1024, (size_t)NP_GAIN_RANGE * 2, st>>>(gp, r);
+    else
     compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks, w.chunk_counts.as<int32_t>(),
                                                      (use_filter && !ids_only) ? nullptr : w.cand.as<uint32_t>(), rp, r,
                                                      ids_only ? nullptr : ix->d_doc_meta, w.cand_meta.as<uint4>());
     if (cs->timed && r == 0) NP_HIP(hipEventRecord(cs->ctx->ev[3], st));
     if (use_filter) {
-      const int hshift = RB == 32 ? 2 : (RB == 64 ? 3 : (RB == 128 ? 4 : 5));   // U <= 255 * RB fits NP_UB_BINS << hshift
-      const unsigned nbx = (unsigned)ix->tune.ub_nbx;
       // hand-out state of the (up to three) filter launches of this round: slots = -1 (empty), ticket = -1; cursors 0
       auto xslots = [&](int lvl) { return w.xcd_slots.as<int32_t>() + ((size_t)r * 3 + lvl) * slot_words; };
       auto xcursor = [&](int lvl) { return w.ub_cursor.as<uint32_t>() + (size_t)lvl * B; };
-      const bool oob = ix->tune.ub_nt == 2 && KP * RB < ((int64_t)1 << 30);   // the table behind a 32-bit buffer offset
-      // exact u8 bound of the records meta[begin[b] .. begin[b] + count[b]) -> U, histogram (optional)
-      // direct_wpq > 0: a short list per query (S1, about n_sel documents): wpq workgroups per query, every query at once,
-      // instead of one query per XCD at a time (8 hand-out steps of ~25 us each for a handful of claims)
-      // floor: the S2 list of the two-level filter with u16 codes -- rows of the centroids no query token is close to are
-      // skipped, U = the floored upper bound, the histogram counts the lower bound (approx_ub_kernel, FLOOR)
-      const bool can_floor = two_level && use_planes && oob && RB <= 64 && s4_warm < 1000;
       auto launch_ub = [&](int lvl, const uint4* meta, const int32_t* begin, const int32_t* count, uint16_t* U, uint32_t* hist,
                            int count_tokens, int direct_wpq, bool floor_rows = false) {
-        int32_t* sl = xslots(lvl);
-        int32_t* tk = sl + 8 * (B + 1);
-        const unsigned grid = direct_wpq > 0 ? (unsigned)(B * direct_wpq) : 8 * nbx;
-        if (floor_rows && can_floor) {
-#define NP_LAUNCH_UBF(ROWB, CT)                                                                                               \
-  approx_ub_kernel<ROWB, CT, 2, 1><<<grid, 256, 0, st>>>(                                                                       \
-      w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes,           \
-      w.qflag.as<uint32_t>(), cs->n_sel, U, hist, hshift, xcursor(lvl), sl, tk, B, ix->tune.ub_steal, w.ctr.as<Counters>(),      \
-      count_tokens, direct_wpq, ix->tune.ub_static, w.hotbits.as<uint32_t>() + (size_t)B * (KP / 32),                           \
-      w.ub_thr2.as<uint32_t>() + 2 * B, d_qoff)
-          if (!ix->code_wide) {
-            if (RB == 32) NP_LAUNCH_UBF(32, uint16_t);
-            else NP_LAUNCH_UBF(64, uint16_t);
-          } else {
-            if (RB == 32) NP_LAUNCH_UBF(32, uint32_t);
-            else NP_LAUNCH_UBF(64, uint32_t);
-          }
-#undef NP_LAUNCH_UBF
-          return;
-        }
-#define NP_LAUNCH_UB(ROWB, CT, NT)                                                                                        \
-  approx_ub_kernel<ROWB, CT, NT><<<grid, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, meta, begin, count, w.n_cand.as<int32_t>(),   \
-                                                       rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(),   \
-                                                       cs->n_sel, U, hist, hshift, xcursor(lvl), sl, tk, B,                \
-                                                       ix->tune.ub_steal, w.ctr.as<Counters>(), count_tokens, direct_wpq,   \
-                                                       ix->tune.ub_static)
-#define NP_LAUNCH_UB_RB(CT, NT)                 \
-  do {                                          \
-    if (RB == 32) NP_LAUNCH_UB(32, CT, NT);     \
-    else if (RB == 64) NP_LAUNCH_UB(64, CT, NT);   \
-    else if (RB == 128) NP_LAUNCH_UB(128, CT, NT); \
-    else NP_LAUNCH_UB(256, CT, NT);             \
-  } while (0)
-        if (!ix->code_wide) {
-          if (oob) NP_LAUNCH_UB_RB(uint16_t, 2);
-          else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint16_t, 1);
-          else NP_LAUNCH_UB_RB(uint16_t, 0);
-        } else {
-          if (oob) NP_LAUNCH_UB_RB(uint32_t, 2);
-          else if (ix->tune.ub_nt == 1) NP_LAUNCH_UB_RB(uint32_t, 1);
-          else NP_LAUNCH_UB_RB(uint32_t, 0);
-        }
-#undef NP_LAUNCH_UB_RB
-#undef NP_LAUNCH_UB
+        launch_ub_at(rp, r, max_rounds, xslots(lvl), xslots(lvl) + 8 * (B + 1), xcursor(lvl), meta, begin, count, w.n_cand.as<int32_t>(), U,
+                     hist, count_tokens, direct_wpq, floor_rows);
       };
       const unsigned ncut = (unsigned)std::min<int64_t>(ix->tune.ub_ncut, std::max<int64_t>(1, ix->n_docs / 16384));
-      // slack of the bound (np_kernels.h); the batched path's mat-vec scores differ from the GEMM's by < 1 more unit
-      // (per query the bracket is Lq + 2 with its OWN token count: padding tokens contribute exactly 0 to both sides, so the
-      // slice's longest query bounds it -- 48-token queries in 64-token rows keep 50, not 66)
-      // (that unit count follows gcut_kernel's bound e >= |G - R| = 1.5 (152 Lq + 2 Lq^2) 2^-24 s, in table units of s / 254:
-      // below one unit up to 64 tokens, four at 256)
-      const float lqf = (float)maxLq;
-      const int slack = maxLq + 2 +
-                        (batched ? std::max(1, (int)std::ceil(1.5f * (152.0f * lqf + 2.0f * lqf * lqf) * 5.9604645e-8f * 254.0f)) : 0);
       CutP cp{};
       cp.hshift = hshift;
       cp.all_src = w.cand_meta.as<uint4>();
@@ -922,7 +1028,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
         w.cand.as<uint32_t>(), w.cand_meta.as<uint4>(), ix->ublock_stride, (int64_t)ix->n_docs * ix->ublock_stride,        \
         w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), d_qoff, cs->n_sel,     \
         w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift, sl, sl + 8 * (B + 1), B, w.ctr.as<Counters>(), slack,       \
-        ix->tune.s4_probe);                                                                                            \
+        ix->tune.s4_probe, gain_path ? 1 : 0);                                                                                            \
   } while (0)
   // lanes per document: 2 (32 documents per claim; blocks of at most 256 bytes) or 4 (16 per claim: half the LDS rows per
   // wave; the only choice for 512-byte blocks).  Documents per staging instruction from the block size (16 B per lane,
@@ -1349,6 +1455,7 @@ int np_hip_search_batch(const np_index* ix, const float* queries, const int32_t*
       acc.n_survivors += (int64_t)h_ctr->n_survivors;
       acc.n_cand_dcodes += (int64_t)(h_ctr->n_cand_dcodes ? h_ctr->n_cand_dcodes : h_ctr->n_cand_codes);
       acc.n_level2 += (int64_t)h_ctr->n_level2;
+      acc.n_level0 += (int64_t)h_ctr->n_level0;
       acc.n_rounds = std::max(acc.n_rounds, (int32_t)h_ctr->n_rounds);
     }
   }

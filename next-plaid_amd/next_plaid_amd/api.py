@@ -87,7 +87,7 @@ class np_stats(C.Structure):
                 ("n_cand_tokens", C.c_int64), ("n_exact_docs", C.c_int64), ("n_exact_tokens", C.c_int64),
                 ("n_cand_codes", C.c_int64), ("n_queries", C.c_int32), ("n_rounds", C.c_int32),
                 ("n_survivors", C.c_int64), ("n_cand_dcodes", C.c_int64), ("n_level2", C.c_int64),
-                ("ms_hot_level", C.c_float), ("reserved0", C.c_int32)]
+                ("ms_hot_level", C.c_float), ("reserved0", C.c_int32), ("n_level0", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
@@ -117,7 +117,10 @@ class np_synth_spec(C.Structure):
 ALL_GATHER_HOST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 NP_COMM_DEFERRED_STATUS = 1
 
+NP_ABI_VERSION = 6     # include/nextplaid_hip.h this mirror was written against
+
 EXPORTS = [
+    "np_hip_abi_version", "np_hip_struct_size", "np_hip_comm_info",
     "np_hip_device_count", "np_hip_last_error", "np_hip_index_open", "np_hip_index_from_arrays",
     "np_hip_index_synth", "np_hip_index_export", "np_hip_index_ivf_size", "np_hip_index_tune", "np_hip_index_close",
     "np_hip_index_info", "np_hip_index_probe_dir", "np_hip_index_write_dir", "np_hip_search_batch", "np_hip_search_batch_device", "np_hip_search_phase_a",
@@ -168,6 +171,19 @@ def lib():
     except OSError as e:  # e.g. libamdhip64 missing
         raise DeviceUnavailableError(f"cannot load {path}: {e}") from e
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    # ABI check before any caller-allocated struct crosses the boundary (np_info / np_stats have grown between versions)
+    if not hasattr(L, "np_hip_abi_version"):
+        raise DeviceUnavailableError(f"{path} predates ABI v6 (no np_hip_abi_version); this mirror needs v{NP_ABI_VERSION}: rebuild it")
+    L.np_hip_abi_version.restype = C.c_int
+    L.np_hip_struct_size.argtypes = [i32]
+    L.np_hip_struct_size.restype = i64
+    ver = int(L.np_hip_abi_version())
+    if ver != NP_ABI_VERSION:
+        raise DeviceUnavailableError(f"{path} speaks ABI v{ver}, this mirror v{NP_ABI_VERSION}: rebuild the library")
+    for which, st in ((0, np_info), (1, np_stats), (2, np_search_params), (3, np_open_opts)):
+        if int(L.np_hip_struct_size(which)) != C.sizeof(st):
+            raise DeviceUnavailableError(f"{path}: sizeof({st.__name__}) is {int(L.np_hip_struct_size(which))} in the library, "
+                                         f"{C.sizeof(st)} in this mirror")
     L.np_hip_device_count.restype = C.c_int
     L.np_hip_last_error.restype = C.c_char_p
     L.np_hip_index_open.argtypes = [C.c_char_p, C.POINTER(np_open_opts), C.POINTER(vp)]
@@ -197,6 +213,7 @@ def lib():
     L.np_hip_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
     L.np_hip_comm_create_hosted.argtypes = [vp, i32, i32, ALL_GATHER_HOST_FN, vp, i32, C.POINTER(vp)]
     L.np_hip_comm_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.np_hip_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.np_hip_comm_destroy.argtypes = [vp]
     L.np_hip_comm_destroy.restype = None
     L.np_hip_search_batch_sharded.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.POINTER(np_search_params), vp, i64,

@@ -259,6 +259,13 @@ class ShardComm:
         api._check(api.lib().np_hip_comm_status(self._h, C.byref(r), C.byref(c)))
         return int(r.value), int(c.value)
 
+    def info(self):
+        """np_hip_comm_info: dict(transport "local" | "rccl" | "hosted", nranks, rccl_ranks = ncclCommCount or 0)."""
+        t, n, r = C.c_int32(), C.c_int32(), C.c_int32()
+        api._check(api.lib().np_hip_comm_info(self._h, C.byref(t), C.byref(n), C.byref(r)))
+        return dict(transport={0: "local", 1: "rccl", 2: "hosted"}.get(int(t.value), "?"), nranks=int(n.value),
+                    rccl_ranks=int(r.value))
+
     def close(self):
         h, self._h = self._h, None
         if h:

@@ -145,3 +145,20 @@ def test_make_traffic_refuses_a_kernel_without_a_stage(tmp_path):
     assert out.returncode == 0, out.stderr[-400:]
     t = json.load(open(tmp_path / "t.json"))
     assert t["approx(S4)"] == (2 * 5000 + 5000) * 1024 and t["qc_gemm(S1)"] == (2 * 1000 + 1000 + 2 * 100 + 100) * 1024
+
+
+def test_gpus_n_without_a_launcher_never_runs_one_rank_silently():
+    """`python bench.py --gpus N` outside torch.distributed.run re-executes itself under the launcher, and where the box
+    has fewer than N devices (this container has none) it FAILS, naming the count -- it used to run one rank labelled n_gpus: 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    import next_plaid_amd as npa
+    if npa.device_count() < 2:
+        assert out.returncode != 0 and "--gpus 2" in out.stderr and "gfx950 device" in out.stderr, out.stderr[-2000:]
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # a launcher whose world size disagrees with --gpus is an error too, whatever the sizes
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "1", "0", "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr

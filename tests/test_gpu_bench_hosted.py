@@ -23,11 +23,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(nproc, extra):
+def _run(nproc, extra, launcher=True):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--hosted", "--docs", "120000",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    pre = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] if launcher else [sys.executable]
+    cmd = pre + [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--hosted", "--docs", "120000",
            "--doc-len", "120", "--centroids", "8192", "--steps", "6", "--warmup", "2", "--cpu-queries", "0", "--parity-queries", "16",
            "--workspace-gib", "1"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -46,6 +49,17 @@ def test_two_ranks_one_replica_group():
     pv = d["parity_vs_oracle"]
     assert pv["queries"] == 16 and pv["topk_ids_identical"] == 16 and pv["max_rel_score_err"] < 2e-5, pv
     assert "2 ranks" in pv["through"]
+
+
+def test_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run used to run one rank and label the line
+    n_gpus: 1.  It now re-executes itself under the launcher: two ranks, one line, n_gpus 2, and the line names the transport the
+    communicator really has (np_hip_comm_info)."""
+    d = _run(2, [], launcher=False)
+    assert d["n_gpus"] == 2 and d["config"]["shards"] == 2 and d["config"]["docs_per_gpu"] == 60000
+    assert d["transport"] == "hosted" and d["rccl_ranks_seen"] == 0
+    pv = d["parity_vs_oracle"]
+    assert pv["topk_ids_identical"] == pv["queries"] == 16, pv
 
 
 def test_four_ranks_two_replica_groups_of_two_shards():

@@ -90,7 +90,8 @@ def tuned(mid):
     """Restores the default kernel-selection knobs after a test changed them on the shared handle."""
     hx = mid[3]
     yield hx
-    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 60), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1), ("s4_planes", 1), ("s4_lpd", 2), ("s4_qm", 1), ("s4_warm", 0), ("s4_hot_auto", 200000), ("s3_bisect", 1)):
+    for k, v in (("s4_mode", 4), ("s4_minb", 8), ("s4_swz", 1), ("s4_filter", 1), ("s6_xcd", 1), ("s6_lds", 1), ("s6_tiles", 1), ("exact_rowmax", 0), ("ub_nt", 2), ("ub_steal", 16384), ("ub_nbx", 96), ("s4_hot", 60), ("ub_direct", 8), ("ub_static", 0), ("hot_static", 1), ("s4_planes", 1), ("s4_lpd", 2), ("s4_qm", 1), ("s4_warm", 0), ("s4_hot_auto", 200000), ("s3_bisect", 1), ("s3_gain", 1), ("s3_gain_mult", 3),
+                 ("s3_gain_direct", 16)):
         hx.tune(k, v)
 
 
@@ -375,6 +376,55 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got[:8], orc):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
+
+
+def test_zeroth_level_preserves_selection():
+    """Round 6: where no centroid_score_threshold is set, S3 sums the probed cells' gains per document (an upper
+    bound of the approximate score from the posting lists alone, gain_sweep_kernel) and only the candidates whose bound reaches
+    tau0 -- the n_sel-th best exact lower bound among the ~3 n_sel documents with the largest sums -- enter the filter.  Several
+    32768-document ranges, ragged and non-finite queries, every size of the S0 list and both launch forms of its exact bound: the
+    selected documents, their order and their exact scores are those of the unfiltered path bit for bit, the level really
+    prunes, it never runs with a threshold, and n_candidates stays the size of the posting-list union."""
+    spec, a = make_arrays(num_docs=150000, num_centroids=4096, dim=128, nbits=4, doc_len_min=30, doc_len_max=70, seed=79)
+    hx = hip_index(a)
+    ox = oracle_index(a)
+    qs, src = synth.make_queries(spec, 40, n_tokens=32, cen=a["centroids"])
+    batch = list(qs[:32]) + [qs[33][:7], qs[34][:1]]
+    bad = qs[35].copy()
+    bad[3, 5] = np.nan
+    batch.append(bad)
+    pruned_somewhere = False
+    for nfs, nprobe, thr in ((256, 32, None), (1024, 8, None), (64, 64, None), (256, 32, 0.4)):
+        p = P(n_full_scores=nfs, top_k=max(nfs // 4, 1), n_ivf_probe=nprobe, centroid_score_threshold=thr)
+        hx.tune("s4_filter", 0)
+        ref = hx.search_batch(batch, p)
+        n_union = hx.last_stats["n_candidates"]
+        hx.tune("s4_filter", 1)
+        for gain, mult, direct in ((0, 3, 16), (1, 3, 16), (1, 1, 0), (1, 8, 4)):
+            hx.tune("s3_gain", gain)
+            hx.tune("s3_gain_mult", mult)
+            hx.tune("s3_gain_direct", direct)
+            got = hx.search_batch(batch, p)
+            st = dict(hx.last_stats)
+            for i, (g, r) in enumerate(zip(got, ref)):
+                assert np.array_equal(g.passage_ids, r.passage_ids), f"nfs={nfs} nprobe={nprobe} gain={gain}/{mult}/{direct} q{i}: selection changed"
+                assert np.array_equal(g.scores, r.scores), f"nfs={nfs} gain={gain} q{i}"
+            assert st["n_candidates"] == n_union, (st["n_candidates"], n_union)
+            if gain == 0 or thr is not None:
+                assert st["n_level0"] == 0, st
+            else:
+                assert 0 < st["n_level0"] <= st["n_candidates"], st
+                pruned_somewhere |= st["n_level0"] < st["n_candidates"] // 2
+    assert pruned_somewhere
+    hx.tune("s3_gain", 1)
+    hx.tune("s3_gain_mult", 3)
+    hx.tune("s3_gain_direct", 16)
+    p = P(n_full_scores=256, top_k=64, n_ivf_probe=32, centroid_score_threshold=None)
+    got = hx.search_batch(batch[:8], p)
+    orc = ox.search_batch(batch[:8], to_oracle_params(p))
+    for g, o in zip(got, orc):
+        assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
+    hx.close()
 
 
 def test_long_documents_overflow_blocks_and_windows():

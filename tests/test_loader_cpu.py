@@ -72,10 +72,10 @@ def test_metadata_counts_are_inferred_when_zero(index_dir):
 
 
 def test_probe_reports_the_abi_version(index_dir):
-    """np_info of ABI v5: abi_version 5, workspace_bytes (the live scratch budget) 0 for a host-only probe."""
+    """np_info of ABI v6 (np_hip_abi_version says so before any struct is handed over): abi_version 6, workspace_bytes (the live scratch budget) 0 for a host-only probe."""
     p, a = index_dir
     info = npa.probe_index_dir(p)
-    assert info.abi_version == 5 and info.workspace_bytes == 0 and info.device == -1
+    assert info.abi_version == 6 == npa.api.lib().np_hip_abi_version() and info.workspace_bytes == 0 and info.device == -1
 
 
 def test_merged_cache_and_extra_files_are_ignored(index_dir):
