@@ -1439,30 +1439,41 @@ struct GainP {
   int code_wide, ublock_stride;
   int64_t ovf_base;
   uint32_t* cand;             // mode 2: [pool] ids at cand_base[b]
-  int32_t* n_emit;            // [B] zeroed
+  int32_t* n_emit;            // [B] zeroed: mode 1 slots handed out above the marginal bin; mode 2 (zeroed again) candidates emitted
+  int32_t* n_marg;            // [B] zeroed: mode 1 slots handed out to the marginal bin
+  const int32_t* n_hi;        // [B] documents above the marginal bin of S0 (gain_thr_kernel)
+  uint16_t* acc;              // [B][n_ranges * NP_GAIN_RANGE] the documents' accumulators (sweep -> emission passes)
+  int n_ranges;
   RoundPlan rp;
   Counters* ctr;
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p, int round) {
+// Sweep: block (range r, query b) scatter-adds the gains of the probed cells over its 32768 documents in LDS, then counts
+// the candidates, adds their bounds to the query's histogram and writes the accumulators out (acc[b][doc], u16, coalesced):
+// the two emission passes below are streaming reads of that array instead of two more sweeps of the posting lists (measured,
+// REST default regime at 10 M documents: 0.83 ms per sweep against ~0.2 ms per streaming pass; t_cs = None at nprobe 32: 2.5 ms).
+// Work items are NP_GAIN_ITEM consecutive entries of one list's part, one per half-wave, four in flight per lane; which list an
+// item belongs to is looked up in a map built with the pass's tables (a bisection of the prefix sums beyond the map's size).
+#define NP_GAIN_MAP 4096
+__global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_acc[];   // NP_GAIN_RANGE / 2 words: two u16 accumulators each
-  __shared__ int64_t s_start[NP_GAIN_CELLS];
-  __shared__ uint32_t s_len[NP_GAIN_CELLS], s_g[NP_GAIN_CELLS], s_items[NP_GAIN_CELLS + 1];
+  // the pass tables and, after the last pass, the histogram share one region: two blocks of 77 KB fit a CU's 160 KB
+  constexpr int TAB_WORDS = 2 * NP_GAIN_CELLS + NP_GAIN_CELLS + NP_GAIN_CELLS + (NP_GAIN_CELLS + 4) + NP_GAIN_MAP / 2;
+  static_assert(TAB_WORDS >= NP_UB_BINS, "the histogram reuses the tables' words");
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[TAB_WORDS];
   __shared__ uint32_t s_wsum[16];
-  __shared__ uint32_t s_hist[MODE == 0 ? NP_UB_BINS : 1];
-  __shared__ uint32_t s_out;
+  int64_t* s_start = reinterpret_cast<int64_t*>(s_tab);
+  uint32_t* s_len = s_tab + 2 * NP_GAIN_CELLS;
+  uint32_t* s_g = s_len + NP_GAIN_CELLS;
+  uint32_t* s_items = s_g + NP_GAIN_CELLS;
+  uint16_t* s_map = reinterpret_cast<uint16_t*>(s_items + NP_GAIN_CELLS + 4);
+  uint32_t* s_hist = s_tab;
   const int b = blockIdx.y, r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (MODE == 2 && p.rp.round_of[b] != round) return;
-  const uint32_t thr = MODE == 0 ? 0u : p.thr[b];
-  if (MODE == 1 && thr == 0u) return;
   const int nc = p.n_cells[b];
   const uint32_t lo = (uint32_t)r * NP_GAIN_RANGE;
   {
     uint4* a4 = reinterpret_cast<uint4*>(s_acc);
     for (int i = tid; i < NP_GAIN_RANGE / 8; i += 1024) a4[i] = make_uint4(0u, 0u, 0u, 0u);
-    if constexpr (MODE == 0)
-      for (int i = tid; i < NP_UB_BINS; i += 1024) s_hist[i] = 0;
   }
   unsigned long long ids = 0;
   for (int c0 = 0; c0 < nc; c0 += NP_GAIN_CELLS) {
@@ -1479,7 +1490,7 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p, int round) {
         s_len[tid] = e - s;
         s_g[tid] = (uint32_t)p.gain[(int64_t)b * p.KP + c0 + tid];
         items = (e - s + NP_GAIN_ITEM - 1) / NP_GAIN_ITEM;
-        if (MODE == 0 && r == 0) ids += (unsigned long long)(p.ivf_off[c + 1] - o0);
+        if (r == 0) ids += (unsigned long long)(p.ivf_off[c + 1] - o0);
       }
       incl = items;
 #pragma unroll
@@ -1493,13 +1504,16 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p, int round) {
     if (tid < NP_GAIN_CELLS) {
       uint32_t woff = 0;
       for (int k = 0; k < wave; ++k) woff += s_wsum[k];
-      s_items[tid] = woff + incl - items;
+      const uint32_t first = woff + incl - items;
+      s_items[tid] = first;
       if (tid == NP_GAIN_CELLS - 1) s_items[NP_GAIN_CELLS] = woff + incl;
+      for (uint32_t k = first; k < min(first + items, (uint32_t)NP_GAIN_MAP); ++k) s_map[k] = (uint16_t)tid;
     }
     __syncthreads();
     const uint32_t total = s_items[NP_GAIN_CELLS];
     const uint32_t hw = (uint32_t)tid >> 5, hl = (uint32_t)tid & 31u;
     auto find = [&](uint32_t it) {   // the list item `it` belongs to: largest t < m with s_items[t] <= it
+      if (it < (uint32_t)NP_GAIN_MAP) return (int)s_map[it];
       int a = 0, z = m;
       while (z - a > 1) {
         const int mid = (a + z) >> 1;
@@ -1508,55 +1522,113 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p, int round) {
       }
       return a;
     };
-    for (uint32_t it = hw; it < total; it += 64) {   // two items per half-wave and step: both loads in flight before the adds
-      const uint32_t it2 = it + 32;
-      const int a0 = find(it), a1 = it2 < total ? find(it2) : a0;
-      const uint32_t off0 = (it - s_items[a0]) * NP_GAIN_ITEM + hl;
-      const uint32_t off1 = it2 < total ? (it2 - s_items[a1]) * NP_GAIN_ITEM + hl : 0xFFFFFFFFu;
-      const bool v0 = off0 < s_len[a0], v1 = off1 < s_len[a1] && it2 < total;
-      uint32_t d0 = lo, d1 = lo;
-      if (v0) d0 = p.ivf[s_start[a0] + off0];
-      if (v1) d1 = p.ivf[s_start[a1] + off1];
-      if (v0) {
-        const uint32_t rel = d0 - lo;
-        atomicAdd(&s_acc[rel >> 1], s_g[a0] << ((rel & 1u) * 16u));
+    for (uint32_t it0 = hw; it0 < total; it0 += 128) {   // four items per half-wave and step: every load in flight before the adds
+      uint32_t d[4], g[4];
+      bool v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t it = it0 + 32u * (uint32_t)k;
+        v[k] = it < total;
+        const int a = v[k] ? find(it) : 0;
+        const uint32_t off = (it - s_items[a]) * NP_GAIN_ITEM + hl;
+        v[k] = v[k] && off < s_len[a];
+        g[k] = s_g[a];
+        d[k] = lo;
+        if (v[k]) d[k] = p.ivf[s_start[a] + off];
       }
-      if (v1) {
-        const uint32_t rel = d1 - lo;
-        atomicAdd(&s_acc[rel >> 1], s_g[a1] << ((rel & 1u) * 16u));
-      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (v[k]) {
+          const uint32_t rel = d[k] - lo;
+          atomicAdd(&s_acc[rel >> 1], g[k] << ((rel & 1u) * 16u));
+        }
     }
   }
   __syncthreads();
+  for (int i = tid; i < NP_UB_BINS; i += 1024) s_hist[i] = 0;   // the tables are consumed
+  __syncthreads();
   // ---- scan: thread t owns documents [32 t, 32 t + 32) of the range
   const uint32_t base = p.gbase[2 * b], sh = p.gbase[2 * b + 1];
-  uint32_t w[16];
+  uint32_t cnt = 0;
   {
     const uint4* a4 = reinterpret_cast<const uint4*>(s_acc) + 4 * tid;
+    uint4* out = reinterpret_cast<uint4*>(p.acc + ((int64_t)b * p.n_ranges + r) * NP_GAIN_RANGE) + 4 * tid;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const uint4 v = a4[k];
-      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+      const uint4 vv = a4[k];
+      out[k] = vv;
+      const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t a = (w4[e] >> (16 * h)) & 0xFFFFu;
+          if (a) {
+            atomicAdd(&s_hist[min((base + (a << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1))], 1u);
+            ++cnt;
+          }
+        }
     }
   }
-  uint32_t mask = 0;   // bit j: document 32 t + j is kept (mode 0: is a candidate)
 #pragma unroll
-  for (int k = 0; k < 16; ++k)
+  for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+  if (lane == 0) s_wsum[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t tot = 0;
+    for (int k = 0; k < 16; ++k) tot += s_wsum[k];
+    if (tot) atomicAdd(&p.n_raw[b], (int32_t)tot);
+  }
+  for (int i = tid; i < NP_UB_BINS; i += 1024) {
+    const uint32_t v = s_hist[i];
+    if (v) atomicAdd(&p.hist0[(int64_t)b * NP_UB_BINS + i], v);
+  }
+  if (r == 0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t a = (w[k] >> (16 * h)) & 0xFFFFu;
-      if (a) {
-        const uint32_t bin = min((base + (a << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
-        if constexpr (MODE == 0) {
-          atomicAdd(&s_hist[bin], 1u);
-          mask |= 1u << (2 * k + h);
-        } else if (thr == 0u || bin >= thr) {
-          mask |= 1u << (2 * k + h);
+    for (int o = 32; o > 0; o >>= 1) ids += __shfl_xor(ids, o);
+    if (lane == 0 && ids) atomicAdd(&p.ctr->n_ivf_ids, ids);
+  }
+}
+
+// Emission passes over the stored accumulators: block (slice of 8192 documents, query b).
+//   MODE 1  S0: the documents whose bin lies ABOVE thr[b] fill slots [0, n_hi[b]) of the query's record slice, the documents of
+//           the marginal bin thr[b] fill the slots behind them as far as the slice goes (any subset of the candidates is a valid
+//           S0; gain_thr_kernel has set n_s0[b] = min(cap, #bin >= thr)).  Records are built from the list blocks' headers.
+//   MODE 2  candidates: bin >= thr[b] (every candidate when thr[b] = 0), bare ids in blocks of ascending ids.
+template <int MODE>
+__global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
+  constexpr int DPB = 8192;   // documents per block: 32 per thread
+  __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_out[2];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (MODE == 2 && p.rp.round_of[b] != round) return;
+  const uint32_t thr = p.thr[b];
+  if (MODE == 1 && thr == 0u) return;
+  const int64_t d_first = (int64_t)blockIdx.x * DPB + 32 * tid;
+  const uint32_t base = p.gbase[2 * b], sh = p.gbase[2 * b + 1];
+  uint32_t mask = 0, marg = 0;   // bit j: document d_first + j is kept / kept and in the marginal bin (mode 1)
+  {
+    const uint4* a4 = reinterpret_cast<const uint4*>(p.acc + (int64_t)b * p.n_ranges * NP_GAIN_RANGE + d_first);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint4 vv = a4[k];
+      const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t a = (w4[e] >> (16 * h)) & 0xFFFFu;
+          if (a) {
+            const uint32_t bin = min((base + (a << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
+            const uint32_t bit = 1u << (8 * k + 2 * e + h);
+            if (thr == 0u || bin >= thr) mask |= bit;
+            if (MODE == 1 && bin == thr) marg |= bit;
+          }
         }
-      }
     }
-  // block-wide exclusive scan of the kept counts
-  const uint32_t cnt = (uint32_t)__popc(mask);
+  }
+  // block-wide exclusive scan of (documents above the marginal bin | marginal ones << 16): at most 8192 each
+  const uint32_t cnt = (uint32_t)__popc(mask & ~marg) | ((uint32_t)__popc(marg) << 16);
   uint32_t incl = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -1566,63 +1638,66 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p, int round) {
   if (lane == 63) s_wsum[wave] = incl;
   __syncthreads();
   uint32_t woff = 0, tot = 0;
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < 4; ++k) {
     if (k < wave) woff += s_wsum[k];
     tot += s_wsum[k];
   }
-  if constexpr (MODE == 0) {
-    if (tid == 0 && tot) atomicAdd(&p.n_raw[b], (int32_t)tot);
-    for (int i = tid; i < NP_UB_BINS; i += 1024) {
-      const uint32_t v = s_hist[i];
-      if (v) atomicAdd(&p.hist0[(int64_t)b * NP_UB_BINS + i], v);
+  if (tot == 0) return;   // block-uniform
+  if (tid == 0) {
+    if constexpr (MODE == 1) {
+      s_out[0] = (tot & 0xFFFFu) ? (uint32_t)atomicAdd(&p.n_emit[b], (int32_t)(tot & 0xFFFFu)) : 0u;
+      s_out[1] = (tot >> 16) ? (uint32_t)p.n_hi[b] + (uint32_t)atomicAdd(&p.n_marg[b], (int32_t)(tot >> 16)) : 0u;
+    } else {
+      s_out[0] = (uint32_t)atomicAdd(&p.n_emit[b], (int32_t)(tot & 0xFFFFu));
     }
-    if (r == 0) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) ids += __shfl_xor(ids, o);
-      if (lane == 0 && ids) atomicAdd(&p.ctr->n_ivf_ids, ids);
+  }
+  __syncthreads();
+  const uint32_t ex = woff + incl - cnt;
+  uint32_t pos = s_out[0] + (ex & 0xFFFFu);
+  if constexpr (MODE == 1) {
+    uint32_t posm = s_out[1] + (ex >> 16);
+    const int cb = p.code_wide ? 4 : 2, hdr = 16 / cb, fit = p.ublock_stride - hdr;
+    uint4* out = p.s0_meta + (int64_t)b * p.s0cap;
+    while (mask) {
+      const int j = __ffs((int)mask) - 1;
+      const bool is_m = (marg >> j) & 1u;
+      mask &= mask - 1;
+      const uint32_t d = (uint32_t)d_first + (uint32_t)j;
+      const uint32_t at = is_m ? posm++ : pos++;
+      if (at < (uint32_t)p.s0cap) {
+        const uint4 hd = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.ucodes) + (int64_t)d * p.ublock_stride * cb);
+        const int64_t cl = (int)hd.x > fit ? p.ovf_base + (int64_t)hd.z * 4 : (int64_t)d * p.ublock_stride + hdr;
+        out[at] = make_uint4(d, hd.x, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
+      }
     }
   } else {
-    if (tot == 0) return;   // block-uniform
-    if (tid == 0) s_out = (uint32_t)atomicAdd(MODE == 1 ? &p.n_s0[b] : &p.n_emit[b], (int32_t)tot);
-    __syncthreads();
-    uint32_t pos = s_out + woff + incl - cnt;
-    if constexpr (MODE == 1) {
-      const int cb = p.code_wide ? 4 : 2, hdr = 16 / cb, fit = p.ublock_stride - hdr;
-      uint4* out = p.s0_meta + (int64_t)b * p.s0cap;
-      while (mask) {
-        const int j = __ffs((int)mask) - 1;
-        mask &= mask - 1;
-        const uint32_t d = lo + 32u * (uint32_t)tid + (uint32_t)j;
-        if (pos < (uint32_t)p.s0cap) {
-          const uint4 hd = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.ucodes) + (int64_t)d * p.ublock_stride * cb);
-          const int64_t cl = (int)hd.x > fit ? p.ovf_base + (int64_t)hd.z * 4 : (int64_t)d * p.ublock_stride + hdr;
-          out[pos] = make_uint4(d, hd.x, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
-        }
-        ++pos;
-      }
-    } else {
-      uint32_t* out = p.cand + p.rp.cand_base[b];
-      const uint32_t limit = (uint32_t)p.rp.n_cand[b];
-      while (mask) {
-        const int j = __ffs((int)mask) - 1;
-        mask &= mask - 1;
-        if (pos < limit) out[pos] = lo + 32u * (uint32_t)tid + (uint32_t)j;
-        ++pos;
-      }
+    uint32_t* out = p.cand + p.rp.cand_base[b];
+    const uint32_t limit = (uint32_t)p.rp.n_cand[b];
+    while (mask) {
+      const int j = __ffs((int)mask) - 1;
+      mask &= mask - 1;
+      if (pos < limit) out[pos] = (uint32_t)d_first + (uint32_t)j;
+      ++pos;
     }
   }
 }
 
-// S0 = the ~target documents with the largest U0 (whole histogram bins, at most `cap`): thr[b] = its lowest bin, 0 = no S0
-// (flagged query, fewer candidates than the target, a cut that would reach bin 0, or no bin set between n_sel and cap)
-__global__ void __launch_bounds__(256) gain_thr_kernel(const uint32_t* __restrict__ hist, int target, int n_sel, int cap,
+// S0 = the ~target documents with the largest U0: thr[b] = the histogram bin in which the count from the top reaches the target
+// (0 = no S0: flagged query, fewer candidates than the target, or a cut that would reach bin 0); n_hi[b] = documents in the
+// bins above it (all taken), n_s0[b] = min(cap, documents in bins >= thr): the marginal bin fills what is left of the slice
+__global__ void __launch_bounds__(256) gain_thr_kernel(const uint32_t* __restrict__ hist, int target, int cap,
                                                        const int32_t* __restrict__ n_raw, const uint32_t* __restrict__ qflag,
-                                                       uint32_t* __restrict__ thr) {
+                                                       uint32_t* __restrict__ thr, int32_t* __restrict__ n_hi,
+                                                       int32_t* __restrict__ n_s0) {
   __shared__ uint32_t s_part[256];
   constexpr int BPT = NP_UB_BINS / 256;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (qflag[b] != 0 || n_raw[b] <= target) {
-    if (tid == 0) thr[b] = 0;
+    if (tid == 0) {
+      thr[b] = 0;
+      n_hi[b] = 0;
+      n_s0[b] = 0;
+    }
     return;
   }
   const uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
@@ -1644,13 +1719,16 @@ __global__ void __launch_bounds__(256) gain_thr_kernel(const uint32_t* __restric
       if (cum + hb[bin] >= (uint32_t)target) break;
       cum += hb[bin];
     }
-    // documents in bins >= bin: cum + hb[bin]; too many for the S0 slice: drop the marginal bin if what is above still
-    // holds n_sel documents (any n_sel lower bounds give a valid threshold)
-    if (cum + hb[bin] > (uint32_t)cap) {
-      if (cum >= (uint32_t)n_sel && cum <= (uint32_t)cap) ++bin;
-      else bin = 0;
+    // cum = documents above `bin` (< target <= cap)
+    if (bin <= 0) {
+      thr[b] = 0;
+      n_hi[b] = 0;
+      n_s0[b] = 0;
+    } else {
+      thr[b] = (uint32_t)bin;
+      n_hi[b] = (int32_t)cum;
+      n_s0[b] = (int32_t)min(cum + hb[bin], (uint32_t)cap);
     }
-    thr[b] = (uint32_t)max(bin, 0);
   }
 }
 

@@ -18,7 +18,7 @@ struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, n_list2, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
       subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2, qpad, planes, levels, hotbits,
-      gain, gsmall, ghist, s0_meta, s0_u;   // zeroth filter level (gain_sweep_kernel)
+      gain, gsmall, ghist, s0_meta, s0_u, gacc;   // zeroth filter level (gain_sweep_kernel)
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
@@ -28,7 +28,7 @@ struct Workspace {
             &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
             &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
             &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits, &gain, &gsmall, &ghist,
-            &s0_meta, &s0_u};
+            &s0_meta, &s0_u, &gacc};
   }
   void release_all() {
     const std::vector<DevBuf*> all = all_bufs();
@@ -206,7 +206,8 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int to
   const int64_t nchunks = (NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS;
   return KP * LQP * 6                      // QCT (f32) + QCU (u8, rows padded to a power of two)
          + KP + 1024                       // per-centroid maxima of the u8 table + their histogram (hot level)
-         + KP * 2 + NP_UB_BINS * 8         // zeroth level: gains of the probed cells, two histograms
+         + KP * 2 + NP_UB_BINS * 8         // zeroth level: gains of the probed cells, two histograms,
+         + (ix->d_ivf_split ? (int64_t)ix->n_ranges * NP_GAIN_RANGE * 2 : 0)   // ... the documents' u16 accumulators
          + NP_UB_BINS * 8
          + G * LQP * 4 + G * 4             // gmax, cellbits
          + KP * 8                          // cells_tmp, cells
@@ -578,16 +579,19 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
                          subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0;
   const int s0_target = ix->tune.s3_gain_mult * cs->n_sel;
   // S0 takes whole histogram bins: the marginal bin may hold a few whole posting lists (documents in ONE probed cell share a bound)
-  const int s0cap = (int)std::min<int64_t>(s0_target + cs->n_sel + 4 * (ix->ivf_size / std::max<int64_t>(ix->K, 1)) + 4096, 1 << 22);
-  // u32 words of w.gsmall: [0, 2B) base / shift, then B each: n_raw, thr0, cut0, n_s0, n_emit, n_direct, round_of0, order0, cursor0;
-  // 4 words round_tab0; then (8-byte aligned) cand_base0 i64 [B]
-  const size_t gs_words = (size_t)11 * B + 4 + ((B & 1) ? 1 : 0), gs_bytes = gs_words * 4 + (size_t)B * 8;
+  // S0 takes the bins above the marginal one whole and fills the rest of its slice from the marginal bin (documents in ONE probed
+  // cell share a bound: a bin may hold whole posting lists)
+  const int s0cap = s0_target + cs->n_sel;
+  // u32 words of w.gsmall: [0, 2B) base / shift, then B each: n_raw, thr0, cut0, n_s0, n_emit, n_direct, round_of0, order0, cursor0,
+  // n_hi, n_hi_emit, n_marg; 4 words round_tab0; then (8-byte aligned) cand_base0 i64 [B]
+  const size_t gs_words = (size_t)14 * B + 4 + ((B & 1) ? 0 : 0), gs_bytes = (gs_words + (gs_words & 1)) * 4 + (size_t)B * 8;
   if (gain_path) {
     NP_TRY(w.gain.reserve((size_t)B * KP * 2));
     NP_TRY(w.gsmall.reserve(gs_bytes));
     NP_TRY(w.ghist.reserve((size_t)2 * B * NP_UB_BINS * 4));
     NP_TRY(w.s0_meta.reserve((size_t)B * s0cap * 16));
     NP_TRY(w.s0_u.reserve((size_t)B * s0cap * 2));
+    NP_TRY(w.gacc.reserve((size_t)B * ix->n_ranges * NP_GAIN_RANGE * 2));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -828,8 +832,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     rp0.n_cand = g_ns0;
     rp0.round_of = reinterpret_cast<int32_t*>(gs + 8 * B);
     rp0.order = reinterpret_cast<int32_t*>(gs + 9 * B);
-    rp0.round_tab = reinterpret_cast<int32_t*>(gs + 11 * B);
-    rp0.cand_base = reinterpret_cast<int64_t*>(gs + gs_words);
+    int32_t* g_nhi = reinterpret_cast<int32_t*>(gs + 11 * B);
+    int32_t* g_nhi_emit = reinterpret_cast<int32_t*>(gs + 12 * B);
+    int32_t* g_nmarg = reinterpret_cast<int32_t*>(gs + 13 * B);
+    rp0.round_tab = reinterpret_cast<int32_t*>(gs + 14 * B);
+    rp0.cand_base = reinterpret_cast<int64_t*>(gs + gs_words + (gs_words & 1));
     uint32_t* hist0 = w.ghist.as<uint32_t>();
     uint32_t* hist_s0 = hist0 + (size_t)B * NP_UB_BINS;
     gp.cells = w.cells.as<uint32_t>();
@@ -857,20 +864,24 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     gp.n_emit = g_nemit;
     gp.rp = rp;
     gp.ctr = w.ctr.as<Counters>();
+    gp.acc = w.gacc.as<uint16_t>();
+    gp.n_ranges = ix->n_ranges;
+    gp.n_hi = g_nhi;
+    gp.n_marg = g_nmarg;
     const size_t glds = (size_t)NP_GAIN_RANGE * 2;
-    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+    NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     if (RB == 32)
       gain_prep_kernel<32><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
                                               d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0);
     else
       gain_prep_kernel<64><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
                                               d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0);
-    const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B);
-    gain_sweep_kernel<0><<<ggrid, 1024, glds, st>>>(gp, 0);                                   // histogram of U0, candidate counts
-    gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, cs->n_sel, s0cap, g_nraw, w.qflag.as<uint32_t>(), g_thr0);
-    gain_sweep_kernel<1><<<ggrid, 1024, glds, st>>>(gp, 0);                                   // S0: records of the best bounds
+    const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B), egrid((unsigned)ix->n_ranges * (NP_GAIN_RANGE / 8192), (unsigned)B);
+    gain_sweep_kernel<<<ggrid, 1024, glds, st>>>(gp);                                         // accumulators, histogram of U0, counts
+    gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, s0cap, g_nraw, w.qflag.as<uint32_t>(), g_thr0, g_nhi, g_ns0);
+    gp.n_emit = g_nhi_emit;
+    gain_emit_kernel<1><<<egrid, 256, 0, st>>>(gp, 0);                                        // S0: records of the best bounds
+    gp.n_emit = g_nemit;
     {
       int32_t* sl0 = w.xcd_slots.as<int32_t>() + (size_t)max_rounds * 3 * slot_words;
       launch_ub_at(rp0, 0, 1, sl0, sl0 + 8 * (B + 1), g_cursor0, w.s0_meta.as<uint4>(), nullptr, g_ns0, g_ns0, w.s0_u.as<uint16_t>(), hist_s0,
@@ -952,7 +963,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     // itself (no record gather here: a 128-B line per candidate at 1.9 % density was this kernel's whole cost)
     const bool ids_only = two_level && ix->ublock_stride > 0;
     if (gain_path)   // the candidates that pass the zeroth level's cut (every candidate where it does not apply), bare ids
-      gain_sweep_kernel<2><<<dim3((unsigned)ix->n_ranges, (unsigned)B), 1024, (size_t)NP_GAIN_RANGE * 2, st>>>(gp, r);
+      gain_emit_kernel<2><<<dim3((unsigned)ix->n_ranges * (NP_GAIN_RANGE / 8192), (unsigned)B), 256, 0, st>>>(gp, r);
     else
     compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks, w.chunk_counts.as<int32_t>(),
                                                      (use_filter && !ids_only) ? nullptr : w.cand.as<uint32_t>(), rp, r,
