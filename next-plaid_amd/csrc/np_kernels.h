@@ -1547,16 +1547,17 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
   __syncthreads();
   for (int i = tid; i < NP_UB_BINS; i += 1024) s_hist[i] = 0;   // the tables are consumed
   __syncthreads();
-  // ---- scan: thread t owns documents [32 t, 32 t + 32) of the range
+  // ---- scan: histogram of the bounds, candidate count, accumulators out
   const uint32_t base = p.gbase[2 * b], sh = p.gbase[2 * b + 1];
   uint32_t cnt = 0;
   {
-    const uint4* a4 = reinterpret_cast<const uint4*>(s_acc) + 4 * tid;
-    uint4* out = reinterpret_cast<uint4*>(p.acc + ((int64_t)b * p.n_ranges + r) * NP_GAIN_RANGE) + 4 * tid;
+    // thread t takes the 16-byte pieces t, t + 1024, ... of the range (8 documents each): conflict-free LDS reads, coalesced stores
+    const uint4* a4 = reinterpret_cast<const uint4*>(s_acc) + tid;
+    uint4* out = reinterpret_cast<uint4*>(p.acc + ((int64_t)b * p.n_ranges + r) * NP_GAIN_RANGE) + tid;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const uint4 vv = a4[k];
-      out[k] = vv;
+      const uint4 vv = a4[k * 1024];
+      out[k * 1024] = vv;
       const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -1590,29 +1591,37 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
   }
 }
 
-// Emission passes over the stored accumulators: block (slice of 8192 documents, query b).
+// Emission passes over the stored accumulators: block (range of 32768 documents, query b).
 //   MODE 1  S0: the documents whose bin lies ABOVE thr[b] fill slots [0, n_hi[b]) of the query's record slice, the documents of
 //           the marginal bin thr[b] fill the slots behind them as far as the slice goes (any subset of the candidates is a valid
 //           S0; gain_thr_kernel has set n_s0[b] = min(cap, #bin >= thr)).  Records are built from the list blocks' headers.
-//   MODE 2  candidates: bin >= thr[b] (every candidate when thr[b] = 0), bare ids in blocks of ascending ids.
+//   MODE 2  candidates: bin >= thr[b] (every candidate when thr[b] = 0), bare ids, a range's ids together in any order (the hot
+//           level takes a claim's block offsets from its smallest id).
 template <int MODE>
 __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
-  constexpr int DPB = 8192;   // documents per block: 32 per thread
+  // one block per (range of 32768 documents, query): thread t takes the 16-byte pieces t, t + 256, ... (8 documents each, 16
+  // pieces: every load of a step is one contiguous 4 KB, all 16 in flight), ONE slot reservation per block (the counters of
+  // a batch's queries share two cache lines: a reservation per 8192 documents serialised 78 k atomics on them)
+  constexpr int NP4 = NP_GAIN_RANGE / 8 / 256;   // pieces per thread
   __shared__ uint32_t s_wsum[4];
   __shared__ uint32_t s_out[2];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (MODE == 2 && p.rp.round_of[b] != round) return;
   const uint32_t thr = p.thr[b];
   if (MODE == 1 && thr == 0u) return;
-  const int64_t d_first = (int64_t)blockIdx.x * DPB + 32 * tid;
+  const int64_t d_block = (int64_t)blockIdx.x * NP_GAIN_RANGE;
   const uint32_t base = p.gbase[2 * b], sh = p.gbase[2 * b + 1];
-  uint32_t mask = 0, marg = 0;   // bit j: document d_first + j is kept / kept and in the marginal bin (mode 1)
-  {
-    const uint4* a4 = reinterpret_cast<const uint4*>(p.acc + (int64_t)b * p.n_ranges * NP_GAIN_RANGE + d_first);
+  uint32_t keep[NP4 / 4], marg[NP4 / 4];   // bit 8 (i & 3) + j of word i >> 2: document j of piece i
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint4 vv = a4[k];
-      const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+  for (int w = 0; w < NP4 / 4; ++w) keep[w] = marg[w] = 0;
+  {
+    const uint4* a4 = reinterpret_cast<const uint4*>(p.acc + (int64_t)b * p.n_ranges * NP_GAIN_RANGE + d_block) + tid;
+    uint4 vv[NP4];
+#pragma unroll
+    for (int i = 0; i < NP4; ++i) vv[i] = a4[i * 256];
+#pragma unroll
+    for (int i = 0; i < NP4; ++i) {
+      const uint32_t w4[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1620,64 +1629,80 @@ __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
           const uint32_t a = (w4[e] >> (16 * h)) & 0xFFFFu;
           if (a) {
             const uint32_t bin = min((base + (a << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
-            const uint32_t bit = 1u << (8 * k + 2 * e + h);
-            if (thr == 0u || bin >= thr) mask |= bit;
-            if (MODE == 1 && bin == thr) marg |= bit;
+            const uint32_t bit = 1u << (8 * (i & 3) + 2 * e + h);
+            if (thr == 0u || bin >= thr) keep[i >> 2] |= bit;
+            if (MODE == 1 && bin == thr) marg[i >> 2] |= bit;
           }
         }
     }
   }
-  // block-wide exclusive scan of (documents above the marginal bin | marginal ones << 16): at most 8192 each
-  const uint32_t cnt = (uint32_t)__popc(mask & ~marg) | ((uint32_t)__popc(marg) << 16);
-  uint32_t incl = cnt;
+  // block-wide exclusive scan of (documents above the marginal bin | marginal ones << 16): at most 32768 in all
+  uint32_t c_hi = 0, c_m = 0;
+#pragma unroll
+  for (int w = 0; w < NP4 / 4; ++w) {
+    c_hi += (uint32_t)__popc(keep[w] & ~marg[w]);
+    c_m += (uint32_t)__popc(marg[w]);
+  }
+  uint32_t incl_hi = c_hi, incl_m = c_m;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-    if (lane >= o) incl += v;
-  }
-  if (lane == 63) s_wsum[wave] = incl;
-  __syncthreads();
-  uint32_t woff = 0, tot = 0;
-  for (int k = 0; k < 4; ++k) {
-    if (k < wave) woff += s_wsum[k];
-    tot += s_wsum[k];
-  }
-  if (tot == 0) return;   // block-uniform
-  if (tid == 0) {
-    if constexpr (MODE == 1) {
-      s_out[0] = (tot & 0xFFFFu) ? (uint32_t)atomicAdd(&p.n_emit[b], (int32_t)(tot & 0xFFFFu)) : 0u;
-      s_out[1] = (tot >> 16) ? (uint32_t)p.n_hi[b] + (uint32_t)atomicAdd(&p.n_marg[b], (int32_t)(tot >> 16)) : 0u;
-    } else {
-      s_out[0] = (uint32_t)atomicAdd(&p.n_emit[b], (int32_t)(tot & 0xFFFFu));
+    const uint32_t v = (uint32_t)__shfl_up((int)incl_hi, o), v2 = (uint32_t)__shfl_up((int)incl_m, o);
+    if (lane >= o) {
+      incl_hi += v;
+      incl_m += v2;
     }
   }
+  if (lane == 63) s_wsum[wave] = incl_hi | (incl_m << 16);   // a wave holds at most 8192 documents
   __syncthreads();
-  const uint32_t ex = woff + incl - cnt;
-  uint32_t pos = s_out[0] + (ex & 0xFFFFu);
+  uint32_t woff_hi = 0, woff_m = 0, tot_hi = 0, tot_m = 0;
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t ws = s_wsum[k];
+    if (k < wave) {
+      woff_hi += ws & 0xFFFFu;
+      woff_m += ws >> 16;
+    }
+    tot_hi += ws & 0xFFFFu;
+    tot_m += ws >> 16;
+  }
+  if (tot_hi + tot_m == 0) return;   // block-uniform
+  if (tid == 0) {
+    s_out[0] = tot_hi ? (uint32_t)atomicAdd(&p.n_emit[b], (int32_t)tot_hi) : 0u;
+    if constexpr (MODE == 1) s_out[1] = tot_m ? (uint32_t)p.n_hi[b] + (uint32_t)atomicAdd(&p.n_marg[b], (int32_t)tot_m) : 0u;
+  }
+  __syncthreads();
+  uint32_t pos = s_out[0] + woff_hi + incl_hi - c_hi;
   if constexpr (MODE == 1) {
-    uint32_t posm = s_out[1] + (ex >> 16);
+    uint32_t posm = s_out[1] + woff_m + incl_m - c_m;
     const int cb = p.code_wide ? 4 : 2, hdr = 16 / cb, fit = p.ublock_stride - hdr;
     uint4* out = p.s0_meta + (int64_t)b * p.s0cap;
-    while (mask) {
-      const int j = __ffs((int)mask) - 1;
-      const bool is_m = (marg >> j) & 1u;
-      mask &= mask - 1;
-      const uint32_t d = (uint32_t)d_first + (uint32_t)j;
-      const uint32_t at = is_m ? posm++ : pos++;
-      if (at < (uint32_t)p.s0cap) {
-        const uint4 hd = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.ucodes) + (int64_t)d * p.ublock_stride * cb);
-        const int64_t cl = (int)hd.x > fit ? p.ovf_base + (int64_t)hd.z * 4 : (int64_t)d * p.ublock_stride + hdr;
-        out[at] = make_uint4(d, hd.x, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
+#pragma unroll
+    for (int w = 0; w < NP4 / 4; ++w) {
+      uint32_t m = keep[w];
+      while (m) {
+        const int j = __ffs((int)m) - 1;
+        m &= m - 1;
+        const bool is_m = (marg[w] >> j) & 1u;
+        const uint32_t d = (uint32_t)d_block + (uint32_t)(((4 * w + (j >> 3)) * 256 + tid) * 8 + (j & 7));
+        const uint32_t at = is_m ? posm++ : pos++;
+        if (at < (uint32_t)p.s0cap) {
+          const uint4 hd = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.ucodes) + (int64_t)d * p.ublock_stride * cb);
+          const int64_t cl = (int)hd.x > fit ? p.ovf_base + (int64_t)hd.z * 4 : (int64_t)d * p.ublock_stride + hdr;
+          out[at] = make_uint4(d, hd.x, (uint32_t)(cl & 0xFFFFFFFFll), (uint32_t)((cl >> 32) & 0xFF) | (hd.y << 8));
+        }
       }
     }
   } else {
     uint32_t* out = p.cand + p.rp.cand_base[b];
     const uint32_t limit = (uint32_t)p.rp.n_cand[b];
-    while (mask) {
-      const int j = __ffs((int)mask) - 1;
-      mask &= mask - 1;
-      if (pos < limit) out[pos] = (uint32_t)d_first + (uint32_t)j;
-      ++pos;
+#pragma unroll
+    for (int w = 0; w < NP4 / 4; ++w) {
+      uint32_t m = keep[w];
+      while (m) {
+        const int j = __ffs((int)m) - 1;
+        m &= m - 1;
+        if (pos < limit) out[pos] = (uint32_t)d_block + (uint32_t)(((4 * w + (j >> 3)) * 256 + tid) * 8 + (j & 7));
+        ++pos;
+      }
     }
   }
 }

@@ -876,7 +876,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     else
       gain_prep_kernel<64><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
                                               d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0);
-    const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B), egrid((unsigned)ix->n_ranges * (NP_GAIN_RANGE / 8192), (unsigned)B);
+    const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B), egrid((unsigned)ix->n_ranges, (unsigned)B);
     gain_sweep_kernel<<<ggrid, 1024, glds, st>>>(gp);                                         // accumulators, histogram of U0, counts
     gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, s0cap, g_nraw, w.qflag.as<uint32_t>(), g_thr0, g_nhi, g_ns0);
     gp.n_emit = g_nhi_emit;
@@ -963,7 +963,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     // itself (no record gather here: a 128-B line per candidate at 1.9 % density was this kernel's whole cost)
     const bool ids_only = two_level && ix->ublock_stride > 0;
     if (gain_path)   // the candidates that pass the zeroth level's cut (every candidate where it does not apply), bare ids
-      gain_emit_kernel<2><<<dim3((unsigned)ix->n_ranges * (NP_GAIN_RANGE / 8192), (unsigned)B), 256, 0, st>>>(gp, r);
+      gain_emit_kernel<2><<<dim3((unsigned)ix->n_ranges, (unsigned)B), 256, 0, st>>>(gp, r);
     else
     compact_kernel<<<dim3(nchunks, B), 256, 0, st>>>(w.docbits.as<uint32_t>(), NW, nchunks, w.chunk_counts.as<int32_t>(),
                                                      (use_filter && !ids_only) ? nullptr : w.cand.as<uint32_t>(), rp, r,
