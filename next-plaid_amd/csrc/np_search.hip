@@ -582,9 +582,9 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // S0 takes the bins above the marginal one whole and fills the rest of its slice from the marginal bin (documents in ONE probed
   // cell share a bound: a bin may hold whole posting lists)
   const int s0cap = s0_target + cs->n_sel;
-  // u32 words of w.gsmall: [0, 2B) base / shift, then B each: n_raw, thr0, cut0, n_s0, n_emit, n_direct, round_of0, order0, cursor0,
+  // u32 words of w.gsmall: [0, 4B) base / shift / floor bin / 0, then B each: n_raw, thr0, cut0, n_s0, n_emit, n_direct, round_of0, order0, cursor0,
   // n_hi, n_hi_emit, n_marg; 4 words round_tab0; then (8-byte aligned) cand_base0 i64 [B]
-  const size_t gs_words = (size_t)14 * B + 4 + ((B & 1) ? 0 : 0), gs_bytes = (gs_words + (gs_words & 1)) * 4 + (size_t)B * 8;
+  const size_t gs_words = (size_t)16 * B + 4, gs_bytes = (gs_words + (gs_words & 1)) * 4 + (size_t)B * 8;
   if (gain_path) {
     NP_TRY(w.gain.reserve((size_t)B * KP * 2));
     NP_TRY(w.gsmall.reserve(gs_bytes));
@@ -821,21 +821,21 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   if (have_cands && gain_path) {
     uint32_t* gs = w.gsmall.as<uint32_t>();
     uint32_t* g_base = gs;
-    int32_t* g_nraw = reinterpret_cast<int32_t*>(gs + 2 * B);
-    uint32_t* g_thr0 = gs + 3 * B;
-    uint32_t* g_cut0 = gs + 4 * B;
-    int32_t* g_ns0 = reinterpret_cast<int32_t*>(gs + 5 * B);
-    int32_t* g_nemit = reinterpret_cast<int32_t*>(gs + 6 * B);
-    int32_t* g_ndirect = reinterpret_cast<int32_t*>(gs + 7 * B);
-    uint32_t* g_cursor0 = gs + 10 * B;
+    int32_t* g_nraw = reinterpret_cast<int32_t*>(gs + 4 * B);
+    uint32_t* g_thr0 = gs + 5 * B;
+    uint32_t* g_cut0 = gs + 6 * B;
+    int32_t* g_ns0 = reinterpret_cast<int32_t*>(gs + 7 * B);
+    int32_t* g_nemit = reinterpret_cast<int32_t*>(gs + 8 * B);
+    int32_t* g_ndirect = reinterpret_cast<int32_t*>(gs + 9 * B);
+    uint32_t* g_cursor0 = gs + 12 * B;
     RoundPlan rp0;          // the S0 launch: one round, identity order, slices of s0cap records
     rp0.n_cand = g_ns0;
-    rp0.round_of = reinterpret_cast<int32_t*>(gs + 8 * B);
-    rp0.order = reinterpret_cast<int32_t*>(gs + 9 * B);
-    int32_t* g_nhi = reinterpret_cast<int32_t*>(gs + 11 * B);
-    int32_t* g_nhi_emit = reinterpret_cast<int32_t*>(gs + 12 * B);
-    int32_t* g_nmarg = reinterpret_cast<int32_t*>(gs + 13 * B);
-    rp0.round_tab = reinterpret_cast<int32_t*>(gs + 14 * B);
+    rp0.round_of = reinterpret_cast<int32_t*>(gs + 10 * B);
+    rp0.order = reinterpret_cast<int32_t*>(gs + 11 * B);
+    int32_t* g_nhi = reinterpret_cast<int32_t*>(gs + 13 * B);
+    int32_t* g_nhi_emit = reinterpret_cast<int32_t*>(gs + 14 * B);
+    int32_t* g_nmarg = reinterpret_cast<int32_t*>(gs + 15 * B);
+    rp0.round_tab = reinterpret_cast<int32_t*>(gs + 16 * B);
     rp0.cand_base = reinterpret_cast<int64_t*>(gs + gs_words + (gs_words & 1));
     uint32_t* hist0 = w.ghist.as<uint32_t>();
     uint32_t* hist_s0 = hist0 + (size_t)B * NP_UB_BINS;
@@ -872,13 +872,13 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     if (RB == 32)
       gain_prep_kernel<32><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
-                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0);
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift);
     else
       gain_prep_kernel<64><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
-                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0);
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift);
     const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B), egrid((unsigned)ix->n_ranges, (unsigned)B);
     gain_sweep_kernel<<<ggrid, 1024, glds, st>>>(gp);                                         // accumulators, histogram of U0, counts
-    gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, s0cap, g_nraw, w.qflag.as<uint32_t>(), g_thr0, g_nhi, g_ns0);
+    gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, cs->n_sel, s0cap, g_base, g_nraw, w.qflag.as<uint32_t>(), g_thr0, g_nhi, g_ns0);
     gp.n_emit = g_nhi_emit;
     gain_emit_kernel<1><<<egrid, 256, 0, st>>>(gp, 0);                                        // S0: records of the best bounds
     gp.n_emit = g_nemit;
@@ -888,7 +888,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
                    0, ix->tune.s3_gain_direct, false);                                        // exact bounds of S0 (histogram: lower bounds)
     }
     ub_thr_kernel<<<B, 256, 0, st>>>(hist_s0, hshift, slack, cs->n_sel, g_ns0, rp0, 0, w.qflag.as<uint32_t>(), g_cut0);   // tau0 - slack
-    gain_count_kernel<<<B, 256, 0, st>>>(hist0, g_cut0, g_nraw, g_ndirect, w.ctr.as<Counters>());
+    gp.thr = g_cut0;
+    gp.n_emit = g_ndirect;
+    gain_emit_kernel<0><<<egrid, 256, 0, st>>>(gp, 0);                                        // candidates at the cut, counted
+    gp.n_emit = g_nemit;
+    gain_count_kernel<<<1, 64, 0, st>>>(g_cut0, g_nraw, g_ndirect, B, w.ctr.as<Counters>());
     plan_rounds_kernel<<<1, 256, 0, st>>>(nullptr, 0, B, pool, max_rounds, rp, w.ctr.as<Counters>(), g_ndirect);
     gp.thr = g_cut0;
   }
