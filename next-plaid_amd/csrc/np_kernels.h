@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(256) probe_finish_kernel(ProbeP p) {
   const uint32_t nfin = s_nfinal;
   if (tid == 0) {
     s_obase = nfin ? (uint32_t)atomicAdd(&p.n_cells[b], (int32_t)nfin) : 0u;
-    if (nfin) atomicAdd(&p.ctr->n_cells, (unsigned long long)nfin);
+    if (nfin && p.ctr) atomicAdd(&p.ctr->n_cells, (unsigned long long)nfin);
   }
   __syncthreads();
   uint32_t* outc = p.cells + (int64_t)b * p.KP + s_obase;
@@ -1317,10 +1317,9 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
 //   P       = the probed cells = union of top(q).  Without a centroid_score_threshold every probed cell is kept, and a centroid
 //             OUTSIDE P is in no token's top-n_probe: QC[q, c] <= theta_q for every token q
 //   in table units (u = S1's monotone u8 table):  ut_q = u(theta_q),   G(c) = sum_q max(0, u[q, c] - ut_q)   for c in P
-//   U0(d)   = sum_q ut_q + sum_{c in P, d in list(c)} (G(c) + 1)
+//   U0(d)   = sum_q ut_q + sum_{c in P, d in list(c)} G(c)
 //          >= sum_q max(ut_q, max_{c in P & codes(d)} u[q, c])  >=  sum_q max_{c in codes(d)} u[q, c] = U(d)
-// (a sum over the document's probed cells instead of a per-token maximum: ONE accumulator per document; the +1 marks the
-// document as a candidate whatever its cells' gains).  d is in list(c) exactly when c is one of its codes, so the accumulator
+// (a sum over the document's probed cells instead of a per-token maximum: ONE accumulator per document).  d is in list(c) exactly when c is one of its codes, so the accumulator
 // is a scatter-add of G(c) + 1 over the probed posting lists -- what mark_slices_kernel does with one bit.  U0 is an upper
 // bound of the exact integer bound U, so it may stand in front of the existing cuts: with tau0 = the n_sel-th largest LOWER
 // bound L among ANY set S0 of candidates (approx_ub_kernel on the ~3 n_sel documents with the largest U0), a document with
@@ -1331,11 +1330,18 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
 // REMOVED cells of a query (search.rs:417-425) would have to enter theta (their scores reach 0.4) and sum theta' = 11.5
 // exceeds tau ~ 10-12: nothing to gain there, so the level runs only where no threshold is set.
 //
-// Three sweeps over the probed posting lists, each block (range r, query b) holding the u16 accumulators of 32768 documents
-// in LDS (two per dword, ds_add_u32; the gains are scaled so that the sum over ALL probed cells fits 16 bits: no carry into
-// the neighbour): 0 = histogram of U0 + candidate count, 1 = emit S0 (records for the exact bound), 2 = emit the candidates
-// that pass the cut (bare ids, in blocks of ascending ids: the hot level takes claims in any order).  A range's part of a
-// posting list comes from a static table built at open (ivf_split[c][r] = first entry of list c with id >= 32768 r).
+// DEEPER THAN THE PROBE (n_ivf_probe < 32): the bound's floor sum_q ut_q falls with the depth (a token's 32nd best score instead
+// of its 8th: 10.3 -> 9.2 score units on the metric corpus, against cuts of 10-12.5: one query in four had NO pruning at depth 8,
+// every query at depth 32).  So the level probes on its own to depth max(n_ivf_probe, 32) (the S2 kernels once more): the cells
+// beyond the search's own are BOUND-ONLY -- their lists add gains but make no candidates.  An accumulator holds 2 x the sum and
+// bit 0 = "in a cell the search probed" (ds_or): a candidate is an accumulator with bit 0 set.
+//
+// One sweep over the probed posting lists, each block (range r, query b) holding the u16 accumulators of 32768 documents
+// in LDS (two per dword, ds_add_u32; the gains are scaled so that twice the sum over ALL probed cells fits 16 bits: no carry
+// into the neighbour), writes the accumulators out; three streaming passes over them count the candidates at the cut, emit S0
+// (records for the exact bound) and emit the candidates that pass the cut (bare ids, ascending inside a range, ranges in any
+// order: the hot level takes a claim's block offsets from its smallest id).  A range's part of a posting list comes from a
+// static table built at open (ivf_split[c][r] = entries of list c with id < 32768 r).
 // ---------------------------------------------------------------------------------------------
 #define NP_UB_BINS 2048    // histogram bins of the integer bounds: bin = U >> hshift, hshift = log2(ROWB / 32) + 2 (U <= 255 * ROWB);
                            // u32 counters in LDS (8 KB): a workgroup's share of a query's documents is unbounded
@@ -1352,7 +1358,8 @@ __global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restric
                                                         const int32_t* __restrict__ qoff, uint16_t* __restrict__ gain /* [B][KP] */,
                                                         uint32_t* __restrict__ gbase /* [B][4]: base, shift, floor bin, 0 */, int B, int s0cap,
                                                         RoundPlan rp0, const int64_t* __restrict__ ivf_off, int64_t floor_entries,
-                                                        int hshift) {
+                                                        int hshift, const uint32_t* __restrict__ real_bits /* [B][KP / 32] the cells the
+                                                            search probes (S2's marks) when `cells` goes deeper; NULL: all of them */) {
   static_assert(RB == 32 || RB == 64, "rows of 32 or 64 query tokens");
   __shared__ uint32_t s_ut[RB];
   __shared__ uint32_t s_red[4];
@@ -1398,8 +1405,8 @@ __global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restric
           g += max(u, t) - t;                      // padding tokens: u = t = 0
         }
     }
-    gb[i] = (uint16_t)(g + 1u);                    // <= 254 * 64 + 1
-    tot += g + 1u;
+    gb[i] = (uint16_t)g;                           // <= 254 * 64
+    tot += g;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o);
@@ -1407,9 +1414,14 @@ __global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restric
   __syncthreads();
   tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   uint32_t sh = 0;
-  while ((tot >> sh) + (uint32_t)nc > 65535u) ++sh;   // sum of ceil(g / 2^sh) <= tot / 2^sh + nc
-  if (sh)
-    for (int i = tid; i < nc; i += 256) gb[i] = (uint16_t)(((uint32_t)gb[i] + (1u << sh) - 1u) >> sh);
+  while ((tot >> sh) + (uint32_t)nc > 32767u) ++sh;   // sum of ceil(g / 2^sh) <= tot / 2^sh + nc; the accumulators hold twice that
+  // stored: the scaled gain (< 2^15) | bit 15 = the search probes this cell itself (its documents are candidates)
+  for (int i = tid; i < nc; i += 256) {
+    const uint32_t c = cells[(int64_t)b * KP + i];
+    const uint32_t real = real_bits ? (real_bits[(int64_t)b * (KP >> 5) + (c >> 5)] >> (c & 31)) & 1u : 1u;
+    gb[i] = (uint16_t)((((uint32_t)gb[i] + (1u << sh) - 1u) >> sh) | (real << 15));
+  }
+  __syncthreads();
   // floor of the sweep's histogram: the largest (scaled) gain value gf with at least 2 x target posting entries in cells of
   // gain >= gf -- the ~3 n_sel best bounds lie above base + gf unless the lists overlap heavily (then S0 is simply smaller)
   __shared__ uint32_t s_gh[256];
@@ -1418,14 +1430,15 @@ __global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restric
   if (tid == 0) s_gmax = 0;
   __syncthreads();
   uint32_t gm = 0;
-  for (int i = tid; i < nc; i += 256) gm = max(gm, (uint32_t)gb[i]);
+  for (int i = tid; i < nc; i += 256) gm = max(gm, (uint32_t)gb[i] & 0x7FFFu);
   if (gm) atomicMax(&s_gmax, gm);
   __syncthreads();
   int gshift = 0;
   while ((s_gmax >> gshift) > 255u) ++gshift;
   for (int i = tid; i < nc; i += 256) {
     const uint32_t c = cells[(int64_t)b * KP + i];
-    atomicAdd(&s_gh[(uint32_t)gb[i] >> gshift], (uint32_t)min<int64_t>(ivf_off[c + 1] - ivf_off[c], 0x3FFFFFFF));
+    if (gb[i] & 0x8000u)   // candidates come from the cells the search probes
+      atomicAdd(&s_gh[((uint32_t)gb[i] & 0x7FFFu) >> gshift], (uint32_t)min<int64_t>(ivf_off[c + 1] - ivf_off[c], 0x3FFFFFFF));
   }
   __syncthreads();
   if (tid == 0) {
@@ -1553,8 +1566,9 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
       const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)ln, k), gk = (uint32_t)__builtin_amdgcn_readlane((int)g, k);
       lmax = max(lmax, lk);
       if ((uint32_t)lane < lk) {
-        const uint32_t rel = d[k] - lo;
-        atomicAdd(&s_acc[rel >> 1], gk << ((rel & 1u) * 16u));
+        const uint32_t rel = d[k] - lo, shl = (rel & 1u) * 16u;
+        if (gk & 0x7FFFu) atomicAdd(&s_acc[rel >> 1], ((gk & 0x7FFFu) * 2u) << shl);
+        if (gk & 0x8000u) atomicOr(&s_acc[rel >> 1], 1u << shl);
       }
     }
     if (lmax > 64u) {                                   // parts longer than a wave (popular centroids)
@@ -1566,8 +1580,9 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
         const uint32_t* src = part(k);
         for (uint32_t off = 64; off < lk; off += 64)
           if (off + (uint32_t)lane < lk) {
-            const uint32_t rel = src[off + lane] - lo;
-            atomicAdd(&s_acc[rel >> 1], gk << ((rel & 1u) * 16u));
+            const uint32_t rel = src[off + lane] - lo, shl = (rel & 1u) * 16u;
+            if (gk & 0x7FFFu) atomicAdd(&s_acc[rel >> 1], ((gk & 0x7FFFu) * 2u) << shl);
+            if (gk & 0x8000u) atomicOr(&s_acc[rel >> 1], 1u << shl);
           }
       }
     }
@@ -1591,9 +1606,9 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const uint32_t a = (w4[e] >> (16 * h)) & 0xFFFFu;
-          if (a) {
+          if (a & 1u) {
             ++cnt;
-            const uint32_t bin = min((base + (a << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
+            const uint32_t bin = min((base + ((a >> 1) << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
             if (bin >= floorbin) atomicAdd(&s_hist[bin], 1u);
           }
         }
@@ -1656,8 +1671,8 @@ __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const uint32_t a = (w4[e] >> (16 * h)) & 0xFFFFu;
-          if (a) {
-            const uint32_t bin = min((base + (a << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
+          if (a & 1u) {
+            const uint32_t bin = min((base + ((a >> 1) << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
             const uint32_t bit = 1u << (8 * (i & 3) + 2 * e + h);
             if (thr == 0u || bin >= thr) keep[i >> 2] |= bit;
             if (MODE == 1 && bin == thr) marg[i >> 2] |= bit;

@@ -18,7 +18,7 @@ struct Workspace {
   DevBuf q, qoff, Qt, Qb, Qbl, QCT, gmax, tauq, cellbits, cells_tmp, cells, n_cells, docbits, chunk_counts, cand, cand_meta, approx, n_cand,
       cand_base, round_of, round_tab, QCU, qinv, qflag, ub, ub_hist, ub_thr, ub_cursor, q_order, xcd_slots, surv_meta, n_surv, n_list2, sel_keys, sel_doc, nsel, exact, out_ids, out_scores, out_keys, out_counts, ctr, subset,
       subset_bits, elig, misc, cut, cmaxu, chist, ub2, ub_hist2, ub_thr2, list_meta, n_l1, n_l2, qpad, planes, levels, hotbits,
-      gain, gsmall, ghist, s0_meta, s0_u, gacc;   // zeroth filter level (gain_sweep_kernel)
+      gain, gsmall, ghist, s0_meta, s0_u, gacc, gdeep;   // zeroth filter level (gain_sweep_kernel)
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
@@ -28,7 +28,7 @@ struct Workspace {
             &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
             &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
             &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits, &gain, &gsmall, &ghist,
-            &s0_meta, &s0_u, &gacc};
+            &s0_meta, &s0_u, &gacc, &gdeep};
   }
   void release_all() {
     const std::vector<DevBuf*> all = all_bufs();
@@ -206,7 +206,7 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int to
   const int64_t nchunks = (NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS;
   return KP * LQP * 6                      // QCT (f32) + QCU (u8, rows padded to a power of two)
          + KP + 1024                       // per-centroid maxima of the u8 table + their histogram (hot level)
-         + KP * 2 + NP_UB_BINS * 8         // zeroth level: gains of the probed cells, two histograms,
+         + KP * 6 + G * 4 + NP_UB_BINS * 8   // zeroth level: gains of the probed cells, its own deeper cell list, two histograms,
          + (ix->d_ivf_split ? (int64_t)ix->n_ranges * NP_GAIN_RANGE * 2 : 0)   // ... the documents' u16 accumulators
          + NP_UB_BINS * 8
          + G * LQP * 4 + G * 4             // gmax, cellbits
@@ -577,6 +577,9 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // the bit-plane first level behind it (it takes the candidate ids in any order) and without a subset.
   const bool gain_path = two_level && use_planes && ix->d_ivf_split != nullptr && ix->tune.s3_gain && !prm.has_threshold &&
                          subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0;
+  // the level probes on its own to depth 32 where the search stops earlier: the bound's floor falls with the depth (np_kernels.h)
+  const int gain_depth = 32;
+  const bool gain_deep = gain_path && prm.n_ivf_probe < gain_depth && ix->K > gain_depth;
   const int s0_target = ix->tune.s3_gain_mult * cs->n_sel;
   // S0 takes whole histogram bins: the marginal bin may hold a few whole posting lists (documents in ONE probed cell share a bound)
   // S0 takes the bins above the marginal one whole and fills the rest of its slice from the marginal bin (documents in ONE probed
@@ -592,6 +595,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     NP_TRY(w.s0_meta.reserve((size_t)B * s0cap * 16));
     NP_TRY(w.s0_u.reserve((size_t)B * s0cap * 2));
     NP_TRY(w.gacc.reserve((size_t)B * ix->n_ranges * NP_GAIN_RANGE * 2));
+    if (gain_deep) NP_TRY(w.gdeep.reserve(((size_t)B * G + (size_t)B * LQP + (size_t)B + (size_t)B * KP) * 4));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -630,6 +634,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       add(w.ub_cursor.p, (size_t)3 * B * 4, 0);
       add(w.xcd_slots.p, ((size_t)max_rounds * 3 + 1) * slot_words * 4, 0xFFFFFFFFu);   // slots and tickets of every launch: -1
     }
+    if (gain_deep) add(w.gdeep.p, ((size_t)B * G + (size_t)B * LQP + (size_t)B) * 4, 0);   // marks, per-token thresholds, cell counts
     if (gain_path) {
       add(w.gsmall.p, gs_bytes, 0);
       add(w.ghist.p, (size_t)2 * B * NP_UB_BINS * 4, 0);
@@ -740,6 +745,19 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     if (pp.lds_gm) probe_mark_kernel<4><<<dim3((unsigned)(LQP / 4), B), 256, gm_lds, st>>>(pp);
     else probe_mark_kernel<8><<<dim3((unsigned)(LQP / 8), B), 256, 0, st>>>(pp);
     probe_finish_kernel<<<dim3(NP_PROBE_NF, B), 256, 0, st>>>(pp);
+    if (gain_deep) {   // the zeroth level's own, deeper probe: bound-only cells beyond the search's
+      ProbeP p2 = pp;
+      uint32_t* gd = w.gdeep.as<uint32_t>();
+      p2.nprobe = gain_depth;
+      p2.cellbits = gd;
+      p2.tauq = gd + (size_t)B * G;
+      p2.n_cells = reinterpret_cast<int32_t*>(gd + (size_t)B * G + (size_t)B * LQP);
+      p2.cells = gd + (size_t)B * G + (size_t)B * LQP + (size_t)B;
+      p2.ctr = nullptr;
+      if (p2.lds_gm) probe_mark_kernel<4><<<dim3((unsigned)(LQP / 4), B), 256, gm_lds, st>>>(p2);
+      else probe_mark_kernel<8><<<dim3((unsigned)(LQP / 8), B), 256, 0, st>>>(p2);
+      probe_finish_kernel<<<dim3(NP_PROBE_NF, B), 256, 0, st>>>(p2);
+    }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));
 
@@ -839,8 +857,16 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     rp0.cand_base = reinterpret_cast<int64_t*>(gs + gs_words + (gs_words & 1));
     uint32_t* hist0 = w.ghist.as<uint32_t>();
     uint32_t* hist_s0 = hist0 + (size_t)B * NP_UB_BINS;
+    const uint32_t* g_tauq = w.tauq.as<uint32_t>();
     gp.cells = w.cells.as<uint32_t>();
     gp.n_cells = w.n_cells.as<int32_t>();
+    if (gain_deep) {
+      const uint32_t* gd = w.gdeep.as<uint32_t>();
+      g_tauq = gd + (size_t)B * G;
+      gp.n_cells = reinterpret_cast<const int32_t*>(gd + (size_t)B * G + (size_t)B * LQP);
+      gp.cells = gd + (size_t)B * G + (size_t)B * LQP + (size_t)B;
+    }
+    const uint32_t* g_real = gain_deep ? w.cellbits.as<uint32_t>() : nullptr;
     gp.KP = KP;
     gp.ivf_off = ix->d_ivf_offsets;
     gp.ivf = ix->d_ivf;
@@ -871,11 +897,13 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     const size_t glds = (size_t)NP_GAIN_RANGE * 2;
     NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     if (RB == 32)
-      gain_prep_kernel<32><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
-                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift);
+      gain_prep_kernel<32><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, g_tauq, LQP, w.qinv.as<float>(),
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift,
+                                              g_real);
     else
-      gain_prep_kernel<64><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, w.tauq.as<uint32_t>(), LQP, w.qinv.as<float>(),
-                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift);
+      gain_prep_kernel<64><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, g_tauq, LQP, w.qinv.as<float>(),
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift,
+                                              g_real);
     const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B), egrid((unsigned)ix->n_ranges, (unsigned)B);
     gain_sweep_kernel<<<ggrid, 1024, glds, st>>>(gp);                                         // accumulators, histogram of U0, counts
     gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, cs->n_sel, s0cap, g_base, g_nraw, w.qflag.as<uint32_t>(), g_thr0, g_nhi, g_ns0);
