@@ -2696,10 +2696,14 @@ __global__ void __launch_bounds__(256) approx_ub_kernel(const uint8_t* __restric
             }
           }
           if constexpr (FLOOR && !WLDS) {   // every bitmap word of the batch requested before the first one is used
+            // (only for slots inside the list, and clamped to the map: what follows a list in memory -- padding, the next block's
+            // header, another overflow list -- must never become an address)
+            const uint32_t wlast = (uint32_t)(KP >> 5) - 1u;
 #pragma unroll
             for (int j = 0; j < SB; ++j)
 #pragma unroll
-              for (int k = 0; k < CPS; ++k) wvg[j][k] = wb[cv[j][k] >> 5];
+              for (int k = 0; k < CPS; ++k)
+                wvg[j][k] = (p0 + CPS * hl + k < nds[j]) ? wb[min(cv[j][k] >> 5, wlast)] : 0u;
           }
 #pragma unroll
           for (int j = 0; j < SB; ++j) {

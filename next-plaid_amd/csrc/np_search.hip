@@ -8,6 +8,7 @@
 #include "np_kernels.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <stdlib.h>
 #include <string.h>
@@ -23,16 +24,12 @@ struct Workspace {
   size_t h_pin_cap = 0;
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
   bool done_valid = false;
-  std::vector<DevBuf*> all_bufs() {
-    return {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits,
-            &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc,
-            &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc,
-            &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits, &gain, &gsmall, &ghist,
-            &s0_meta, &s0_u, &gacc, &gdeep};
+  static constexpr int NBUF = 66;
+  std::array<DevBuf*, NBUF> all_bufs() {   // no heap allocation: total_bytes() runs on the search path
+    return {&q, &qoff, &Qt, &Qb, &Qbl, &QCT, &gmax, &tauq, &cellbits, &cells_tmp, &cells, &n_cells, &docbits, &chunk_counts, &cand, &cand_meta, &approx, &n_cand, &cand_base, &round_of, &round_tab, &QCU, &qinv, &qflag, &ub, &ub_hist, &ub_thr, &ub_cursor, &q_order, &xcd_slots, &surv_meta, &n_surv, &n_list2, &sel_keys, &sel_doc, &nsel, &exact, &out_ids, &out_scores, &out_keys, &out_counts, &ctr, &subset, &subset_bits, &elig, &misc, &cut, &cmaxu, &chist, &ub2, &ub_hist2, &ub_thr2, &list_meta, &n_l1, &n_l2, &qpad, &planes, &levels, &hotbits, &gain, &gsmall, &ghist, &s0_meta, &s0_u, &gacc, &gdeep};
   }
   void release_all() {
-    const std::vector<DevBuf*> all = all_bufs();
-    for (DevBuf* b : all) b->release();
+    for (DevBuf* b : all_bufs()) b->release();
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
     h_pin_cap = 0;
@@ -44,6 +41,7 @@ struct Workspace {
     for (DevBuf* b : all_bufs()) t += b->cap;
     return t;
   }
+  unsigned probe_tick = 0;   // rate limit of the free-memory probe while the budget stands below its value at open
   size_t pool_bytes() const {   // the candidate pool and its companions (sized by the budget)
     return cand.cap + cand_meta.cap + approx.cap + ub.cap + surv_meta.cap + ub2.cap + list_meta.cap;
   }
@@ -483,7 +481,9 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     // pools: 466 instead of ~15 000 queries/s.
     const int64_t want = std::min<int64_t>(plan.pool, (int64_t)std::max(B, 1) * std::max<int64_t>(ix->n_docs, 1));
     const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
-    const bool below = allow_grow && budget < ix->ws_budget_open;
+    // (a context whose own pool fills the device never sees a whole budget free: it would pay hipMemGetInfo on every call for
+    // nothing, so the regrow probe runs on every 32nd call of the context; a pool that must GROW always looks)
+    const bool below = allow_grow && budget < ix->ws_budget_open && (w.probe_tick++ & 31u) == 0u;
     if ((int64_t)w.cand.cap < want * 4 || below) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -494,7 +494,10 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
         if (avail < budget && need > avail) nb = std::max<int64_t>(avail, (int64_t)256 << 20);
         else if (below && (int64_t)free_b >= ix->ws_budget_open + ((int64_t)1 << 30)) nb = ix->ws_budget_open;
         if (nb != budget) {
-          ix->ws_budget.store(nb, std::memory_order_relaxed);
+          // concurrent contexts share the budget: only the context whose view is still current installs its value (a lost
+          // race re-plans from whatever the winner stored)
+          int64_t seen = budget;
+          (void)ix->ws_budget.compare_exchange_strong(seen, nb, std::memory_order_relaxed);
           plan = plan_workspace(ix, B, LQP, &prm);
         }
       }

@@ -182,3 +182,35 @@ def test_colgrep_window_and_encoder_query_length(big):
     p = P(n_full_scores=8192, top_k=10, n_ivf_probe=32, centroid_score_threshold=0.4, centroid_batch_size=cbs)
     for g, o in zip(hx.search_batch(mixed, p), ox.search_batch(mixed, to_oracle_params(p))):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} mixed lengths")
+
+
+def test_crate_natural_regime(big):
+    """the configuration the crate and its REST API produce by themselves at scale -- K beyond
+    centroid_batch_size = 100 000 (kmeans.rs:303-309 picks 2^19 at 10 M x 300 tokens), `centroid_score_threshold` None and
+    `n_ivf_probe` 8 (next-plaid-api/src/models.rs:271-284), n_full_scores 4096 and ColGREP's 8192, 32- and 48-token queries --
+    as one case: batched probe + no threshold + mat-vec re-scoring, through the production path (since round 6 with the
+    zeroth filter level in front: u32 code lists, its own probe to depth 32).  Stage traces bit-equal, rankings those of the
+    oracle, the source document first."""
+    name, spec, hx, ox, qs, src, cbs = big
+    cen = synth.centroids(spec)
+    q48, src48 = synth.make_queries(spec, 8, n_tokens=48, cen=cen, first_query=200)
+    for nfs in (4096, 8192):
+        p = P(n_full_scores=nfs, top_k=10, n_ivf_probe=8, centroid_score_threshold=None, centroid_batch_size=cbs)
+        trace_equal(hx, ox, qs[0], p, f"{name} crate-natural nfs={nfs} Lq=32")
+        trace_equal(hx, ox, q48[0], p, f"{name} crate-natural nfs={nfs} Lq=48")
+        for batch, srcs, what in ((qs[:16], src[:16], "Lq=32"), (q48, src48, "Lq=48")):
+            got = hx.search_batch(batch, p)
+            st = dict(hx.last_stats)
+            ref = ox.search_batch(batch, to_oracle_params(p))
+            for i, (g, o) in enumerate(zip(got, ref)):
+                assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} crate-natural nfs={nfs} {what} q{i}")
+                assert g.passage_ids[0] == srcs[i]
+            assert 0 < st["n_level0"] <= st["n_candidates"], st          # the zeroth level ran (no threshold)
+            assert 0 < st["n_survivors"] <= st["n_level0"], st
+            hx.tune("s3_gain", 0)
+            try:
+                for g, o in zip(hx.search_batch(batch, p), got):          # ... and changed nothing
+                    assert np.array_equal(g.passage_ids, o.passage_ids) and np.array_equal(g.scores, o.scores)
+                assert hx.last_stats["n_level0"] == 0
+            finally:
+                hx.tune("s3_gain", 1)

@@ -460,7 +460,9 @@ def test_long_documents_overflow_blocks_and_windows():
             for i, (g, r) in enumerate(zip(got, ref)):
                 assert np.array_equal(g.passage_ids, r.passage_ids) and np.array_equal(g.scores, r.scores), \
                     f"open={open_planes} hot={hot} planes={planes} q{i}"
-            assert st["n_cand_dcodes"] / max(st["n_candidates"], 1) > 128, st      # the lists really are longer than one window
+            # the lists really are longer than one window (n_cand_dcodes counts the candidates the filter saw: with no threshold
+            # set, those the zeroth level handed over)
+            assert st["n_cand_dcodes"] / max(st["n_level0"] or st["n_candidates"], 1) > 128, st
             assert 0 < st["n_survivors"] < st["n_candidates"]
             if hot:
                 assert 0 < st["n_level2"] < st["n_candidates"], (open_planes, hot, planes, st)   # the two-level filter really ran
@@ -814,3 +816,40 @@ def test_rerank_maxsim_matches_handler():
         npa.rerank_maxsim(q, [])
     with pytest.raises(npa.ShapeError):
         npa.rerank_maxsim(q, [np.zeros((2, 5), np.float32)])
+
+
+def test_unsorted_posting_lists_take_the_full_sweep():
+    """S3 bisects a posting list for a document range (and, round 6, the zeroth level reads its range's part through
+    a table built at open) only when every list of ivf.npy ascends -- what the crate writes (index.rs:479-504), not what a
+    third-party writer must.  An index whose lists are permuted (one reversed, one rotated) must be detected at open and served
+    by the full sweep: results equal the sorted index's bit for bit, and the zeroth level -- which needs ascending lists --
+    does not run."""
+    spec, a = make_arrays(num_docs=60000, num_centroids=1024, dim=64, nbits=4, doc_len_min=10, doc_len_max=40, seed=83)
+    qs, src = synth.make_queries(spec, 16, n_tokens=32, cen=a["centroids"])
+    b = dict(a)
+    ivf = a["ivf"].copy()
+    off = np.concatenate([[0], np.cumsum(a["ivf_lengths"].astype(np.int64))])
+    longest = np.argsort(-a["ivf_lengths"])[:40]
+    for j, c in enumerate(longest):   # the longest lists: every query probes some of them
+        s, e = int(off[c]), int(off[c + 1])
+        ivf[s:e] = ivf[s:e][::-1] if j % 2 == 0 else np.roll(ivf[s:e], 7)
+    b["ivf"] = ivf
+    hs, hu = hip_index(a), hip_index(b)
+    try:
+        for thr, nprobe in ((None, 8), (0.4, 32), (None, 32)):
+            p = P(n_full_scores=256, top_k=64, n_ivf_probe=nprobe, centroid_score_threshold=thr)
+            rs = hs.search_batch(qs, p)
+            st_s = dict(hs.last_stats)
+            ru = hu.search_batch(qs, p)
+            st_u = dict(hu.last_stats)
+            for i, (x, y) in enumerate(zip(rs, ru)):
+                assert np.array_equal(x.passage_ids, y.passage_ids) and np.array_equal(x.scores, y.scores), (thr, nprobe, i)
+            assert st_s["n_candidates"] == st_u["n_candidates"]
+            assert st_u["n_level0"] == 0                       # unsorted lists: no range table, no zeroth level
+            if thr is None:
+                assert st_s["n_level0"] > 0                    # ... which the sorted index does run
+        tr_s, tr_u = hs.debug_trace(qs[0], p), hu.debug_trace(qs[0], p)
+        assert np.array_equal(tr_s["cand"], tr_u["cand"]) and np.array_equal(tr_s["sel"], tr_u["sel"])
+    finally:
+        hs.close()
+        hu.close()
