@@ -478,8 +478,16 @@ def test_candidate_pool_rounds(mid):
     spec, a, ox, hx, qs, src = mid
     small = hip_index(a, workspace_bytes=11 << 20, max_batch=16)
     p = P(n_full_scores=512, top_k=10, n_ivf_probe=64, centroid_score_threshold=None)
+    # (round 6: with no threshold the zeroth filter level prunes the candidates BEFORE the pool is planned -- that is half its
+    # point: t_cs = None at nprobe 32 needed two rounds at 10 M documents, now one -- so the rounds are forced without it first)
+    gained = small.search_batch(qs[:16], p)
+    rounds_gained = small.last_stats["n_rounds"]
+    small.tune("s3_gain", 0)
     res = small.search_batch(qs[:16], p)
     assert small.last_stats["n_rounds"] >= 2, small.last_stats
+    assert rounds_gained <= small.last_stats["n_rounds"]
+    for r, g in zip(res, gained):
+        assert np.array_equal(r.passage_ids, g.passage_ids) and np.array_equal(r.scores, g.scores)
     ref = hx.search_batch(qs[:16], p)
     assert hx.last_stats["n_rounds"] == 1
     assert small.last_stats["n_candidates"] == hx.last_stats["n_candidates"]
