@@ -83,7 +83,7 @@ bool set_tuning(Tuning* t, const std::string& n, int value) {
   else if (n == "s4_warm") t->s4_warm = clamp(value, 0, 1000);
   else if (n == "ub_ncut") t->ub_ncut = clamp(value, 1, 512);
   else if (n == "s3_bisect") t->s3_bisect = clamp(value, 0, 1);
-  else if (n == "s3_gain") t->s3_gain = clamp(value, 0, 1);
+  else if (n == "s3_gain") t->s3_gain = clamp(value, 0, 2);
   else if (n == "s3_gain_mult") t->s3_gain_mult = clamp(value, 1, 16);
   else if (n == "s3_gain_direct") t->s3_gain_direct = clamp(value, 0, 64);
   else if (n == "s4_hot_auto") t->s4_hot_auto = clamp(value, 0, 0x7fffffff);

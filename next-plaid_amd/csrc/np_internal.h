@@ -126,8 +126,11 @@ struct Tuning {
   int s3_slices = 1;     // S3: document-bitmap ranges built in LDS (mark_slices_kernel) instead of atomicOr in memory
   int s3_gain = 1;       // zeroth filter level (gain_sweep_kernel): per-document sums of the probed cells' gains prune the candidates
                          // before any list block is read -- where no centroid_score_threshold is set (with one, the removed cells
-                         // lift the bound's floor above the cut: tools/sim/s3_gain_sim.py).  Read at OPEN too (0: the range table of
-                         // the posting lists is not built)
+                         // lift the bound's floor above the cut: tools/sim/s3_gain_sim.py).  0 off (read at OPEN too: the range
+                         // table of the posting lists is not built), 2 whenever it applies, 1 (default) = 2 with a run / skip policy:
+                         // the level costs ~2 ms per batch at 10 M documents whatever it prunes, so while the candidates it removed
+                         // in the handle's recent batches would not have cost the filter that much (K = 2^19: the bound's floor
+                         // reaches the cut, 85 % of the candidates stay) it is skipped for 31 batches and tried again
   int s3_gain_mult = 3;  // ... S0 = the s3_gain_mult x n_sel candidates with the largest bound take the exact bound first (tau0)
   int s3_gain_direct = 16;   // ... workgroups per query of that launch (0 = one query per XCD at a time, like the S2 list)
   int s4_filter = 1;     // u8 upper-bound filter ahead of the exact f32 approximate scores
@@ -220,6 +223,9 @@ struct DeviceIndex {
   int64_t ws_budget_open = 0;   // the budget at open: the live one grows back towards it when the device has headroom again
   bool ws_auto = false;
   Tuning tune;
+  // zeroth filter level, run / skip policy (s3_gain = 1): batches left to skip, and the parameters the count belongs to
+  mutable std::atomic<int> gain_skip{0};
+  mutable std::atomic<uint64_t> gain_key{0};
   CodeArr codes() const { return CodeArr{d_codes, code_wide}; }
   CodeArr ucodes() const { return CodeArr{d_ucodes, code_wide}; }
   size_t code_bytes() const { return code_wide ? 4 : 2; }

@@ -1832,7 +1832,9 @@ __global__ void __launch_bounds__(256) gain_thr_kernel(const uint32_t* __restric
 // not apply; the work counters
 __global__ void __launch_bounds__(64) gain_count_kernel(const uint32_t* __restrict__ cut, const int32_t* __restrict__ n_raw,
                                                         int32_t* __restrict__ n_out /* [B]: in = counted at the cut */, int B,
-                                                        Counters* ctr) {
+                                                        Counters* ctr,
+                                                        unsigned long long* __restrict__ h_report /* pinned host word: candidates << 32 |
+                                                            kept, for the host's run / skip policy (read a batch later, never waited for) */) {
   unsigned long long raw = 0, kept = 0;
   for (int b = threadIdx.x; b < B; b += 64) {
     if (cut[b] == 0u) n_out[b] = n_raw[b];
@@ -1847,6 +1849,7 @@ __global__ void __launch_bounds__(64) gain_count_kernel(const uint32_t* __restri
   if (threadIdx.x == 0) {
     atomicAdd(&ctr->n_candidates, raw);
     atomicAdd(&ctr->n_level0, kept);
+    if (h_report) *h_report = (min(raw, 0xFFFFFFFFull) << 32) | min(kept, 0xFFFFFFFFull);
   }
 }
 

@@ -22,6 +22,7 @@ struct Workspace {
       gain, gsmall, ghist, s0_meta, s0_u, gacc, gdeep;   // zeroth filter level (gain_sweep_kernel)
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
+  unsigned long long* h_gain = nullptr;   // pinned: the zeroth level's last (candidates << 32 | kept), written by the device
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
   bool done_valid = false;
   static constexpr int NBUF = 66;
@@ -33,6 +34,8 @@ struct Workspace {
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
     h_pin_cap = 0;
+    if (h_gain) (void)hipHostFree(h_gain);
+    h_gain = nullptr;
     if (done) (void)hipEventDestroy(done);
     done = nullptr;
   }
@@ -578,8 +581,34 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // before any list block is read.  Only where no centroid_score_threshold is set (the cells a threshold removes would lift
   // the bound's floor above the cut: tools/sim/s3_gain_sim.py), on ascending posting lists (range table built at open), with
   // the bit-plane first level behind it (it takes the candidate ids in any order) and without a subset.
-  const bool gain_path = two_level && use_planes && ix->d_ivf_split != nullptr && ix->tune.s3_gain && !prm.has_threshold &&
-                         subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0;
+  bool gain_path = two_level && use_planes && ix->d_ivf_split != nullptr && ix->tune.s3_gain && !prm.has_threshold &&
+                   subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0;
+  if (gain_path && ix->tune.s3_gain == 1) {
+    // Run / skip policy.  The level costs about the same whatever it prunes (one sweep of the probed lists to depth 32, the
+    // accumulators of every document written and read three times: ~0.2 us per 1000 documents and query), and what it buys is the
+    // filter's ~70 ns per candidate it removes.  The device leaves (candidates, kept) of each batch in a pinned word; a context
+    // reads the word of ITS previous batch here -- never waited for: a batch still in flight simply has not reported -- and when
+    // the removed candidates would not have paid for the level, the handle skips it for 31 batches and then tries again.
+    // Results do not depend on the decision.
+    const uint64_t key = ((uint64_t)(uint32_t)prm.n_ivf_probe << 40) ^ ((uint64_t)(uint32_t)cs->n_sel << 16) ^ (uint64_t)(uint32_t)LQP;
+    if (ix->gain_key.exchange(key, std::memory_order_relaxed) != key) ix->gain_skip.store(0, std::memory_order_relaxed);
+    if (w.h_gain) {
+      const unsigned long long v = __atomic_exchange_n(w.h_gain, 0ull, __ATOMIC_RELAXED);
+      const double raw = (double)(v >> 32), kept = (double)(v & 0xFFFFFFFFull);
+      const double benefit_ms = (raw - kept) * 70e-6;                                 // 70 ns of filter per removed candidate
+      const double cost_ms = 2.0 * ((double)ix->n_docs / 1e7) * ((double)B / 64.0);   // measured: 2.0-2.4 ms at 10 M documents x 64 queries
+      if (raw > 0 && benefit_ms < cost_ms) ix->gain_skip.store(31, std::memory_order_relaxed);
+    } else if (hipHostMalloc((void**)&w.h_gain, 64, hipHostMallocDefault) == hipSuccess) {
+      *w.h_gain = 0;
+    } else {
+      w.h_gain = nullptr;
+      (void)hipGetLastError();
+    }
+    if (ix->gain_skip.load(std::memory_order_relaxed) > 0) {
+      ix->gain_skip.fetch_sub(1, std::memory_order_relaxed);
+      gain_path = false;
+    }
+  }
   // the level probes on its own to depth 32 where the search stops earlier: the bound's floor falls with the depth (np_kernels.h)
   const int gain_depth = 32;
   const bool gain_deep = gain_path && prm.n_ivf_probe < gain_depth && ix->K > gain_depth;
@@ -923,7 +952,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     gp.n_emit = g_ndirect;
     gain_emit_kernel<0><<<egrid, 256, 0, st>>>(gp, 0);                                        // candidates at the cut, counted
     gp.n_emit = g_nemit;
-    gain_count_kernel<<<1, 64, 0, st>>>(g_cut0, g_nraw, g_ndirect, B, w.ctr.as<Counters>());
+    gain_count_kernel<<<1, 64, 0, st>>>(g_cut0, g_nraw, g_ndirect, B, w.ctr.as<Counters>(), ix->tune.s3_gain == 1 ? w.h_gain : nullptr);
     plan_rounds_kernel<<<1, 256, 0, st>>>(nullptr, 0, B, pool, max_rounds, rp, w.ctr.as<Counters>(), g_ndirect);
     gp.thr = g_cut0;
   }

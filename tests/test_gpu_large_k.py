@@ -194,6 +194,7 @@ def test_crate_natural_regime(big):
     name, spec, hx, ox, qs, src, cbs = big
     cen = synth.centroids(spec)
     q48, src48 = synth.make_queries(spec, 8, n_tokens=48, cen=cen, first_query=200)
+    hx.tune("s3_gain", 2)          # whenever it applies: the default (1) may skip it after batches it did not pay for
     for nfs in (4096, 8192):
         p = P(n_full_scores=nfs, top_k=10, n_ivf_probe=8, centroid_score_threshold=None, centroid_batch_size=cbs)
         trace_equal(hx, ox, qs[0], p, f"{name} crate-natural nfs={nfs} Lq=32")
@@ -213,4 +214,5 @@ def test_crate_natural_regime(big):
                     assert np.array_equal(g.passage_ids, o.passage_ids) and np.array_equal(g.scores, o.scores)
                 assert hx.last_stats["n_level0"] == 0
             finally:
-                hx.tune("s3_gain", 1)
+                hx.tune("s3_gain", 2)
+    hx.tune("s3_gain", 1)

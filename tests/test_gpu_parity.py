@@ -401,7 +401,7 @@ def test_zeroth_level_preserves_selection():
         n_union = hx.last_stats["n_candidates"]
         hx.tune("s4_filter", 1)
         for gain, mult, direct in ((0, 3, 16), (1, 3, 16), (1, 1, 0), (1, 8, 4)):
-            hx.tune("s3_gain", gain)
+            hx.tune("s3_gain", 2 * gain)   # 2 = whenever it applies (1 = with the run / skip policy)
             hx.tune("s3_gain_mult", mult)
             hx.tune("s3_gain_direct", direct)
             got = hx.search_batch(batch, p)
@@ -416,7 +416,7 @@ def test_zeroth_level_preserves_selection():
                 assert 0 < st["n_level0"] <= st["n_candidates"], st
                 pruned_somewhere |= st["n_level0"] < st["n_candidates"] // 2
     assert pruned_somewhere
-    hx.tune("s3_gain", 1)
+    hx.tune("s3_gain", 2)
     hx.tune("s3_gain_mult", 3)
     hx.tune("s3_gain_direct", 16)
     p = P(n_full_scores=256, top_k=64, n_ivf_probe=32, centroid_score_threshold=None)
@@ -843,6 +843,8 @@ def test_unsorted_posting_lists_take_the_full_sweep():
         ivf[s:e] = ivf[s:e][::-1] if j % 2 == 0 else np.roll(ivf[s:e], 7)
     b["ivf"] = ivf
     hs, hu = hip_index(a), hip_index(b)
+    hs.tune("s3_gain", 2)
+    hu.tune("s3_gain", 2)
     try:
         for thr, nprobe in ((None, 8), (0.4, 32), (None, 32)):
             p = P(n_full_scores=256, top_k=64, n_ivf_probe=nprobe, centroid_score_threshold=thr)
