@@ -586,7 +586,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   if (gain_path && ix->tune.s3_gain == 1) {
     // Run / skip policy.  The level costs about the same whatever it prunes (one sweep of the probed lists to depth 32, the
     // accumulators of every document written and read three times: ~0.2 us per 1000 documents and query), and what it buys is the
-    // filter's ~70 ns per candidate it removes.  The device leaves (candidates, kept) of each batch in a pinned word; a context
+    // filter's ~0.1 ns of GPU time per candidate it removes.  The device leaves (candidates, kept) of each batch in a pinned word; a context
     // reads the word of ITS previous batch here -- never waited for: a batch still in flight simply has not reported -- and when
     // the removed candidates would not have paid for the level, the handle skips it for 31 batches and then tries again.
     // Results do not depend on the decision.
@@ -595,7 +595,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     if (w.h_gain) {
       const unsigned long long v = __atomic_exchange_n(w.h_gain, 0ull, __ATOMIC_RELAXED);
       const double raw = (double)(v >> 32), kept = (double)(v & 0xFFFFFFFFull);
-      const double benefit_ms = (raw - kept) * 70e-6;                                 // 70 ns of filter per removed candidate
+      const double benefit_ms = (raw - kept) * 1e-7;                                  // the filter's ~0.06-0.2 ns of GPU time per candidate
+                                                                                      // (8 ms per 130 M at K = 2^16, 3.2 ms per 16 M at 2^19)
       const double cost_ms = 2.0 * ((double)ix->n_docs / 1e7) * ((double)B / 64.0);   // measured: 2.0-2.4 ms at 10 M documents x 64 queries
       if (raw > 0 && benefit_ms < cost_ms) ix->gain_skip.store(31, std::memory_order_relaxed);
     } else if (hipHostMalloc((void**)&w.h_gain, 64, hipHostMallocDefault) == hipSuccess) {
