@@ -1414,7 +1414,9 @@ __global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restric
   __syncthreads();
   tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   uint32_t sh = 0;
-  while ((tot >> sh) + (uint32_t)nc > 32767u) ++sh;   // sum of ceil(g / 2^sh) <= tot / 2^sh + nc; the accumulators hold twice that
+  // sum of ceil(g / 2^sh) <= tot / 2^sh + nc; the accumulators hold twice that.  (nc <= depth x query tokens <= 16384: the host
+  // runs the level only then -- with more cells than accumulator units no scaling could fit)
+  while (sh < 24u && (tot >> sh) + (uint32_t)nc > 32767u) ++sh;
   // stored: the scaled gain (< 2^15) | bit 15 = the search probes this cell itself (its documents are candidates)
   for (int i = tid; i < nc; i += 256) {
     const uint32_t c = cells[(int64_t)b * KP + i];

@@ -582,7 +582,9 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // the bound's floor above the cut: tools/sim/s3_gain_sim.py), on ascending posting lists (range table built at open), with
   // the bit-plane first level behind it (it takes the candidate ids in any order) and without a subset.
   bool gain_path = two_level && use_planes && ix->d_ivf_split != nullptr && ix->tune.s3_gain && !prm.has_threshold &&
-                   subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0;
+                   subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0 &&
+                   (int64_t)std::max(prm.n_ivf_probe, 32) * maxLq <= 16384;   // probed cells per query: the scaled gains of all of
+                                                                               // them must fit a 15-bit accumulator (gain_prep_kernel)
   if (gain_path && ix->tune.s3_gain == 1) {
     // Run / skip policy.  The level costs about the same whatever it prunes (one sweep of the probed lists to depth 32, the
     // accumulators of every document written and read three times: ~0.2 us per 1000 documents and query), and what it buys is the

@@ -177,3 +177,80 @@ def test_plane_levels_are_increasing_and_end_at_the_top():
             room = max(top, lam + 1) - lam
             if room >= PLANES:
                 assert all(a < b for a, b in zip(t, t[1:])), (lam, top, e, t)
+
+
+# ---- round 6: the zeroth level (np_kernels.h "S3, ZEROTH filter level": gain_prep_kernel / gain_sweep_kernel) -------------------------
+
+def probe(QC, nprobe):
+    """search.rs:388-414: per token the top-nprobe centroids; returns the marked cells and theta_q = the nprobe-th best score."""
+    Lq, K = QC.shape
+    marks = np.zeros(K, bool)
+    theta = np.zeros(Lq, np.float32)
+    for q in range(Lq):
+        top = np.argsort(-QC[q], kind="stable")[:nprobe]
+        marks[top] = True
+        theta[q] = QC[q, top].min()
+    return marks, theta
+
+
+def gain_bound(QC, s, docs, nprobe, depth, acc_bits=15):
+    """The level's arithmetic: ut_q = u(theta_q at the DEPTH), G(c) = sum_q max(0, u[q,c] - ut_q) for the cells marked at that
+    depth, scaled by 2^-sh (rounded up) so that the sum over all of them fits the accumulator; U0 = base + (sum of the document's
+    marked cells' scaled gains << sh).  Candidates = documents holding a cell the SEARCH probes (depth nprobe)."""
+    u = u8_table(QC, s)
+    real, _ = probe(QC, nprobe)
+    deep, theta = probe(QC, max(nprobe, depth))
+    ut = u8_table(theta[:, None], s)[:, 0]
+    G = np.maximum(u - ut[:, None], 0).sum(axis=0)               # [K]
+    cells = np.nonzero(deep)[0]
+    sh = 0
+    assert cells.size < (1 << acc_bits) - 1      # np_search.hip runs the level only while depth x query tokens stays far below 2^15
+    while (int(G[cells].sum()) >> sh) + cells.size > (1 << acc_bits) - 1:
+        sh += 1
+    Gs = np.where(deep, (G + (1 << sh) - 1) >> sh, 0)
+    base = int(ut.sum())
+    U0 = np.array([base + (int(Gs[c].sum()) << sh) for c in docs])
+    cand = np.array([bool(real[c].any()) for c in docs])
+    return U0, cand, base, sh, real, deep
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("nprobe,depth,acc_bits", [(4, 4, 15), (2, 8, 15), (8, 32, 15), (4, 16, 10)])
+def test_zeroth_level_bound_and_cut(seed, nprobe, depth, acc_bits):
+    """U0 >= U for every candidate, at the probe's own depth and deeper (bound-only cells), with the gains scaled into a narrow
+    accumulator; and the cut the pipeline makes with it -- tau0 = the n_sel-th largest LOWER bound among ANY set S0 of candidates
+    (the ones with the largest U0, a random set, a set missing the best documents) minus the slack, candidates with U0 below it
+    dropped -- never removes a document of the true top n_sel of the candidates (ties included)."""
+    rng = np.random.default_rng(7000 + seed)
+    Lq = int(rng.integers(1, 33))
+    QC, s, docs = make_instance(rng, K=256, n_docs=500, Lq=Lq, ties=(seed % 3 == 2), codes_per_doc=(1, 4) if seed % 2 else (3, 30))
+    U0, cand, base, sh, real, deep = gain_bound(QC, s, docs, nprobe, depth, acc_bits)
+    assert (deep | ~real).all() and cand.any()
+    if acc_bits == 10:
+        assert sh > 0, "the narrow accumulator was meant to force a scaling"
+    u = u8_table(QC, s)
+    U = np.array([u[:, c].max(axis=1).sum() for c in docs])
+    Lb = np.maximum(np.array([u[:, c].max(axis=1).sum() - clipped_charge(u[:, c].max(axis=1)) for c in docs]), 0)
+    approx = np.array([QC[:, c].max(axis=1).astype(np.float32).sum(dtype=np.float32) for c in docs])
+    assert (U0[cand] >= U[cand]).all(), "the gain sum must dominate the exact bound"
+    # a centroid outside the marks scores <= theta_q for every token: the premise of the bound
+    _, theta = probe(QC, max(nprobe, depth))
+    assert (QC[:, ~deep] <= theta[:, None] + 0).all()
+    slack = Lq + 2
+    ci = np.nonzero(cand)[0]
+    for n_sel in (1, 5, 40):
+        if ci.size <= n_sel:
+            continue
+        true_top = np.zeros(len(docs), bool)
+        true_top[ci] = approx[ci] >= nth_largest(approx[ci], n_sel)
+        order = ci[np.argsort(-U0[ci], kind="stable")]
+        for S0 in (order[:3 * n_sel], rng.permutation(ci)[:max(3 * n_sel, n_sel + 1)], order[n_sel // 2:n_sel // 2 + 2 * n_sel + 1]):
+            if S0.size < n_sel:
+                continue
+            tau0 = nth_largest(Lb[S0], n_sel) - slack
+            keep = cand & ((U0 >= tau0) | (tau0 <= 0))
+            assert (keep | ~true_top).all(), f"n_sel={n_sel}: the zeroth level cut a document of the true top"
+    # the level is not vacuous: with the best bounds as S0 something is dropped on the instances with real lists
+    if not seed % 2 and ci.size > 200 and depth >= 8:
+        tau0 = nth_largest(Lb[order[:15]], 5) - slack
+        assert (U0[ci] < tau0).any()
