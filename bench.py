@@ -484,6 +484,11 @@ def main():
     # ---- roofline of the dominant kernel (rank 0's shard) ------------------------------------------------------------------
     Lq, d = a.query_tokens, dim
     cand_tokens, exact_tokens = stages["n_cand_tokens"], stages["n_exact_tokens"]
+    lvl0 = stages.get("n_level0", 0)
+    if lvl0 and lvl0 < stages["n_candidates"]:
+        # the zeroth filter level ran: the hot level -- which counts the candidates' tokens -- saw only what it handed over; the
+        # contract's Tc is the token count of EVERY candidate (exact for fixed-length corpora, scaled by the counts otherwise)
+        cand_tokens = stages["n_candidates"] * a.doc_len if len_min == a.doc_len else cand_tokens * stages["n_candidates"] / lvl0
     per_stage = {
         # name: (ms, bound, algorithmic units per launch, unit, peak)
         # split-bf16 S1: three bf16 MFMAs per product, priced against the dense bf16 peak

@@ -31,7 +31,7 @@ try:
           "S3", round(s["ms_candidates"], 3), "S4", round(s["ms_approx"], 3), "S5", round(s["ms_select"], 3), "S6", round(s["ms_exact"], 3),
           "| parity", d.get("parity_vs_oracle"), "| cpu", (d.get("cpu_baseline") or {}).get("value"),
           "| roof", r["kernel"], r["frac"], "traffic", r["traffic"], "| B/tok", d.get("hbm_bytes_per_token"),
-          "| surv", s.get("n_survivors"), "codes", s.get("n_cand_codes"), "cand", s.get("n_candidates"))
+          "| surv", s.get("n_survivors"), "codes", s.get("n_cand_codes"), "cand", s.get("n_candidates"), "lvl0", s.get("n_level0"))
 except Exception as e:
     print(name, "FAILED", type(e).__name__, e)
 EOF
