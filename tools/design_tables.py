@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Installs the evidence of a final GPU call under profiles/ and regenerates the measured tables of DESIGN.md
-(between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r05_*.
+(between <!-- BEGIN:x --> / <!-- END:x --> markers) from profiles/r06_*.
 
-  design_tables.py install <gpurun_out tag> [--merge]   copy gpurun_out/<tag>/... to profiles/r05_* (names below); --merge keeps
+  design_tables.py install <gpurun_out tag> [--merge]   copy gpurun_out/<tag>/... to profiles/r06_* (names below); --merge keeps
                                                 the committed lines the call did not re-measure
-  design_tables.py                              regenerate the tables from profiles/r05_*
+  design_tables.py                              regenerate the tables from profiles/r06_*
 """
 import json
 import os
@@ -14,13 +14,13 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 P = os.path.join(ROOT, "profiles") + "/"
-R = "r05"
+R = "r06"
 
 GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
     f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "single_level_10m"],
     f"{R}_bench_regimes.jsonl": ["api_default", "tcs_none", "dist05", "dist08", "lq48_10m", "nfs8192_10m", "colgrep_10m", "k19_10m",
-                                 "k19_split_10m", "c3_np32", "c4_k18_12500k", "k20_2500k"],
+                                 "k19_split_10m", "k19_rest", "k19_rest_lq48_nfs8192", "c3_np32", "c4_k18_12500k", "k20_2500k"],
 }
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k",
            f"{R}_bench_disk_1m.json": "disk1m"}
@@ -74,7 +74,7 @@ def install(tag, merge=False):
         shutil.copy(os.path.join(src, "pmcd", "derived.txt"), P + f"{R}_pmc_derived_10m.txt")
     if not os.path.exists(os.path.join(src, "test_all.log")) or "-k" in open(os.path.join(src, "test_all.log")).read()[:0]:
         return
-    if " deselected" in open(os.path.join(src, "test_all.log")).read() and "189 passed" not in open(os.path.join(src, "test_all.log")).read() \
+    if " deselected" in open(os.path.join(src, "test_all.log")).read() and "passed" not in open(os.path.join(src, "test_all.log")).read() \
             and os.path.exists(P + f"{R}_test_gpu.log"):
         return   # a partial / superseded test run never replaces the full one
     with open(P + f"{R}_test_gpu.log", "w") as f:
@@ -122,8 +122,9 @@ def tables():
               f"{d1['index_build_s']:.2f} s (1 M); {d10['hbm_bytes_per_token']:.1f} B per token. CPU baseline (oracle C restatement, {cb10['cores']} threads, "
               f"{cb10['cpu_model']}): {cb10['value']:.1f} queries/s at 10 M, {cb1['value']:.1f} at 1 M. `roofline.traffic` (PMC, 10 M): "
               f"S4 {tr['approx(S4)']/1e9:.2f} GB, S6 {tr['exact(S6)']/1e9:.2f} GB, S3 {tr['candidates(S3)']/1e9:.2f} GB per batch.", "",
-          f"Round 4 → round 5: 10 M documents 18.9 k → {d10['value']/1e3:.1f} k queries/s (p50 3.89 → {d10['p50_batch_latency_ms']:.2f} ms, S4 2.35 → "
-          f"{s10['ms_approx']:.2f} ms); 1 M documents 38.8 k → {d1['value']/1e3:.1f} k queries/s (S4 0.73 → {s1['ms_approx']:.2f} ms).  "
+          f"Round 5 → round 6 (this path is untouched by the round's work, which went into the regimes without a threshold): 10 M documents 20.2 k → "
+          f"{d10['value']/1e3:.1f} k queries/s (p50 3.62 → {d10['p50_batch_latency_ms']:.2f} ms, S4 2.19 → "
+          f"{s10['ms_approx']:.2f} ms); 1 M documents 41.4 k → {d1['value']/1e3:.1f} k queries/s (S4 0.72 → {s1['ms_approx']:.2f} ms).  "
           f"The bench line's `roofline.frac` prices the contract's algorithmic bytes ({d10['roofline']['frac']:.2f} for S4); the bytes the stage "
           f"really moved (PMC, every kernel of the stage) give `roofline.frac_physical` = {d10['roofline'].get('frac_physical')}; the dominant kernel "
           f"alone (`approx_hotp_kernel`, {d10['roofline']['dominant_kernel']['ms_per_launch']:.3f} ms by its own HIP events): "
@@ -156,6 +157,8 @@ def tables():
             ("colgrep_10m", "**ColGREP's defaults together**: 48-token queries + `n_full_scores = 8192` + nprobe 8 (`colgrep/src/index/mod.rs:777-819`)"),
             ("k19_10m", "K = 2¹⁹ (the crate's k-means heuristic at this size, `kmeans.rs:303-309`): batched path, bit-exact S1-S5"),
             ("k19_split_10m", "K = 2¹⁹ with the opt-in split-bf16 S1 (`s1_split`, no mat-vec re-scoring)"),
+            ("k19_rest", "**the crate-natural regime**: K = 2¹⁹ (`kmeans.rs:303-309`) × `centroid_score_threshold = None` × `n_ivf_probe = 8` (`models.rs:271-284`): batched probe + mat-vec re-scoring + no threshold, bit-exact S1-S5"),
+            ("k19_rest_lq48_nfs8192", "the same with 48-token queries and `n_full_scores = 8192`"),
             ("c3_np32", "config 3 shape: 8 841 823 docs, clipped LogNormal lengths (mean 73, max 180), K = 2¹⁸, nbits 2, nprobe 32")]
     for k, lab in labs:
         d = reg.get(k)
