@@ -1356,9 +1356,8 @@ __global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restric
                                                         const uint32_t* __restrict__ cells, const int32_t* __restrict__ n_cells,
                                                         const uint32_t* __restrict__ tauq, int LQP, const float* __restrict__ qinv,
                                                         const int32_t* __restrict__ qoff, uint16_t* __restrict__ gain /* [B][KP] */,
-                                                        uint32_t* __restrict__ gbase /* [B][4]: base, shift, floor bin, 0 */, int B, int s0cap,
-                                                        RoundPlan rp0, const int64_t* __restrict__ ivf_off, int64_t floor_entries,
-                                                        int hshift, const uint32_t* __restrict__ real_bits /* [B][KP / 32] the cells the
+                                                        uint32_t* __restrict__ gbase /* [B][4]: base, shift, level shift r, b0 */, int B, int s0cap,
+                                                        RoundPlan rp0, int hshift, const uint32_t* __restrict__ real_bits /* [B][KP / 32] the cells the
                                                             search probes (S2's marks) when `cells` goes deeper; NULL: all of them */) {
   static_assert(RB == 32 || RB == 64, "rows of 32 or 64 query tokens");
   __shared__ uint32_t s_ut[RB];
@@ -1424,40 +1423,41 @@ __global__ void __launch_bounds__(256) gain_prep_kernel(const uint8_t* __restric
     gb[i] = (uint16_t)((((uint32_t)gb[i] + (1u << sh) - 1u) >> sh) | (real << 15));
   }
   __syncthreads();
-  // floor of the sweep's histogram: the largest (scaled) gain value gf with at least 2 x target posting entries in cells of
-  // gain >= gf -- the ~3 n_sel best bounds lie above base + gf unless the lists overlap heavily (then S0 is simply smaller)
-  __shared__ uint32_t s_gh[256];
+  // LEVELS.  Everything behind the sweep works on 8-bit levels of the bound instead of its 2048 histogram bins:
+  //     level(U0) = 1 + min(254, ((U0 >> hshift) - b0) >> r),   b0 = base >> hshift   (0 = not a candidate)
+  // monotone in U0, so "level >= level(cut)" keeps a superset of "bin >= cut" -- what a cut on an upper bound tolerates -- and the
+  // documents' levels are ONE byte each in memory (the emission passes stream them) and 256 counters in the sweep.  r spreads
+  // four times the largest single cell's gain over the 254 levels (a document in a handful of strong cells still resolves;
+  // beyond that the level saturates: such documents are always kept).
   __shared__ uint32_t s_gmax;
-  s_gh[tid] = 0;
   if (tid == 0) s_gmax = 0;
   __syncthreads();
   uint32_t gm = 0;
   for (int i = tid; i < nc; i += 256) gm = max(gm, (uint32_t)gb[i] & 0x7FFFu);
   if (gm) atomicMax(&s_gmax, gm);
   __syncthreads();
-  int gshift = 0;
-  while ((s_gmax >> gshift) > 255u) ++gshift;
-  for (int i = tid; i < nc; i += 256) {
-    const uint32_t c = cells[(int64_t)b * KP + i];
-    if (gb[i] & 0x8000u)   // candidates come from the cells the search probes
-      atomicAdd(&s_gh[((uint32_t)gb[i] & 0x7FFFu) >> gshift], (uint32_t)min<int64_t>(ivf_off[c + 1] - ivf_off[c], 0x3FFFFFFF));
-  }
-  __syncthreads();
   if (tid == 0) {
     uint32_t base = 0;
     for (int q = 0; q < RB; ++q) base += s_ut[q];
-    unsigned long long cum = 0;
-    int bin = 255;
-    for (; bin > 0; --bin) {
-      cum += s_gh[bin];
-      if (cum >= (unsigned long long)floor_entries) break;
-    }
-    const uint32_t gf = (uint32_t)bin << gshift;     // lower edge of that bin (bin 0: count every candidate)
+    const uint32_t span = ((4u * s_gmax) << sh) >> hshift;
+    uint32_t r = 0;
+    while (r < 11u && (span >> r) > 254u) ++r;
     gbase[4 * b] = base;
     gbase[4 * b + 1] = sh;
-    gbase[4 * b + 2] = bin > 0 ? min((base + (gf << sh)) >> hshift, (uint32_t)(NP_UB_BINS - 1)) : 0u;
-    gbase[4 * b + 3] = 0;
+    gbase[4 * b + 2] = r;
+    gbase[4 * b + 3] = base >> hshift;
   }
+}
+
+// level of a document's accumulator (bit 0 = candidate, bits 1.. = the scaled gain sum); 0 = not a candidate
+__device__ __forceinline__ uint32_t gain_level(uint32_t a, uint32_t base, uint32_t sh, uint32_t r, uint32_t b0, int hshift) {
+  if (!(a & 1u)) return 0u;
+  const uint32_t bin = min((base + ((a >> 1) << sh)) >> hshift, (uint32_t)(NP_UB_BINS - 1));
+  return 1u + min(254u, (bin - b0) >> r);
+}
+// the level a histogram-bin threshold maps to (monotone: level(bin(doc)) >= level_of_bin(t) for every doc with bin >= t)
+__device__ __forceinline__ uint32_t gain_level_of_bin(uint32_t t, uint32_t r, uint32_t b0) {
+  return t <= b0 ? 1u : 1u + min(254u, (t - b0) >> r);
 }
 
 struct GainP {
@@ -1469,12 +1469,12 @@ struct GainP {
   const uint32_t* split;      // [K][R1]: split[c * R1 + r] = entries of list c with id < r * NP_GAIN_RANGE
   int R1;
   const uint16_t* gain;       // [B][KP] by cell position
-  const uint32_t* gbase;      // [B][4]: base, shift, floor bin of the sweep's histogram, 0
+  const uint32_t* gbase;      // [B][4]: base, gain shift, level shift r, b0 = base >> hshift
   int hshift;
   int64_t n_docs;
-  uint32_t* hist0;            // [B][NP_UB_BINS] (mode 0)
+  uint32_t* hist0;            // [B][256] documents per level (sweep)
   int32_t* n_raw;             // [B] candidates (mode 0)
-  const uint32_t* thr;        // [B] mode 1: bin threshold of S0 (0 = no S0); mode 2: bin of the cut (0 = keep every candidate)
+  const uint32_t* thr;        // [B] mode 1: LEVEL threshold of S0 (0 = no S0); mode 2: level of the cut (<= 1: keep every candidate)
   uint4* s0_meta;             // mode 1: [B][s0cap] records
   int32_t* n_s0;              // [B] zeroed
   int s0cap;
@@ -1485,28 +1485,29 @@ struct GainP {
   int32_t* n_emit;            // [B] zeroed: mode 1 slots handed out above the marginal bin; mode 2 (zeroed again) candidates emitted
   int32_t* n_marg;            // [B] zeroed: mode 1 slots handed out to the marginal bin
   const int32_t* n_hi;        // [B] documents above the marginal bin of S0 (gain_thr_kernel)
-  uint16_t* acc;              // [B][n_ranges * NP_GAIN_RANGE] the documents' accumulators (sweep -> emission passes)
+  uint8_t* lvl;               // [B][n_ranges * NP_GAIN_RANGE] the documents' levels, 0 = not a candidate (sweep -> emission passes)
   int n_ranges;
   RoundPlan rp;
   Counters* ctr;
 };
 
-// Sweep: block (range r, query b) scatter-adds the gains of the probed cells over its 32768 documents in LDS, counts the
-// candidates, adds the bounds of the BEST ones to the query's histogram and writes the accumulators out (acc[b][doc], u16,
-// coalesced): the passes below (count, S0, candidates) are streaming reads of that array instead of further sweeps of the
-// posting lists (measured, REST default regime at 10 M documents: 0.83 ms per sweep against ~0.15 ms per streaming pass).
+// Sweep: block (range r, query b) scatter-adds the gains of the probed cells over its 32768 documents in LDS, then turns every
+// accumulator into its 8-bit level, counts the levels into the query's 256-bin histogram and writes the levels out
+// (lvl[b][doc], one byte per document, coalesced): the passes below (S0, candidates) are streaming reads of that array instead
+// of further sweeps of the posting lists (measured, REST default regime at 10 M documents: 0.83 ms per sweep against ~0.15 ms
+// per streaming pass), and the histogram gives the round plan the exact number of candidates at any cut.
 // A wave works through TASKS of 16 probed cells with no block-wide barrier in between: the 16 cells' parts of their posting
 // lists (~34 entries each at K = 2^16) are 16 loads in flight per lane, and the metadata of the wave's next task (cell id ->
 // range table, list offset, gain: two dependent round trips) travels during the current one.  (First version: per pass of 256
 // cells a prefix sum of 32-entry items and three barriers, four items in flight per half-wave -- one memory round trip per
 // 128 items and ~5 us of barriers and dependent loads per pass: 2.4 ms per batch at t_cs = None, nprobe 32.)
-// Only bounds at or above the query's floor bin enter the histogram (gain_prep_kernel: the bin below which at least twice the S0
-// target of posting entries lie above): the histogram exists to find the ~3 n_sel best bounds, and counting EVERY candidate
-// made 64 lanes hit the two or three bins of the low-gain cells at once (same-address LDS atomics serialise).
+// Levels 1 and 2 -- the documents of ONE weak cell, the bulk of the candidates -- are counted in registers: 64 lanes adding to
+// the same two LDS counters at once serialise (a complete 2048-bin histogram of every candidate cost the sweep ~10 us per
+// block).
 #define NP_GAIN_TASK 16
 __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_acc[];   // NP_GAIN_RANGE / 2 words: two u16 accumulators each
-  __shared__ uint32_t s_hist[NP_UB_BINS];
+  __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_wsum[16];
   const int b = blockIdx.y, r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = p.n_cells[b];
@@ -1514,7 +1515,7 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
   {
     uint4* a4 = reinterpret_cast<uint4*>(s_acc);
     for (int i = tid; i < NP_GAIN_RANGE / 8; i += 1024) a4[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = tid; i < NP_UB_BINS; i += 1024) s_hist[i] = 0;
+    if (tid < 256) s_hist[tid] = 0;
   }
   __syncthreads();
   const uint32_t* cellb = p.cells + (int64_t)b * p.KP;
@@ -1591,43 +1592,55 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
     t0 += STEP;
   }
   __syncthreads();
-  // ---- scan: candidate count, histogram of the best bounds, accumulators out
-  const uint32_t base = p.gbase[4 * b], sh = p.gbase[4 * b + 1], floorbin = p.gbase[4 * b + 2];
-  uint32_t cnt = 0;
+  // ---- scan: levels out, their histogram, candidate count
+  const uint32_t base = p.gbase[4 * b], sh = p.gbase[4 * b + 1], lr = p.gbase[4 * b + 2], b0 = p.gbase[4 * b + 3];
+  uint32_t c1 = 0, c2 = 0, cnt = 0;
   {
-    // thread t takes the 16-byte pieces t, t + 1024, ... of the range (8 documents each): conflict-free LDS reads, coalesced stores
+    // thread t takes the 16-byte pieces t, t + 1024, ... of the range (8 documents each): conflict-free LDS reads, coalesced
+    // 8-byte stores
     const uint4* a4 = reinterpret_cast<const uint4*>(s_acc) + tid;
-    uint4* out = reinterpret_cast<uint4*>(p.acc + ((int64_t)b * p.n_ranges + r) * NP_GAIN_RANGE) + tid;
+    uint2* out = reinterpret_cast<uint2*>(p.lvl + ((int64_t)b * p.n_ranges + r) * NP_GAIN_RANGE) + tid;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint4 vv = a4[k * 1024];
-      out[k * 1024] = vv;
       const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+      uint32_t o[2] = {0u, 0u};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const uint32_t a = (w4[e] >> (16 * h)) & 0xFFFFu;
-          if (a & 1u) {
+          const uint32_t l = gain_level((w4[e] >> (16 * h)) & 0xFFFFu, base, sh, lr, b0, p.hshift);
+          o[e >> 1] |= l << (8 * (2 * (e & 1) + h));
+          if (l) {
             ++cnt;
-            const uint32_t bin = min((base + ((a >> 1) << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
-            if (bin >= floorbin) atomicAdd(&s_hist[bin], 1u);
+            if (l == 1u) ++c1;
+            else if (l == 2u) ++c2;
+            else atomicAdd(&s_hist[l], 1u);
           }
         }
+      out[k * 1024] = make_uint2(o[0], o[1]);
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
-  if (lane == 0) s_wsum[wave] = cnt;
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += (uint32_t)__shfl_xor((int)cnt, o);
+    c1 += (uint32_t)__shfl_xor((int)c1, o);
+    c2 += (uint32_t)__shfl_xor((int)c2, o);
+  }
+  if (lane == 0) {
+    s_wsum[wave] = cnt;
+    if (c1) atomicAdd(&s_hist[1], c1);
+    if (c2) atomicAdd(&s_hist[2], c2);
+  }
   __syncthreads();
   if (tid == 0) {
     uint32_t tot = 0;
     for (int k = 0; k < 16; ++k) tot += s_wsum[k];
     if (tot) atomicAdd(&p.n_raw[b], (int32_t)tot);
   }
-  for (int i = tid; i < NP_UB_BINS; i += 1024) {
-    const uint32_t v = s_hist[i];
-    if (v) atomicAdd(&p.hist0[(int64_t)b * NP_UB_BINS + i], v);
+  if (tid < 256) {
+    const uint32_t v = s_hist[tid];
+    if (v) atomicAdd(&p.hist0[(int64_t)b * 256 + tid], v);
   }
   if (r == 0) {
 #pragma unroll
@@ -1636,77 +1649,59 @@ __global__ void __launch_bounds__(1024) gain_sweep_kernel(GainP p) {
   }
 }
 
-// Emission passes over the stored accumulators: block (range of 32768 documents, query b).
-//   MODE 0  count: documents with bin >= thr[b] -> n_emit[b] (the round plan needs the exact number; thr[b] = 0: nothing to do, the
-//           query keeps every candidate and gain_count_kernel takes n_raw)
-//   MODE 1  S0: the documents whose bin lies ABOVE thr[b] fill slots [0, n_hi[b]) of the query's record slice, the documents of
-//           the marginal bin thr[b] fill the slots behind them as far as the slice goes (any subset of the candidates is a valid
-//           S0; gain_thr_kernel has set n_s0[b] = min(cap, #bin >= thr)).  Records are built from the list blocks' headers.
-//   MODE 2  candidates: bin >= thr[b] (every candidate when thr[b] = 0), bare ids, ascending inside a range, the ranges in any
+// Emission passes over the stored levels: block (range of 32768 documents, query b).
+//   MODE 1  S0: the documents whose level lies ABOVE thr[b] fill slots [0, n_hi[b]) of the query's record slice, the documents of
+//           the marginal level thr[b] fill the slots behind them as far as the slice goes (any subset of the candidates is a valid
+//           S0; gain_thr_kernel has set n_s0[b] = min(cap, #level >= thr)).  Records are built from the list blocks' headers.
+//   MODE 2  candidates: level >= thr[b] (every candidate when thr[b] <= 1), bare ids, ascending inside a range, the ranges in any
 //           order (the hot level takes a claim's block offsets from its smallest id).
 template <int MODE>
 __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
-  // one block per (range of 32768 documents, query): thread t takes the 16-byte pieces t, t + 256, ... (8 documents each, 16
-  // pieces: every load of a step is one contiguous 4 KB, all 16 in flight), ONE slot reservation per block (the counters of
-  // a batch's queries share two cache lines: a reservation per 8192 documents serialised 78 k atomics on them)
-  constexpr int NP4 = NP_GAIN_RANGE / 8 / 256;   // pieces per thread
+  // thread t takes the 16-byte pieces t, t + 256, ... (16 documents each, 8 pieces: every load of a step is one contiguous 4 KB,
+  // all 8 in flight), ONE slot reservation per block (the counters of a batch's queries share two cache lines: a reservation per
+  // 8192 documents serialised 78 k atomics on them)
+  constexpr int NPC = NP_GAIN_RANGE / 16 / 256;   // pieces per thread: 8
   __shared__ uint32_t s_out[2];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (MODE == 2 && p.rp.round_of[b] != round) return;
   const uint32_t thr = p.thr[b];
-  if (MODE <= 1 && thr == 0u) return;
+  if (MODE == 1 && thr == 0u) return;
   const int64_t d_block = (int64_t)blockIdx.x * NP_GAIN_RANGE;
-  const uint32_t base = p.gbase[4 * b], sh = p.gbase[4 * b + 1];
-  uint32_t keep[NP4 / 4], marg[NP4 / 4];   // bit 8 (i & 3) + j of word i >> 2: document j of piece i
+  uint32_t keep[NPC / 2], marg[NPC / 2];   // bit 16 (i & 1) + j of word i >> 1: document j of piece i
 #pragma unroll
-  for (int w = 0; w < NP4 / 4; ++w) keep[w] = marg[w] = 0;
+  for (int w = 0; w < NPC / 2; ++w) keep[w] = marg[w] = 0;
   {
-    const uint4* a4 = reinterpret_cast<const uint4*>(p.acc + (int64_t)b * p.n_ranges * NP_GAIN_RANGE + d_block) + tid;
-    uint4 vv[NP4];
+    const uint4* a4 = reinterpret_cast<const uint4*>(p.lvl + (int64_t)b * p.n_ranges * NP_GAIN_RANGE + d_block) + tid;
+    uint4 vv[NPC];
 #pragma unroll
-    for (int i = 0; i < NP4; ++i) vv[i] = a4[i * 256];
+    for (int i = 0; i < NPC; ++i) vv[i] = a4[i * 256];
 #pragma unroll
-    for (int i = 0; i < NP4; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       const uint32_t w4[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t a = (w4[e] >> (16 * h)) & 0xFFFFu;
-          if (a & 1u) {
-            const uint32_t bin = min((base + ((a >> 1) << sh)) >> p.hshift, (uint32_t)(NP_UB_BINS - 1));
-            const uint32_t bit = 1u << (8 * (i & 3) + 2 * e + h);
-            if (thr == 0u || bin >= thr) keep[i >> 2] |= bit;
-            if (MODE == 1 && bin == thr) marg[i >> 2] |= bit;
-          }
+        for (int h = 0; h < 4; ++h) {
+          const uint32_t l = (w4[e] >> (8 * h)) & 0xFFu;
+          const uint32_t bit = 1u << (16 * (i & 1) + 4 * e + h);
+          if (l != 0u && l >= thr) keep[i >> 1] |= bit;
+          if (MODE == 1 && l == thr) marg[i >> 1] |= bit;
         }
     }
   }
-  if constexpr (MODE == 0) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int w = 0; w < NP4 / 4; ++w) c += (uint32_t)__popc(keep[w]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
-    __shared__ uint32_t s_cw[4];
-    if (lane == 0) s_cw[wave] = c;
-    __syncthreads();
-    if (tid == 0 && s_cw[0] + s_cw[1] + s_cw[2] + s_cw[3]) atomicAdd(&p.n_emit[b], (int32_t)(s_cw[0] + s_cw[1] + s_cw[2] + s_cw[3]));
-    return;
-  }
   // Slots in ASCENDING document order (piece-major: piece i * 256 + t): the hot level stages a claim's 32 list blocks together,
   // and ids scattered over the whole range cost it DRAM locality (measured: 4.09 vs 3.36 ms per batch in the REST default regime
-  // with a thread-major order).  Per piece row i an exclusive scan over the 256 threads of (kept above the marginal bin | marginal
-  // ones << 16) -- at most 2048 each -- then the rows' totals.
-  __shared__ __attribute__((aligned(16))) uint32_t s_c[NP4][256];
-  __shared__ uint32_t s_row[NP4];
+  // with a thread-major order).  Per piece row i an exclusive scan over the 256 threads of (kept above the marginal level |
+  // marginal ones << 16) -- at most 4096 each -- then the rows' totals.
+  __shared__ __attribute__((aligned(16))) uint32_t s_c[NPC][256];
+  __shared__ uint32_t s_row[NPC];
 #pragma unroll
-  for (int i = 0; i < NP4; ++i) {
-    const uint32_t k8 = (keep[i >> 2] >> (8 * (i & 3))) & 0xFFu, m8 = (marg[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-    s_c[i][tid] = (uint32_t)__popc(k8 & ~m8) | ((uint32_t)__popc(m8) << 16);
+  for (int i = 0; i < NPC; ++i) {
+    const uint32_t k16 = (keep[i >> 1] >> (16 * (i & 1))) & 0xFFFFu, m16 = (marg[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+    s_c[i][tid] = (uint32_t)__popc(k16 & ~m16) | ((uint32_t)__popc(m16) << 16);
   }
   __syncthreads();
-  for (int i = wave; i < NP4; i += 4) {
+  for (int i = wave; i < NPC; i += 4) {
     const uint4 c4 = *reinterpret_cast<const uint4*>(&s_c[i][4 * lane]);
     const uint32_t mine = c4.x + c4.y + c4.z + c4.w;
     uint32_t incl = mine;
@@ -1720,14 +1715,14 @@ __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
     if (lane == 63) s_row[i] = incl;
   }
   __syncthreads();
-  uint32_t rowbase[NP4], tot = 0;
+  uint32_t rowbase[NPC], tot_hi = 0, tot_m = 0;   // (kept separately: a range holds up to 32768 of either, beyond a 16-bit field)
 #pragma unroll
-  for (int i = 0; i < NP4; ++i) {
-    rowbase[i] = tot;
-    tot += s_row[i];
+  for (int i = 0; i < NPC; ++i) {
+    rowbase[i] = tot_hi | (tot_m << 16);   // < 32768 each while i < NPC
+    tot_hi += s_row[i] & 0xFFFFu;
+    tot_m += s_row[i] >> 16;
   }
-  const uint32_t tot_hi = tot & 0xFFFFu, tot_m = tot >> 16;
-  if (tot == 0) return;   // block-uniform
+  if (tot_hi + tot_m == 0) return;   // block-uniform
   if (tid == 0) {
     s_out[0] = tot_hi ? (uint32_t)atomicAdd(&p.n_emit[b], (int32_t)tot_hi) : 0u;
     if constexpr (MODE == 1) s_out[1] = tot_m ? (uint32_t)p.n_hi[b] + (uint32_t)atomicAdd(&p.n_marg[b], (int32_t)tot_m) : 0u;
@@ -1737,15 +1732,15 @@ __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
     const int cb = p.code_wide ? 4 : 2, hdr = 16 / cb, fit = p.ublock_stride - hdr;
     uint4* out = p.s0_meta + (int64_t)b * p.s0cap;
 #pragma unroll
-    for (int i = 0; i < NP4; ++i) {
-      const uint32_t at0 = rowbase[i] + s_c[i][tid];
-      uint32_t pos = s_out[0] + (at0 & 0xFFFFu), posm = s_out[1] + (at0 >> 16);
-      uint32_t m = (keep[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-      const uint32_t mg = (marg[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    for (int i = 0; i < NPC; ++i) {
+      const uint32_t pre = s_c[i][tid];
+      uint32_t pos = s_out[0] + (rowbase[i] & 0xFFFFu) + (pre & 0xFFFFu), posm = s_out[1] + (rowbase[i] >> 16) + (pre >> 16);
+      uint32_t m = (keep[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+      const uint32_t mg = (marg[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
       while (m) {
         const int j = __ffs((int)m) - 1;
         m &= m - 1;
-        const uint32_t d = (uint32_t)d_block + (uint32_t)((i * 256 + tid) * 8 + j);
+        const uint32_t d = (uint32_t)d_block + (uint32_t)((i * 256 + tid) * 16 + j);
         const uint32_t at = ((mg >> j) & 1u) ? posm++ : pos++;
         if (at < (uint32_t)p.s0cap) {
           const uint4 hd = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.ucodes) + (int64_t)d * p.ublock_stride * cb);
@@ -1758,100 +1753,106 @@ __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
     uint32_t* out = p.cand + p.rp.cand_base[b];
     const uint32_t limit = (uint32_t)p.rp.n_cand[b];
 #pragma unroll
-    for (int i = 0; i < NP4; ++i) {
-      uint32_t pos = s_out[0] + ((rowbase[i] + s_c[i][tid]) & 0xFFFFu);
-      uint32_t m = (keep[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    for (int i = 0; i < NPC; ++i) {
+      uint32_t pos = s_out[0] + (rowbase[i] & 0xFFFFu) + (s_c[i][tid] & 0xFFFFu);
+      uint32_t m = (keep[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
       while (m) {
         const int j = __ffs((int)m) - 1;
         m &= m - 1;
-        if (pos < limit) out[pos] = (uint32_t)d_block + (uint32_t)((i * 256 + tid) * 8 + j);
+        if (pos < limit) out[pos] = (uint32_t)d_block + (uint32_t)((i * 256 + tid) * 16 + j);
         ++pos;
       }
     }
   }
 }
 
-// S0 = the ~target documents with the largest U0: thr[b] = the histogram bin in which the count from the top reaches the target
-// (0 = no S0: flagged query, fewer candidates than the target, or a cut that would reach bin 0); n_hi[b] = documents in the
-// bins above it (all taken), n_s0[b] = min(cap, documents in bins >= thr): the marginal bin fills what is left of the slice
-__global__ void __launch_bounds__(256) gain_thr_kernel(const uint32_t* __restrict__ hist, int target, int n_sel, int cap,
-                                                       const uint32_t* __restrict__ gbase, const int32_t* __restrict__ n_raw,
-                                                       const uint32_t* __restrict__ qflag,
-                                                       uint32_t* __restrict__ thr, int32_t* __restrict__ n_hi,
-                                                       int32_t* __restrict__ n_s0) {
-  __shared__ uint32_t s_part[256];
-  constexpr int BPT = NP_UB_BINS / 256;
-  const int b = blockIdx.x, tid = threadIdx.x;
+// S0 = the ~target documents with the largest U0: thr[b] = the LEVEL at which the count from the top reaches the target (0 = no
+// S0: flagged query, or fewer candidates than the target); n_hi[b] = documents above it (all taken), n_s0[b] = min(cap, documents
+// at levels >= thr): the marginal level fills what is left of the slice.  One wave per query.
+__global__ void __launch_bounds__(64) gain_thr_kernel(const uint32_t* __restrict__ hist /* [B][256] */, int target, int cap,
+                                                      const int32_t* __restrict__ n_raw, const uint32_t* __restrict__ qflag,
+                                                      uint32_t* __restrict__ thr, int32_t* __restrict__ n_hi,
+                                                      int32_t* __restrict__ n_s0) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (qflag[b] != 0 || n_raw[b] <= target) {
-    if (tid == 0) {
+    if (lane == 0) {
       thr[b] = 0;
       n_hi[b] = 0;
       n_s0[b] = 0;
     }
     return;
   }
-  const uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
-  const int top = (255 - tid) * BPT;
-  uint32_t mine = 0;
+  // lane l owns levels 255 - 4 l .. 252 - 4 l (descending); suffix counts by a wave scan
+  const uint32_t* hb = hist + (int64_t)b * 256;
+  uint32_t h4[4], mine = 0;
 #pragma unroll
-  for (int k = 0; k < BPT; ++k) mine += hb[top + k];
-  s_part[tid] = mine;
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t cum = 0;
-    int t = 0;
-    for (; t < 255; ++t) {
-      if (cum + s_part[t] >= (uint32_t)target) break;
-      cum += s_part[t];
-    }
-    int bin = (255 - t) * BPT + BPT - 1;
-    for (; bin > (255 - t) * BPT; --bin) {
-      if (cum + hb[bin] >= (uint32_t)target) break;
-      cum += hb[bin];
-    }
-    // cum = documents above `bin` (< target <= cap).  The sweep counted only bins >= the query's floor bin: a target not reached
-    // there makes the floor bin the marginal one (any n_sel documents give a valid threshold)
-    const int fb = (int)gbase[4 * b + 2];
-    if (bin < fb) {
-      uint32_t above = 0;
-      for (int k = NP_UB_BINS - 1; k > fb; --k) above += hb[k];
-      bin = (above + hb[fb] >= (uint32_t)n_sel) ? fb : 0;
-      cum = above;
-    }
-    if (bin <= 0) {
+  for (int k = 0; k < 4; ++k) {
+    h4[k] = hb[255 - 4 * lane - k];
+    mine += h4[k];
+  }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= o) incl += v;
+  }
+  const unsigned long long reach = __ballot(incl >= (uint32_t)target);
+  if (reach == 0ull) {   // cannot happen (n_raw > target and every candidate has a level >= 1): no S0
+    if (lane == 0) {
       thr[b] = 0;
       n_hi[b] = 0;
       n_s0[b] = 0;
-    } else {
-      thr[b] = (uint32_t)bin;
-      n_hi[b] = (int32_t)cum;
-      n_s0[b] = (int32_t)min(cum + hb[bin], (uint32_t)cap);
     }
+    return;
+  }
+  const int first = __ffsll((long long)reach) - 1;
+  if (lane == first) {
+    uint32_t cum = incl - mine;
+    int k = 0;
+    for (; k < 3; ++k) {
+      if (cum + h4[k] >= (uint32_t)target) break;
+      cum += h4[k];
+    }
+    const int level = 255 - 4 * lane - k;
+    thr[b] = (uint32_t)max(level, 1);
+    n_hi[b] = (int32_t)cum;                                        // < target <= cap
+    n_s0[b] = (int32_t)min(cum + h4[k], (uint32_t)cap);
   }
 }
 
-// candidates of query b after the zeroth level: what the count pass found at the cut, or every candidate where the level does
-// not apply; the work counters
-__global__ void __launch_bounds__(64) gain_count_kernel(const uint32_t* __restrict__ cut, const int32_t* __restrict__ n_raw,
-                                                        int32_t* __restrict__ n_out /* [B]: in = counted at the cut */, int B,
-                                                        Counters* ctr,
+// The cut in levels and the candidates it keeps: lcut[b] = level of the histogram-bin threshold tau0 - slack (ub_thr_kernel on
+// S0's exact lower bounds; 0 there = the level does not apply: every candidate stays), n_out[b] = documents at levels >= lcut
+// (the sweep's histogram is complete); the work counters and the host's report.  One wave per query, then block 0's lane 0.
+__global__ void __launch_bounds__(64) gain_count_kernel(const uint32_t* __restrict__ cut_bin, const uint32_t* __restrict__ hist,
+                                                        const uint32_t* __restrict__ gbase, const int32_t* __restrict__ n_raw,
+                                                        uint32_t* __restrict__ lcut, int32_t* __restrict__ n_out, Counters* ctr,
                                                         unsigned long long* __restrict__ h_report /* pinned host word: candidates << 32 |
-                                                            kept, for the host's run / skip policy (read a batch later, never waited for) */) {
-  unsigned long long raw = 0, kept = 0;
-  for (int b = threadIdx.x; b < B; b += 64) {
-    if (cut[b] == 0u) n_out[b] = n_raw[b];
-    raw += (unsigned long long)n_raw[b];
-    kept += (unsigned long long)n_out[b];
-  }
+                                                            kept, accumulated over the batch's queries, for the host's run / skip
+                                                            policy (read a batch later, never waited for) */,
+                                                        unsigned long long* __restrict__ d_report /* [2] zeroed: the batch's sums */,
+                                                        int B) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t cb = cut_bin[b];
+  uint32_t n = (uint32_t)n_raw[b], lc = 1u;
+  if (cb) {
+    lc = gain_level_of_bin(cb, gbase[4 * b + 2], gbase[4 * b + 3]);
+    uint32_t c = 0;
+    for (int l = lane; l < 256; l += 64) c += (uint32_t)l >= lc ? hist[(int64_t)b * 256 + l] : 0u;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    raw += __shfl_xor(raw, o);
-    kept += __shfl_xor(kept, o);
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    n = c;
   }
-  if (threadIdx.x == 0) {
-    atomicAdd(&ctr->n_candidates, raw);
-    atomicAdd(&ctr->n_level0, kept);
-    if (h_report) *h_report = (min(raw, 0xFFFFFFFFull) << 32) | min(kept, 0xFFFFFFFFull);
+  if (lane == 0) {
+    lcut[b] = lc;
+    n_out[b] = (int32_t)n;
+    atomicAdd(&ctr->n_candidates, (unsigned long long)n_raw[b]);
+    atomicAdd(&ctr->n_level0, (unsigned long long)n);
+    const unsigned long long raw = atomicAdd(&d_report[0], (unsigned long long)n_raw[b]) + (unsigned long long)n_raw[b];
+    (void)raw;
+    atomicAdd(&d_report[1], (unsigned long long)n);
+    __threadfence();
+    if (atomicAdd(&d_report[2], 1ull) + 1ull == (unsigned long long)B && h_report)   // the last query of the batch reports
+      *h_report = (min(d_report[0], 0xFFFFFFFFull) << 32) | min(d_report[1], 0xFFFFFFFFull);
   }
 }
 

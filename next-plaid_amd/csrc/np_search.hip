@@ -208,7 +208,7 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int to
   return KP * LQP * 6                      // QCT (f32) + QCU (u8, rows padded to a power of two)
          + KP + 1024                       // per-centroid maxima of the u8 table + their histogram (hot level)
          + KP * 6 + G * 4 + NP_UB_BINS * 8   // zeroth level: gains of the probed cells, its own deeper cell list, two histograms,
-         + (ix->d_ivf_split ? (int64_t)ix->n_ranges * NP_GAIN_RANGE * 2 : 0)   // ... the documents' u16 accumulators
+         + (ix->d_ivf_split ? (int64_t)ix->n_ranges * NP_GAIN_RANGE : 0)   // ... the documents' level bytes
          + NP_UB_BINS * 8
          + G * LQP * 4 + G * 4             // gmax, cellbits
          + KP * 8                          // cells_tmp, cells
@@ -621,15 +621,15 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // cell share a bound: a bin may hold whole posting lists)
   const int s0cap = s0_target + cs->n_sel;
   // u32 words of w.gsmall: [0, 4B) base / shift / floor bin / 0, then B each: n_raw, thr0, cut0, n_s0, n_emit, n_direct, round_of0, order0, cursor0,
-  // n_hi, n_hi_emit, n_marg; 4 words round_tab0; then (8-byte aligned) cand_base0 i64 [B]
-  const size_t gs_words = (size_t)16 * B + 4, gs_bytes = (gs_words + (gs_words & 1)) * 4 + (size_t)B * 8;
+  // n_hi, n_hi_emit, n_marg, lcut; 4 words round_tab0; 6 words = 3 x u64 batch report; then (8-byte aligned) cand_base0 i64 [B]
+  const size_t gs_words = (size_t)17 * B + 4 + 8, gs_bytes = (gs_words + (gs_words & 1)) * 4 + (size_t)B * 8;
   if (gain_path) {
     NP_TRY(w.gain.reserve((size_t)B * KP * 2));
     NP_TRY(w.gsmall.reserve(gs_bytes));
-    NP_TRY(w.ghist.reserve((size_t)2 * B * NP_UB_BINS * 4));
+    NP_TRY(w.ghist.reserve((size_t)B * (256 + NP_UB_BINS) * 4));   // levels of all candidates; exact lower bounds of S0
     NP_TRY(w.s0_meta.reserve((size_t)B * s0cap * 16));
     NP_TRY(w.s0_u.reserve((size_t)B * s0cap * 2));
-    NP_TRY(w.gacc.reserve((size_t)B * ix->n_ranges * NP_GAIN_RANGE * 2));
+    NP_TRY(w.gacc.reserve((size_t)B * ix->n_ranges * NP_GAIN_RANGE));   // one level byte per document and query
     if (gain_deep) NP_TRY(w.gdeep.reserve(((size_t)B * G + (size_t)B * LQP + (size_t)B + (size_t)B * KP) * 4));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
@@ -672,7 +672,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     if (gain_deep) add(w.gdeep.p, ((size_t)B * G + (size_t)B * LQP + (size_t)B) * 4, 0);   // marks, per-token thresholds, cell counts
     if (gain_path) {
       add(w.gsmall.p, gs_bytes, 0);
-      add(w.ghist.p, (size_t)2 * B * NP_UB_BINS * 4, 0);
+      add(w.ghist.p, (size_t)B * (256 + NP_UB_BINS) * 4, 0);
     }
     if (two_level && B > 0) {
       add(w.chist.p, (size_t)B * 256 * 4, 0);
@@ -888,10 +888,12 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     int32_t* g_nhi = reinterpret_cast<int32_t*>(gs + 13 * B);
     int32_t* g_nhi_emit = reinterpret_cast<int32_t*>(gs + 14 * B);
     int32_t* g_nmarg = reinterpret_cast<int32_t*>(gs + 15 * B);
-    rp0.round_tab = reinterpret_cast<int32_t*>(gs + 16 * B);
+    uint32_t* g_lcut = gs + 16 * B;
+    rp0.round_tab = reinterpret_cast<int32_t*>(gs + 17 * B);
+    unsigned long long* g_report = reinterpret_cast<unsigned long long*>(gs + ((17 * (size_t)B + 4 + 1) & ~(size_t)1));
     rp0.cand_base = reinterpret_cast<int64_t*>(gs + gs_words + (gs_words & 1));
     uint32_t* hist0 = w.ghist.as<uint32_t>();
-    uint32_t* hist_s0 = hist0 + (size_t)B * NP_UB_BINS;
+    uint32_t* hist_s0 = hist0 + (size_t)B * 256;
     const uint32_t* g_tauq = w.tauq.as<uint32_t>();
     gp.cells = w.cells.as<uint32_t>();
     gp.n_cells = w.n_cells.as<int32_t>();
@@ -925,7 +927,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     gp.n_emit = g_nemit;
     gp.rp = rp;
     gp.ctr = w.ctr.as<Counters>();
-    gp.acc = w.gacc.as<uint16_t>();
+    gp.lvl = w.gacc.as<uint8_t>();
     gp.n_ranges = ix->n_ranges;
     gp.n_hi = g_nhi;
     gp.n_marg = g_nmarg;
@@ -933,15 +935,13 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gain_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
     if (RB == 32)
       gain_prep_kernel<32><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, g_tauq, LQP, w.qinv.as<float>(),
-                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift,
-                                              g_real);
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, hshift, g_real);
     else
       gain_prep_kernel<64><<<B, 256, 0, st>>>(w.QCU.as<uint8_t>(), KP, gp.cells, gp.n_cells, g_tauq, LQP, w.qinv.as<float>(),
-                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, ix->d_ivf_offsets, 2 * (int64_t)s0_target, hshift,
-                                              g_real);
+                                              d_qoff, w.gain.as<uint16_t>(), g_base, B, s0cap, rp0, hshift, g_real);
     const dim3 ggrid((unsigned)ix->n_ranges, (unsigned)B), egrid((unsigned)ix->n_ranges, (unsigned)B);
     gain_sweep_kernel<<<ggrid, 1024, glds, st>>>(gp);                                         // accumulators, histogram of U0, counts
-    gain_thr_kernel<<<B, 256, 0, st>>>(hist0, s0_target, cs->n_sel, s0cap, g_base, g_nraw, w.qflag.as<uint32_t>(), g_thr0, g_nhi, g_ns0);
+    gain_thr_kernel<<<B, 64, 0, st>>>(hist0, s0_target, s0cap, g_nraw, w.qflag.as<uint32_t>(), g_thr0, g_nhi, g_ns0);
     gp.n_emit = g_nhi_emit;
     gain_emit_kernel<1><<<egrid, 256, 0, st>>>(gp, 0);                                        // S0: records of the best bounds
     gp.n_emit = g_nemit;
@@ -951,13 +951,10 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
                    0, ix->tune.s3_gain_direct, false);                                        // exact bounds of S0 (histogram: lower bounds)
     }
     ub_thr_kernel<<<B, 256, 0, st>>>(hist_s0, hshift, slack, cs->n_sel, g_ns0, rp0, 0, w.qflag.as<uint32_t>(), g_cut0);   // tau0 - slack
-    gp.thr = g_cut0;
-    gp.n_emit = g_ndirect;
-    gain_emit_kernel<0><<<egrid, 256, 0, st>>>(gp, 0);                                        // candidates at the cut, counted
-    gp.n_emit = g_nemit;
-    gain_count_kernel<<<1, 64, 0, st>>>(g_cut0, g_nraw, g_ndirect, B, w.ctr.as<Counters>(), ix->tune.s3_gain == 1 ? w.h_gain : nullptr);
+    gain_count_kernel<<<B, 64, 0, st>>>(g_cut0, hist0, g_base, g_nraw, g_lcut, g_ndirect, w.ctr.as<Counters>(),
+                                        ix->tune.s3_gain == 1 ? w.h_gain : nullptr, g_report, B);   // the cut in levels, candidates kept
     plan_rounds_kernel<<<1, 256, 0, st>>>(nullptr, 0, B, pool, max_rounds, rp, w.ctr.as<Counters>(), g_ndirect);
-    gp.thr = g_cut0;
+    gp.thr = g_lcut;
   }
   if (have_cands && !gain_path) {
     if (ix->tune.s3_slices) {
