@@ -3616,14 +3616,17 @@ __global__ void __launch_bounds__(256) hot_planes_kernel(const uint8_t* __restri
 
 template <int RB, typename CT, int LPD, int PF /* walk steps in flight ahead of the prefetch: 1 or 2 */,
           int DPI /* documents per staging instruction: 4 (blocks <= 240 B), 2 (<= 496 B), 1 */,
-          int QM /* hot codes of a lane: 0 = compacted in place over its share (LDS writes), 1 = a 64-bit position mask in registers */>
+          int QM /* hot codes of a lane: 0 = compacted in place over its share (LDS writes), 1 = a 64-bit position mask in registers */,
+          int WPB = 4 /* waves per workgroup.  The hot bitmap is one copy per WORKGROUP: at K = 2^19 its 64 KB left room for ONE
+                         4-wave workgroup per CU (round 6: 3.5 ms of hot level per batch in the crate-natural regime); 12 waves
+                         sharing one copy fill the CU like three small workgroups do at K = 2^16 */>
 // (Round 5, measured and removed -- commit 122dafe has the code: the NEXT claim's blocks requested into REGISTERS the moment this
 // claim's rows are in LDS, so that they travel during its whole scan, and written to the rows after the walk.  The ISA did what
 // was asked -- 8 buffer loads at the top of the claim, no vector-memory wait until the walk's first fold -- and the kernel did
 // not move: 2.19 vs 2.18 ms of S4 at 10 M documents, and 5.07 vs 5.34 k queries/s in the dense regime (t_cs = None), where the
 // 141 VGPRs cost more than the overlap gained.  A claim's time is one HBM round trip under load plus its compute whichever way the
 // two are arranged; what would help is more claims in flight per CU, which LDS rows or registers both cap.)
-__global__ void __launch_bounds__(256) approx_hotp_kernel(
+__global__ void __launch_bounds__(64 * WPB) approx_hotp_kernel(
     const uint32_t* __restrict__ planes /* [B][KP][RB / 4] */, int64_t K, int64_t KP, const uint32_t* __restrict__ hotbits /* [B][KP / 32] */,
     const uint32_t* __restrict__ lam_b, const uint32_t* __restrict__ lev /* [B][16] */,
     const uint32_t* __restrict__ cand_ids /* [pool] shard-local document ids (compact_kernel) */,
@@ -3674,7 +3677,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
   uint32_t toks32 = 0, ucnt32 = 0, rows32 = 0;
   // the scan looks every staged position up in the bitmap, also past a list's end: the rows must never hold anything but
   // codes (< K) behind the header, so they start zeroed (afterwards they only ever receive list entries or zeros)
-  for (int i = tid; i < 4 * (DPW * row_b + slack) / 4; i += 256) (s_dyn + bmw)[i] = 0u;
+  for (int i = tid; i < WPB * (DPW * row_b + slack) / 4; i += 64 * WPB) (s_dyn + bmw)[i] = 0u;
   for (int step = 0;; ++step) {
     __syncthreads();
     if (tid == 0) s_q = xcd_next_query(slots, ticket, x, step, B, rp.order, rb, re, [&]() { return -3; });
@@ -3687,7 +3690,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
     uint4* metab = cand_meta + pbase;
     if (qflag[b] || n <= (int64_t)n_sel) {
       // the cuts keep every candidate of this query: no bound to compute, but the later stages still want the records
-      for (int64_t i = ((int64_t)(blockIdx.x >> 3) * 256 + tid); i < n; i += (int64_t)(gridDim.x >> 3) * 256) {
+      for (int64_t i = ((int64_t)(blockIdx.x >> 3) * (64 * WPB) + tid); i < n; i += (int64_t)(gridDim.x >> 3) * (64 * WPB)) {
         const uint32_t d = idb[i];
         const uint4 hd = *reinterpret_cast<const uint4*>(codes + (int64_t)d * ublock_stride);
         const int64_t cl = (int)hd.x > fit ? ovf_base + (int64_t)hd.z * 4 : (int64_t)d * ublock_stride + HDR;
@@ -3703,8 +3706,8 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
     // ---- hot bitmap (hot_levels_kernel): bit c = M[c] > Lambda
     {
       const uint32_t* hbits = hotbits + (int64_t)b * (KP >> 5);
-      for (int w = tid; w < (int)(KP >> 5); w += 256) BITS(w) = hbits[w];
-      for (int i = tid; i < NP_UB_BINS / 2; i += 256) s_hist[i] = 0;
+      for (int w = tid; w < (int)(KP >> 5); w += 64 * WPB) BITS(w) = hbits[w];
+      for (int i = tid; i < NP_UB_BINS / 2; i += 64 * WPB) s_hist[i] = 0;
     }
     __syncthreads();
     const uint64_t tb64 = reinterpret_cast<uint64_t>(planes + (int64_t)b * KP * NS);
@@ -3715,8 +3718,8 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
     uint32_t* hb = hist + (int64_t)b * NP_UB_BINS;
     // claims round-robin: wave g of the NW waves of this XCD takes claims g, g + NW, ... (approx_hot_kernel: a cursor
     // atomic per claim costs more than the imbalance it removes)
-    const int64_t NW = (int64_t)(gridDim.x >> 3) * 4;
-    int64_t i0 = ((int64_t)(blockIdx.x >> 3) * 4 + wave) * DPW, i1 = i0 + NW * DPW;
+    const int64_t NW = (int64_t)(gridDim.x >> 3) * WPB;
+    int64_t i0 = ((int64_t)(blockIdx.x >> 3) * WPB + wave) * DPW, i1 = i0 + NW * DPW;
     const uint32_t id_last = idb[n - 1];
     char* row = s_rows + (size_t)grp * row_b;        // this lane's document
     const CT* rowc = reinterpret_cast<const CT*>(row) + HDR;   // its codes (behind the block header)
@@ -4049,7 +4052,7 @@ __global__ void __launch_bounds__(256) approx_hotp_kernel(
       i1 += NW * DPW;
     }
     __syncthreads();
-    for (int i = tid; i < NP_UB_BINS / 2; i += 256) {
+    for (int i = tid; i < NP_UB_BINS / 2; i += 64 * WPB) {
       const uint32_t v = s_hist[i];
       if (v) atomicAdd(&hb[2 * i], v);
     }

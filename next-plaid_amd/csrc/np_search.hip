@@ -1087,24 +1087,25 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     else if (RB == 128) NP_LAUNCH_HOT(128, CT); \
     else NP_LAUNCH_HOT(256, CT);                \
   } while (0)
-#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV, QMV)                                                                          \
+#define NP_LAUNCH_HOTP_W(ROWB, CT, LPDV, PFV, DPIV, QMV, WPBV, NBX)                                                        \
   do {                                                                                                                   \
     const size_t bm = sizeof(CT) == 2 ? 0 : (size_t)(((KP >> 5) + 3) & ~(int64_t)3) * 4;   /* u16 codes: static bitmap */   \
     /* idle lanes of the last packed staging instruction write 16 B each past the rows it fills (1 KiB per instruction);     \
        the one-block-per-instruction fallback overruns by at most 256 B */                                                  \
     const size_t rowb = (size_t)ix->ublock_stride * sizeof(CT) + 16;                                                          \
     const int slack = (int)std::max<int64_t>(256, 1024 - (int64_t)(DPIV) * (int64_t)rowb);                                   \
-    const size_t dynp = bm + (size_t)4 * ((64 / LPDV) * rowb + (size_t)slack);                                               \
+    const size_t dynp = bm + (size_t)(WPBV) * ((64 / LPDV) * rowb + (size_t)slack);                                          \
     if (dynp > 16 * 1024)                                                                                                \
-      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV>), \
+      NP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV, WPBV>), \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynp));                                \
-    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV><<<8 * pnbx, 256, dynp, st>>>(                 \
+    approx_hotp_kernel<ROWB, CT, LPDV, PFV, DPIV, QMV, WPBV><<<8 * (NBX), 64 * (WPBV), dynp, st>>>(                 \
         w.planes.as<uint32_t>(), ix->K, KP, w.hotbits.as<uint32_t>(), w.ub_thr2.as<uint32_t>() + B, w.levels.as<uint32_t>(), \
         w.cand.as<uint32_t>(), w.cand_meta.as<uint4>(), ix->ublock_stride, (int64_t)ix->n_docs * ix->ublock_stride,        \
         w.n_cand.as<int32_t>(), rp, r, max_rounds, (const CT*)ix->d_ucodes, w.qflag.as<uint32_t>(), d_qoff, cs->n_sel,     \
         w.ub.as<uint16_t>(), w.ub_hist.as<uint32_t>(), hshift, sl, sl + 8 * (B + 1), B, w.ctr.as<Counters>(), slack,       \
         ix->tune.s4_probe, gain_path ? 1 : 0);                                                                                            \
   } while (0)
+#define NP_LAUNCH_HOTP(ROWB, CT, LPDV, PFV, DPIV, QMV) NP_LAUNCH_HOTP_W(ROWB, CT, LPDV, PFV, DPIV, QMV, 4, pnbx)
   // lanes per document: 2 (32 documents per claim; blocks of at most 256 bytes) or 4 (16 per claim: half the LDS rows per
   // wave; the only choice for 512-byte blocks).  Documents per staging instruction from the block size (16 B per lane,
   // block + 16 B of padding per row)
@@ -1126,6 +1127,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
             if (!ix->code_wide) {
               if (RB == 32) NP_LAUNCH_HOTP_L(32, uint16_t);
               else NP_LAUNCH_HOTP_L(64, uint16_t);
+            } else if ((KP >> 3) >= 32 * 1024 && plpd == 4 && ix->ublock_stride * 4 > 240 && ix->ublock_stride * 4 <= 496) {
+              // u32 code lists with a hot bitmap of 32 KB or more (K >= 2^18), the usual 4-lane form: ONE workgroup of 12 waves per
+              // CU shares the bitmap (with 4-wave workgroups the 64 KB of K = 2^19 left one per CU: 4 waves)
+              if (RB == 32) NP_LAUNCH_HOTP_W(32, uint32_t, 4, 1, 2, 0, 12, 32);
+              else NP_LAUNCH_HOTP_W(64, uint32_t, 4, 1, 2, 0, 12, 32);
             } else {
               if (RB == 32) NP_LAUNCH_HOTP_L(32, uint32_t);
               else NP_LAUNCH_HOTP_L(64, uint32_t);
@@ -1134,6 +1140,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
           else NP_LAUNCH_HOT_RB(uint32_t);
 #undef NP_LAUNCH_HOTP_L
 #undef NP_LAUNCH_HOTP
+#undef NP_LAUNCH_HOTP_W
 #undef NP_LAUNCH_HOT_RB
 #undef NP_LAUNCH_HOT
           if (cs->timed && r == 0) {
