@@ -4121,6 +4121,74 @@ __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restr
   const int q0 = qoff[b], Lq = qoff[b + 1] - q0;
   const int ql = lane & 31, half = lane >> 5;
   const int ndoc_iter = (n + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
+  if constexpr (!TAIL) {
+    if (Lq <= 32) {
+      // One query tile (the usual case): the lane's query row lives in REGISTERS for the whole block -- the kernel is bound by
+      // LDS bandwidth (per (token, code) pair a lane read its 512-byte query row AND the 512-byte centroid row from LDS: four
+      // SIMDs ask the CU's one LDS for 4 x 512 cycles of reads per 512 cycles of packed-f32 VALU work), and the query row is
+      // the half that never changes.  Same arithmetic, same order: eight partial sums, multiply then add.
+      for (int w = tid; w < 32 * (DIM / 4); w += 256) {
+        const int r = w / (DIM / 4), c4 = w - r * (DIM / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < Lq) v = *reinterpret_cast<const float4*>(qrows + (int64_t)(q0 + r) * DIM + 4 * c4);
+        *reinterpret_cast<float4*>(&sQ[r * QS + 4 * c4]) = v;
+      }
+      __syncthreads();
+      float4 xr[DIM / 4];
+#pragma unroll
+      for (int k4 = 0; k4 < DIM / 4; ++k4) xr[k4] = *reinterpret_cast<const float4*>(&sQ[ql * QS + 4 * k4]);
+      for (int it = 0; it < ndoc_iter; ++it) {
+        const int i = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        const bool live = i < n;
+        const uint4 m = meta[pbase + (live ? i : 0)];
+        const int nd = live ? (int)m.y : 0;
+        const int64_t cl = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
+        float mx = NP_NEG_INF;
+        for (int j0 = 0; j0 < nd; j0 += 2) {
+          const int j = j0 + half;
+          {
+            const uint32_t c = codes[cl + max(min(j, nd - 1), 0)];
+            const float4* src = reinterpret_cast<const float4*>(centroids + (int64_t)c * DIM);
+            if (ql < DIM / 4) *reinterpret_cast<float4*>(&sC[wave][half][4 * ql]) = src[ql];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, p45 = {0.f, 0.f}, p67 = {0.f, 0.f};
+          const float* yc = &sC[wave][half][0];
+#pragma unroll
+          for (int k = 0; k < DIM; k += 8) {
+            const float4 x0 = xr[k / 4], x1 = xr[k / 4 + 1];
+            const float4 y0 = *reinterpret_cast<const float4*>(yc + k), y1 = *reinterpret_cast<const float4*>(yc + k + 4);
+            p01 = p01 + (f32x2){x0.x, x0.y} * (f32x2){y0.x, y0.y};
+            p23 = p23 + (f32x2){x0.z, x0.w} * (f32x2){y0.z, y0.w};
+            p45 = p45 + (f32x2){x1.x, x1.y} * (f32x2){y1.x, y1.y};
+            p67 = p67 + (f32x2){x1.z, x1.w} * (f32x2){y1.z, y1.w};
+          }
+          float sum = 0.f;
+          sum = sum + (p01.x + p45.x);
+          sum = sum + (p01.y + p45.y);
+          sum = sum + (p23.x + p67.x);
+          sum = sum + (p23.y + p67.y);
+          if (j < nd && sum > mx) mx = sum;          // search.rs:286-291
+          __builtin_amdgcn_wave_barrier();            // sC is rewritten by the next step
+        }
+        sM[wave][lane] = mx;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          float score = 0.f;
+          for (int qq = 0; qq < Lq; ++qq) {
+            const float a0 = sM[wave][qq], a1 = sM[wave][32 + qq];
+            const float mm = (a1 > a0) ? a1 : a0;
+            if (mm > NP_NEG_INF) score = score + mm;
+          }
+          if (live) approx[pbase + i] = score;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
   for (int it = 0; it < ndoc_iter; ++it) {           // block-uniform trip count (barriers inside)
     const int i = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
     const bool live = i < n;
