@@ -4144,33 +4144,46 @@ __global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restr
         const int nd = live ? (int)m.y : 0;
         const int64_t cl = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
         float mx = NP_NEG_INF;
-        for (int j0 = 0; j0 < nd; j0 += 2) {
-          const int j = j0 + half;
-          {
-            const uint32_t c = codes[cl + max(min(j, nd - 1), 0)];
-            const float4* src = reinterpret_cast<const float4*>(centroids + (int64_t)c * DIM);
-            if (ql < DIM / 4) *reinterpret_cast<float4*>(&sC[wave][half][4 * ql]) = src[ql];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, p45 = {0.f, 0.f}, p67 = {0.f, 0.f};
-          const float* yc = &sC[wave][half][0];
+        // The step's centroid row is one global round trip behind its code: a step that fetched code -> row -> LDS -> compute in
+        // turn was a chain of ~1.5 us per pair of codes (34 steps per document).  The document's codes are read 64 at a time into
+        // a register per lane (a step's code comes by ds_bpermute), and the NEXT step's rows are requested before this step's
+        // arithmetic.
+        for (int c0 = 0; c0 < nd; c0 += 64) {
+          const int ncs = min(64, nd - c0);
+          const uint32_t cr0 = c0 + lane < nd ? codes[cl + c0 + lane] : 0u;
+          auto row_piece = [&](int jj) {   // this lane's 16 bytes of the row of code jj of the chunk (clamped: a duplicate of the last)
+            const uint32_t c = (uint32_t)__shfl((int)cr0, min(jj, ncs - 1));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ql < DIM / 4) v = reinterpret_cast<const float4*>(centroids + (int64_t)c * DIM)[ql];
+            return v;
+          };
+          float4 nxt = row_piece(half);
+          for (int j0 = 0; j0 < ncs; j0 += 2) {
+            const int j = j0 + half;
+            const float4 cur = nxt;
+            if (j0 + 2 < ncs) nxt = row_piece(j0 + 2 + half);
+            if (ql < DIM / 4) *reinterpret_cast<float4*>(&sC[wave][half][4 * ql]) = cur;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, p45 = {0.f, 0.f}, p67 = {0.f, 0.f};
+            const float* yc = &sC[wave][half][0];
 #pragma unroll
-          for (int k = 0; k < DIM; k += 8) {
-            const float4 x0 = xr[k / 4], x1 = xr[k / 4 + 1];
-            const float4 y0 = *reinterpret_cast<const float4*>(yc + k), y1 = *reinterpret_cast<const float4*>(yc + k + 4);
-            p01 = p01 + (f32x2){x0.x, x0.y} * (f32x2){y0.x, y0.y};
-            p23 = p23 + (f32x2){x0.z, x0.w} * (f32x2){y0.z, y0.w};
-            p45 = p45 + (f32x2){x1.x, x1.y} * (f32x2){y1.x, y1.y};
-            p67 = p67 + (f32x2){x1.z, x1.w} * (f32x2){y1.z, y1.w};
+            for (int k = 0; k < DIM; k += 8) {
+              const float4 x0 = xr[k / 4], x1 = xr[k / 4 + 1];
+              const float4 y0 = *reinterpret_cast<const float4*>(yc + k), y1 = *reinterpret_cast<const float4*>(yc + k + 4);
+              p01 = p01 + (f32x2){x0.x, x0.y} * (f32x2){y0.x, y0.y};
+              p23 = p23 + (f32x2){x0.z, x0.w} * (f32x2){y0.z, y0.w};
+              p45 = p45 + (f32x2){x1.x, x1.y} * (f32x2){y1.x, y1.y};
+              p67 = p67 + (f32x2){x1.z, x1.w} * (f32x2){y1.z, y1.w};
+            }
+            float sum = 0.f;
+            sum = sum + (p01.x + p45.x);
+            sum = sum + (p01.y + p45.y);
+            sum = sum + (p23.x + p67.x);
+            sum = sum + (p23.y + p67.y);
+            if (j < ncs && sum > mx) mx = sum;          // search.rs:286-291 (codes in list order: chunks ascend)
+            __builtin_amdgcn_wave_barrier();            // sC is rewritten by the next step
           }
-          float sum = 0.f;
-          sum = sum + (p01.x + p45.x);
-          sum = sum + (p01.y + p45.y);
-          sum = sum + (p23.x + p67.x);
-          sum = sum + (p23.y + p67.y);
-          if (j < nd && sum > mx) mx = sum;          // search.rs:286-291
-          __builtin_amdgcn_wave_barrier();            // sC is rewritten by the next step
         }
         sM[wave][lane] = mx;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
