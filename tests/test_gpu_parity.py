@@ -424,6 +424,9 @@ def test_zeroth_level_preserves_selection():
     orc = ox.search_batch(batch[:8], to_oracle_params(p))
     for g, o in zip(got, orc):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32)
+    one = hx.search(batch[0], p)                       # MmapIndex::search: a batch of one takes the level too
+    assert hx.last_stats["n_level0"] > 0
+    assert np.array_equal(one.passage_ids, got[0].passage_ids) and np.array_equal(one.scores, got[0].scores)
     hx.close()
 
 
