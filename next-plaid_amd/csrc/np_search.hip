@@ -23,6 +23,7 @@ struct Workspace {
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
   unsigned long long* h_gain = nullptr;   // pinned: the zeroth level's last (candidates << 32 | kept), written by the device
+  uint64_t h_gain_key = 0;                // ... and the parameters of the batch that will write (or wrote) it
   hipEvent_t done = nullptr;  // recorded at the end of every use of this workspace
   bool done_valid = false;
   static constexpr int NBUF = 66;
@@ -600,7 +601,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       const double benefit_ms = (raw - kept) * 1e-7;                                  // the filter's ~0.06-0.2 ns of GPU time per candidate
                                                                                       // (8 ms per 130 M at K = 2^16, 3.2 ms per 16 M at 2^19)
       const double cost_ms = 2.0 * ((double)ix->n_docs / 1e7) * ((double)B / 64.0);   // measured: 2.0-2.4 ms at 10 M documents x 64 queries
-      if (raw > 0 && benefit_ms < cost_ms) ix->gain_skip.store(31, std::memory_order_relaxed);
+      // (a report of a batch with other parameters says nothing about these)
+      if (raw > 0 && w.h_gain_key == key && benefit_ms < cost_ms) ix->gain_skip.store(31, std::memory_order_relaxed);
     } else if (hipHostMalloc((void**)&w.h_gain, 64, hipHostMallocDefault) == hipSuccess) {
       *w.h_gain = 0;
     } else {
@@ -610,6 +612,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     if (ix->gain_skip.load(std::memory_order_relaxed) > 0) {
       ix->gain_skip.fetch_sub(1, std::memory_order_relaxed);
       gain_path = false;
+    } else {
+      w.h_gain_key = key;
     }
   }
   // the level probes on its own to depth 32 where the search stops earlier: the bound's floor falls with the depth (np_kernels.h)
