@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(256) inv_norm_kernel(int64_t T, int dim /* row
 // ivf_split[c][r] = number of entries of posting list c with id < r * 32768 (r = 0 .. n_ranges): the zeroth filter level
 // (gain_sweep_kernel, np_kernels.h) holds the accumulators of one 32768-document range per block and reads exactly its part of
 // every probed list.  One thread per (list, boundary), a bisection each; ascending lists only.
-#define NP_SPLIT_RANGE 32768
+#define NP_SPLIT_RANGE NP_IVF_SPLIT_RANGE
 __global__ void __launch_bounds__(256) ivf_split_kernel(const uint32_t* __restrict__ ivf, const int64_t* __restrict__ ivf_off,
                                                         int64_t K, int R1, uint32_t* __restrict__ split) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -172,6 +172,9 @@ struct Tuning {
   int exact_rowmax = 0;  // force the row-max form of the QC-reuse S6 kernel
 };
 
+// documents per range of the posting lists' range table (d_ivf_split) = per block of the zeroth filter level's sweep (np_kernels.h)
+#define NP_IVF_SPLIT_RANGE 32768
+
 struct DeviceIndex {
   int device = 0;
   int64_t N_total = 0, n_emb_total = 0;

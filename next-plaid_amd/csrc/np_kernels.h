@@ -1345,7 +1345,7 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
 // ---------------------------------------------------------------------------------------------
 #define NP_UB_BINS 2048    // histogram bins of the integer bounds: bin = U >> hshift, hshift = log2(ROWB / 32) + 2 (U <= 255 * ROWB);
                            // u32 counters in LDS (8 KB): a workgroup's share of a query's documents is unbounded
-#define NP_GAIN_RANGE 32768      // documents per accumulator range
+#define NP_GAIN_RANGE NP_IVF_SPLIT_RANGE   // documents per accumulator range = the granularity of the posting lists' range table (np_internal.h)
 #define NP_GAIN_CELLS 256        // probed cells staged per pass
 #define NP_GAIN_ITEM 32          // posting entries per work item (half a wave)
 
@@ -1471,12 +1471,10 @@ struct GainP {
   const uint16_t* gain;       // [B][KP] by cell position
   const uint32_t* gbase;      // [B][4]: base, gain shift, level shift r, b0 = base >> hshift
   int hshift;
-  int64_t n_docs;
   uint32_t* hist0;            // [B][256] documents per level (sweep)
   int32_t* n_raw;             // [B] candidates (mode 0)
   const uint32_t* thr;        // [B] mode 1: LEVEL threshold of S0 (0 = no S0); mode 2: level of the cut (<= 1: keep every candidate)
   uint4* s0_meta;             // mode 1: [B][s0cap] records
-  int32_t* n_s0;              // [B] zeroed
   int s0cap;
   const void* ucodes;         // list blocks (headers): mode 1 builds the records itself
   int code_wide, ublock_stride;
@@ -1847,8 +1845,7 @@ __global__ void __launch_bounds__(64) gain_count_kernel(const uint32_t* __restri
     n_out[b] = (int32_t)n;
     atomicAdd(&ctr->n_candidates, (unsigned long long)n_raw[b]);
     atomicAdd(&ctr->n_level0, (unsigned long long)n);
-    const unsigned long long raw = atomicAdd(&d_report[0], (unsigned long long)n_raw[b]) + (unsigned long long)n_raw[b];
-    (void)raw;
+    atomicAdd(&d_report[0], (unsigned long long)n_raw[b]);
     atomicAdd(&d_report[1], (unsigned long long)n);
     __threadfence();
     if (atomicAdd(&d_report[2], 1ull) + 1ull == (unsigned long long)B && h_report)   // the last query of the batch reports

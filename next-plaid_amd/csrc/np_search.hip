@@ -916,12 +916,10 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     gp.gain = w.gain.as<uint16_t>();
     gp.gbase = g_base;
     gp.hshift = hshift;
-    gp.n_docs = ix->n_docs;
     gp.hist0 = hist0;
     gp.n_raw = g_nraw;
     gp.thr = g_thr0;
     gp.s0_meta = w.s0_meta.as<uint4>();
-    gp.n_s0 = g_ns0;
     gp.s0cap = s0cap;
     gp.ucodes = ix->d_ucodes;
     gp.code_wide = ix->code_wide;
