@@ -1330,6 +1330,12 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint32_t* __restrict
 // REMOVED cells of a query (search.rs:417-425) would have to enter theta (their scores reach 0.4) and sum theta' = 11.5
 // exceeds tau ~ 10-12: nothing to gain there, so the level runs only where no threshold is set.
 //
+// WITH A THRESHOLD (search.rs:417-425) the cells it removes are still in some token's top-n_probe: folding them into theta lifts
+// the floor to the cut (sum theta' = 11.5 on the metric corpus: nothing pruned).  Swept as BOUND-ONLY cells instead -- their lists
+// add gains, only the KEPT cells' documents are candidates -- the floor stays sum theta_q and the level keeps 5-17 % of the
+// candidates at 0.5 distinct codes per token and 8-39 % at 0.8 (profiles/r06_sim_s3_gain_thr_*.txt); on the metric corpus
+// (0.23: 186 k candidates per query against 9.4 M posting entries to sweep) it costs more than it saves, which the run / skip
+// rule finds out by itself.
 // DEEPER THAN THE PROBE (n_ivf_probe < 32): the bound's floor sum_q ut_q falls with the depth (a token's 32nd best score instead
 // of its 8th: 10.3 -> 9.2 score units on the metric corpus, against cuts of 10-12.5: one query in four had NO pruning at depth 8,
 // every query at depth 32).  So the level probes on its own to depth max(n_ivf_probe, 32) (the S2 kernels once more): the cells
@@ -1764,6 +1770,18 @@ __global__ void __launch_bounds__(256) gain_emit_kernel(GainP p, int round) {
   }
 }
 
+// the kept cells of every query (S2's list AFTER the centroid_score_threshold) as a bitmap: with a threshold the level sweeps every
+// probed cell, and only the kept ones make candidates (gain_prep_kernel's real_bits)
+__global__ void __launch_bounds__(256) cells_to_bits_kernel(const uint32_t* __restrict__ cells, const int32_t* __restrict__ n_cells,
+                                                            int64_t KP, uint32_t* __restrict__ bits /* [B][KP / 32] zeroed */) {
+  const int b = blockIdx.x;
+  const int n = n_cells[b];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t c = cells[(int64_t)b * KP + i];
+    atomicOr(&bits[(int64_t)b * (KP >> 5) + (c >> 5)], 1u << (c & 31));
+  }
+}
+
 // S0 = the ~target documents with the largest U0: thr[b] = the LEVEL at which the count from the top reaches the target (0 = no
 // S0: flagged query, or fewer candidates than the target); n_hi[b] = documents above it (all taken), n_s0[b] = min(cap, documents
 // at levels >= thr): the marginal level fills what is left of the slice.  One wave per query.
@@ -1824,9 +1842,9 @@ __global__ void __launch_bounds__(64) gain_thr_kernel(const uint32_t* __restrict
 __global__ void __launch_bounds__(64) gain_count_kernel(const uint32_t* __restrict__ cut_bin, const uint32_t* __restrict__ hist,
                                                         const uint32_t* __restrict__ gbase, const int32_t* __restrict__ n_raw,
                                                         uint32_t* __restrict__ lcut, int32_t* __restrict__ n_out, Counters* ctr,
-                                                        unsigned long long* __restrict__ h_report /* pinned host word: candidates << 32 |
-                                                            kept, accumulated over the batch's queries, for the host's run / skip
-                                                            policy (read a batch later, never waited for) */,
+                                                        unsigned long long* __restrict__ h_report /* pinned host words: [0] candidates << 32 |
+                                                            kept over the batch's queries, [1] posting entries swept, for the host's
+                                                            run / skip policy (read a batch later, never waited for) */,
                                                         unsigned long long* __restrict__ d_report /* [2] zeroed: the batch's sums */,
                                                         int B) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -1848,8 +1866,11 @@ __global__ void __launch_bounds__(64) gain_count_kernel(const uint32_t* __restri
     atomicAdd(&d_report[0], (unsigned long long)n_raw[b]);
     atomicAdd(&d_report[1], (unsigned long long)n);
     __threadfence();
-    if (atomicAdd(&d_report[2], 1ull) + 1ull == (unsigned long long)B && h_report)   // the last query of the batch reports
-      *h_report = (min(d_report[0], 0xFFFFFFFFull) << 32) | min(d_report[1], 0xFFFFFFFFull);
+    if (atomicAdd(&d_report[2], 1ull) + 1ull == (unsigned long long)B && h_report) {   // the last query of the batch reports
+      h_report[1] = ctr->n_ivf_ids;                       // posting entries the sweep read (what the level cost)
+      __threadfence_system();
+      h_report[0] = (min(d_report[0], 0xFFFFFFFFull) << 32) | min(d_report[1], 0xFFFFFFFFull);
+    }
   }
 }
 

@@ -582,29 +582,34 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // before any list block is read.  Only where no centroid_score_threshold is set (the cells a threshold removes would lift
   // the bound's floor above the cut: tools/sim/s3_gain_sim.py), on ascending posting lists (range table built at open), with
   // the bit-plane first level behind it (it takes the candidate ids in any order) and without a subset.
-  bool gain_path = two_level && use_planes && ix->d_ivf_split != nullptr && ix->tune.s3_gain && !prm.has_threshold &&
+  bool gain_path = two_level && use_planes && ix->d_ivf_split != nullptr && ix->tune.s3_gain &&
                    subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0 &&
                    (int64_t)std::max(prm.n_ivf_probe, 32) * maxLq <= 16384;   // probed cells per query: the scaled gains of all of
                                                                                // them must fit a 15-bit accumulator (gain_prep_kernel)
   if (gain_path && ix->tune.s3_gain == 1) {
-    // Run / skip policy.  The level costs about the same whatever it prunes (one sweep of the probed lists to depth 32, the
-    // accumulators of every document written and read three times: ~0.2 us per 1000 documents and query), and what it buys is the
-    // filter's ~0.1 ns of GPU time per candidate it removes.  The device leaves (candidates, kept) of each batch in a pinned word; a context
-    // reads the word of ITS previous batch here -- never waited for: a batch still in flight simply has not reported -- and when
-    // the removed candidates would not have paid for the level, the handle skips it for 31 batches and then tries again.
-    // Results do not depend on the decision.
-    const uint64_t key = ((uint64_t)(uint32_t)prm.n_ivf_probe << 40) ^ ((uint64_t)(uint32_t)cs->n_sel << 16) ^ (uint64_t)(uint32_t)LQP;
-    if (ix->gain_key.exchange(key, std::memory_order_relaxed) != key) ix->gain_skip.store(0, std::memory_order_relaxed);
+    // Run / skip policy.  The level costs about the same whatever it prunes -- one sweep of the probed lists (to depth 32; with a
+    // threshold also the cells it removes), a level byte per document and query written and read twice -- and what it buys is the
+    // filter's time per candidate it removes (~0.1 ns of GPU time per 192-byte list block).  The device leaves (candidates, kept,
+    // posting entries swept) of each batch in pinned words; a context reads the words of ITS previous batch here -- never waited
+    // for: a batch still in flight simply has not reported -- and when the removed candidates would not have paid for the level,
+    // the handle skips it for 31 batches (255 when it was not even close) and then tries again.  With a threshold the level starts
+    // skipped (the metric corpus: it does not pay) and is tried for the first time after 63 batches.  Results do not depend on the
+    // decision.
+    const uint64_t key = ((uint64_t)(uint32_t)prm.n_ivf_probe << 40) ^ ((uint64_t)(uint32_t)cs->n_sel << 16) ^ (uint64_t)(uint32_t)LQP ^
+                         ((uint64_t)(prm.has_threshold ? 1u : 0u) << 63);
+    if (ix->gain_key.exchange(key, std::memory_order_relaxed) != key)
+      ix->gain_skip.store(prm.has_threshold ? 63 : 0, std::memory_order_relaxed);
     if (w.h_gain) {
-      const unsigned long long v = __atomic_exchange_n(w.h_gain, 0ull, __ATOMIC_RELAXED);
-      const double raw = (double)(v >> 32), kept = (double)(v & 0xFFFFFFFFull);
-      const double benefit_ms = (raw - kept) * 1e-7;                                  // the filter's ~0.06-0.2 ns of GPU time per candidate
-                                                                                      // (8 ms per 130 M at K = 2^16, 3.2 ms per 16 M at 2^19)
-      const double cost_ms = 2.0 * ((double)ix->n_docs / 1e7) * ((double)B / 64.0);   // measured: 2.0-2.4 ms at 10 M documents x 64 queries
+      const unsigned long long v = __atomic_exchange_n(&w.h_gain[0], 0ull, __ATOMIC_ACQUIRE);
+      const double raw = (double)(v >> 32), kept = (double)(v & 0xFFFFFFFFull), swept = (double)w.h_gain[1];
+      const double block_b = (double)ix->ublock_stride * (double)ix->code_bytes();
+      const double benefit_ms = (raw - kept) * 1e-7 * std::max(1.0, block_b / 192.0);   // 8 ms per 130 M candidates at K = 2^16
+      const double cost_ms = 0.8 * ((double)ix->n_docs / 1e7) * ((double)B / 64.0) + swept * 3e-9;   // passes + ~330 M entries per ms
       // (a report of a batch with other parameters says nothing about these)
-      if (raw > 0 && w.h_gain_key == key && benefit_ms < cost_ms) ix->gain_skip.store(31, std::memory_order_relaxed);
+      if (raw > 0 && w.h_gain_key == key && benefit_ms < cost_ms)
+        ix->gain_skip.store(benefit_ms > 0.7 * cost_ms ? 31 : 255, std::memory_order_relaxed);
     } else if (hipHostMalloc((void**)&w.h_gain, 64, hipHostMallocDefault) == hipSuccess) {
-      *w.h_gain = 0;
+      w.h_gain[0] = w.h_gain[1] = 0;
     } else {
       w.h_gain = nullptr;
       (void)hipGetLastError();
@@ -617,8 +622,10 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     }
   }
   // the level probes on its own to depth 32 where the search stops earlier: the bound's floor falls with the depth (np_kernels.h)
-  const int gain_depth = 32;
-  const bool gain_deep = gain_path && prm.n_ivf_probe < gain_depth && ix->K > gain_depth;
+  // ... and with a threshold it sweeps the cells the threshold removes too (bound-only): its own probe, without the threshold
+  const int gain_depth = std::max(32, prm.n_ivf_probe);
+  const bool gain_deep = gain_path && (prm.n_ivf_probe < gain_depth || prm.has_threshold) && ix->K > gain_depth;
+  if (gain_path && prm.has_threshold && !gain_deep) gain_path = false;
   const int s0_target = ix->tune.s3_gain_mult * cs->n_sel;
   // S0 takes whole histogram bins: the marginal bin may hold a few whole posting lists (documents in ONE probed cell share a bound)
   // S0 takes the bins above the marginal one whole and fills the rest of its slice from the marginal bin (documents in ONE probed
@@ -634,7 +641,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     NP_TRY(w.s0_meta.reserve((size_t)B * s0cap * 16));
     NP_TRY(w.s0_u.reserve((size_t)B * s0cap * 2));
     NP_TRY(w.gacc.reserve((size_t)B * ix->n_ranges * NP_GAIN_RANGE));   // one level byte per document and query
-    if (gain_deep) NP_TRY(w.gdeep.reserve(((size_t)B * G + (size_t)B * LQP + (size_t)B + (size_t)B * KP) * 4));
+    if (gain_deep) NP_TRY(w.gdeep.reserve(((size_t)B * G + (size_t)B * LQP + (size_t)B + (size_t)B * G + (size_t)B * KP) * 4));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
@@ -673,7 +680,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       add(w.ub_cursor.p, (size_t)3 * B * 4, 0);
       add(w.xcd_slots.p, ((size_t)max_rounds * 3 + 1) * slot_words * 4, 0xFFFFFFFFu);   // slots and tickets of every launch: -1
     }
-    if (gain_deep) add(w.gdeep.p, ((size_t)B * G + (size_t)B * LQP + (size_t)B) * 4, 0);   // marks, per-token thresholds, cell counts
+    if (gain_deep) add(w.gdeep.p, ((size_t)B * G + (size_t)B * LQP + (size_t)B + (size_t)B * G) * 4, 0);   // marks, per-token thresholds, cell counts, kept-cell bitmap
     if (gain_path) {
       add(w.gsmall.p, gs_bytes, 0);
       add(w.ghist.p, (size_t)B * (256 + NP_UB_BINS) * 4, 0);
@@ -788,14 +795,18 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       ProbeP p2 = pp;
       uint32_t* gd = w.gdeep.as<uint32_t>();
       p2.nprobe = gain_depth;
+      p2.has_thr = 0;          // every probed cell: the ones a threshold removes are swept as bound-only cells
       p2.cellbits = gd;
       p2.tauq = gd + (size_t)B * G;
       p2.n_cells = reinterpret_cast<int32_t*>(gd + (size_t)B * G + (size_t)B * LQP);
-      p2.cells = gd + (size_t)B * G + (size_t)B * LQP + (size_t)B;
+      p2.cells = gd + (size_t)2 * B * G + (size_t)B * LQP + (size_t)B;   // (the kept-cell bitmap sits in between)
       p2.ctr = nullptr;
       if (p2.lds_gm) probe_mark_kernel<4><<<dim3((unsigned)(LQP / 4), B), 256, gm_lds, st>>>(p2);
       else probe_mark_kernel<8><<<dim3((unsigned)(LQP / 8), B), 256, 0, st>>>(p2);
       probe_finish_kernel<<<dim3(NP_PROBE_NF, B), 256, 0, st>>>(p2);
+      if (prm.has_threshold)   // which of them make candidates: the cells the threshold kept
+        cells_to_bits_kernel<<<B, 256, 0, st>>>(w.cells.as<uint32_t>(), w.n_cells.as<int32_t>(), KP,
+                                                gd + (size_t)B * G + (size_t)B * LQP + (size_t)B);
     }
   }
   if (cs->timed) NP_HIP(hipEventRecord(cs->ctx->ev[2], st));
@@ -905,9 +916,11 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       const uint32_t* gd = w.gdeep.as<uint32_t>();
       g_tauq = gd + (size_t)B * G;
       gp.n_cells = reinterpret_cast<const int32_t*>(gd + (size_t)B * G + (size_t)B * LQP);
-      gp.cells = gd + (size_t)B * G + (size_t)B * LQP + (size_t)B;
+      gp.cells = gd + (size_t)2 * B * G + (size_t)B * LQP + (size_t)B;
     }
-    const uint32_t* g_real = gain_deep ? w.cellbits.as<uint32_t>() : nullptr;
+    // the cells whose documents are candidates: the search's own marks, or -- with a threshold -- the cells it kept
+    const uint32_t* g_real = !gain_deep ? nullptr
+                             : (prm.has_threshold ? w.gdeep.as<uint32_t>() + (size_t)B * G + (size_t)B * LQP + (size_t)B : w.cellbits.as<uint32_t>());
     gp.KP = KP;
     gp.ivf_off = ix->d_ivf_offsets;
     gp.ivf = ix->d_ivf;

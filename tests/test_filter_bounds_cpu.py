@@ -193,12 +193,14 @@ def probe(QC, nprobe):
     return marks, theta
 
 
-def gain_bound(QC, s, docs, nprobe, depth, acc_bits=15):
+def gain_bound(QC, s, docs, nprobe, depth, acc_bits=15, thr=None):
     """The level's arithmetic: ut_q = u(theta_q at the DEPTH), G(c) = sum_q max(0, u[q,c] - ut_q) for the cells marked at that
     depth, scaled by 2^-sh (rounded up) so that the sum over all of them fits the accumulator; U0 = base + (sum of the document's
     marked cells' scaled gains << sh).  Candidates = documents holding a cell the SEARCH probes (depth nprobe)."""
     u = u8_table(QC, s)
     real, _ = probe(QC, nprobe)
+    if thr is not None:        # search.rs:417-425: a probed cell is kept iff its best score over the tokens reaches the threshold;
+        real = real & (QC.max(axis=0) >= thr)   # the removed ones stay in the sweep as bound-only cells
     deep, theta = probe(QC, max(nprobe, depth))
     ut = u8_table(theta[:, None], s)[:, 0]
     G = np.maximum(u - ut[:, None], 0).sum(axis=0)               # [K]
@@ -215,17 +217,21 @@ def gain_bound(QC, s, docs, nprobe, depth, acc_bits=15):
 
 
 @pytest.mark.parametrize("seed", range(8))
-@pytest.mark.parametrize("nprobe,depth,acc_bits", [(4, 4, 15), (2, 8, 15), (8, 32, 15), (4, 16, 10)])
-def test_zeroth_level_bound_and_cut(seed, nprobe, depth, acc_bits):
+@pytest.mark.parametrize("nprobe,depth,acc_bits,thr", [(4, 4, 15, None), (2, 8, 15, None), (8, 32, 15, None), (4, 16, 10, None),
+                                                        (8, 8, 15, 0.45), (4, 16, 15, 0.3)])
+def test_zeroth_level_bound_and_cut(seed, nprobe, depth, acc_bits, thr):
     """U0 >= U for every candidate, at the probe's own depth and deeper (bound-only cells), with the gains scaled into a narrow
     accumulator; and the cut the pipeline makes with it -- tau0 = the n_sel-th largest LOWER bound among ANY set S0 of candidates
     (the ones with the largest U0, a random set, a set missing the best documents) minus the slack, candidates with U0 below it
-    dropped -- never removes a document of the true top n_sel of the candidates (ties included)."""
+    dropped -- never removes a document of the true top n_sel of the candidates (ties included).  With a centroid_score_threshold
+    the cells it removes stay in the sum as bound-only cells and only the kept cells' documents are candidates."""
     rng = np.random.default_rng(7000 + seed)
     Lq = int(rng.integers(1, 33))
     QC, s, docs = make_instance(rng, K=256, n_docs=500, Lq=Lq, ties=(seed % 3 == 2), codes_per_doc=(1, 4) if seed % 2 else (3, 30))
-    U0, cand, base, sh, real, deep = gain_bound(QC, s, docs, nprobe, depth, acc_bits)
-    assert (deep | ~real).all() and cand.any()
+    U0, cand, base, sh, real, deep = gain_bound(QC, s, docs, nprobe, depth, acc_bits, thr)
+    assert (deep | ~real).all()
+    if not cand.any():
+        return                 # the threshold removed every probed cell: no candidates, nothing to check
     if acc_bits == 10:
         assert sh > 0, "the narrow accumulator was meant to force a scaling"
     u = u8_table(QC, s)
@@ -251,6 +257,6 @@ def test_zeroth_level_bound_and_cut(seed, nprobe, depth, acc_bits):
             keep = cand & ((U0 >= tau0) | (tau0 <= 0))
             assert (keep | ~true_top).all(), f"n_sel={n_sel}: the zeroth level cut a document of the true top"
     # the level is not vacuous: with the best bounds as S0 something is dropped on the instances with real lists
-    if not seed % 2 and ci.size > 200 and depth >= 8:
+    if not seed % 2 and ci.size > 200 and depth >= 8 and thr is None:
         tau0 = nth_largest(Lb[order[:15]], 5) - slack
         assert (U0[ci] < tau0).any()

@@ -384,7 +384,8 @@ def test_zeroth_level_preserves_selection():
     tau0 -- the n_sel-th best exact lower bound among the ~3 n_sel documents with the largest sums -- enter the filter.  Several
     32768-document ranges, ragged and non-finite queries, every size of the S0 list and both launch forms of its exact bound: the
     selected documents, their order and their exact scores are those of the unfiltered path bit for bit, the level really
-    prunes, it never runs with a threshold, and n_candidates stays the size of the posting-list union."""
+    prunes -- with a threshold too, where the removed cells are swept as bound-only cells -- and n_candidates stays the size of the
+    posting-list union."""
     spec, a = make_arrays(num_docs=150000, num_centroids=4096, dim=128, nbits=4, doc_len_min=30, doc_len_max=70, seed=79)
     hx = hip_index(a)
     ox = oracle_index(a)
@@ -394,7 +395,7 @@ def test_zeroth_level_preserves_selection():
     bad[3, 5] = np.nan
     batch.append(bad)
     pruned_somewhere = False
-    for nfs, nprobe, thr in ((256, 32, None), (1024, 8, None), (64, 64, None), (256, 32, 0.4)):
+    for nfs, nprobe, thr in ((256, 32, None), (1024, 8, None), (64, 64, None), (256, 32, 0.4), (512, 8, 0.35)):
         p = P(n_full_scores=nfs, top_k=max(nfs // 4, 1), n_ivf_probe=nprobe, centroid_score_threshold=thr)
         hx.tune("s4_filter", 0)
         ref = hx.search_batch(batch, p)
@@ -410,9 +411,9 @@ def test_zeroth_level_preserves_selection():
                 assert np.array_equal(g.passage_ids, r.passage_ids), f"nfs={nfs} nprobe={nprobe} gain={gain}/{mult}/{direct} q{i}: selection changed"
                 assert np.array_equal(g.scores, r.scores), f"nfs={nfs} gain={gain} q{i}"
             assert st["n_candidates"] == n_union, (st["n_candidates"], n_union)
-            if gain == 0 or thr is not None:
+            if gain == 0:
                 assert st["n_level0"] == 0, st
-            else:
+            else:     # with a threshold too: the cells it removes are swept as bound-only cells
                 assert 0 < st["n_level0"] <= st["n_candidates"], st
                 pruned_somewhere |= st["n_level0"] < st["n_candidates"] // 2
     assert pruned_somewhere

@@ -31,6 +31,8 @@ TCS = os.environ.get("SIM_TCS", "0.4")
 TCS = None if TCS.lower() == "none" else float(TCS)
 RAND = int(os.environ.get("SIM_RAND256", "51"))
 NSEL = int(os.environ.get("SIM_NSEL", "1024"))
+SWEEP_REMOVED = int(os.environ.get("SIM_SWEEP_REMOVED", "0"))   # 1: the cells a threshold removes are swept as BOUND-ONLY cells (their
+                                                                # gains count, their documents are no candidates): theta stays theta_q
 EXACT_SHARE = float(os.environ.get("SIM_EXACT_SHARE", "1.0"))   # share of a chunk's candidates (largest UB0) that get exact scores
 K = 65536
 spec = synth.SynthSpec(num_docs=NDOCS, num_centroids=K, dim=128, nbits=4, doc_len_min=300, doc_len_max=300,
@@ -64,6 +66,8 @@ def scan(args):
         idx = np.nonzero(hit)[0]
         cc = cs[idx].astype(np.int64)
         kk = kh[idx]
+        if SWEEP_REMOVED:      # gains of every probed cell the document holds (kept or removed)
+            kk = (G["probed"][qi][cs] & first)[idx]
         ub0 = thp.sum() + np.where(kk, gain[cc], 0.0).sum(axis=1)
         ncell = kk.sum(axis=1)
         n_ex = idx.size if EXACT_SHARE >= 1.0 else max(int(idx.size * EXACT_SHARE), min(idx.size, 64))
@@ -84,7 +88,7 @@ def scan(args):
 def main():
     cen = synth.centroids(spec)
     qs, src = synth.make_queries(spec, NQ, n_tokens=LQ, cen=cen)
-    G["kept"], G["gain"], G["QC"], G["thp"] = [], [], [], []
+    G["kept"], G["gain"], G["QC"], G["thp"], G["probed"] = [], [], [], [], []
     for q in qs:
         QC = (q @ cen.T).astype(np.float32)              # [Lq, K]
         P = np.zeros(K, bool)
@@ -98,10 +102,11 @@ def main():
             kept &= QC.max(axis=0) >= TCS
         removed = P & ~kept
         thp = theta.copy()
-        if removed.any():
+        if removed.any() and not SWEEP_REMOVED:
             thp = np.maximum(thp, QC[:, removed].max(axis=1))
-        gain = np.where(kept, np.maximum(QC - thp[:, None], 0.0).sum(axis=0), 0.0).astype(np.float32)
-        G["kept"].append(kept); G["gain"].append(gain); G["QC"].append(QC); G["thp"].append(thp)
+        gset = P if SWEEP_REMOVED else kept
+        gain = np.where(gset, np.maximum(QC - thp[:, None], 0.0).sum(axis=0), 0.0).astype(np.float32)
+        G["kept"].append(kept); G["gain"].append(gain); G["QC"].append(QC); G["thp"].append(thp); G["probed"].append(P)
         print(f"query: probed {int(P.sum())} kept {int(kept.sum())} sum theta {theta.sum():.2f} sum theta' {thp.sum():.2f} "
               f"gain of kept cells: max {gain.max():.2f} mean {gain[kept].mean():.2f} total {gain.sum():.1f}", flush=True)
     t0 = time.time()

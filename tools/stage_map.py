@@ -31,7 +31,7 @@ STAGE = {
     # (round 6: the zeroth filter level -- three sweeps of the probed posting lists with per-document gain sums, thresholds, counts.
     # Its S0 list takes approx_ub_kernel / ub_thr_kernel inside these events too; they stay listed under S4 by name: the level
     # runs only without a centroid_score_threshold, i.e. never on the default workload the PMC traffic file is keyed to)
-    "gain_prep_kernel": S3, "gain_sweep_kernel": S3, "gain_emit_kernel": S3, "gain_thr_kernel": S3, "gain_count_kernel": S3,
+    "gain_prep_kernel": S3, "gain_sweep_kernel": S3, "cells_to_bits_kernel": S2, "gain_emit_kernel": S3, "gain_thr_kernel": S3, "gain_count_kernel": S3,
     # ev[3] .. ev[4]: the two-level upper-bound filter and the exact approximate scores of the survivors
     "approx_hotp_kernel": S4, "approx_hot_kernel": S4, "approx_ub_kernel": S4, "ub_thr_kernel": S4, "ub_cut_kernel": S4,
     "approx_xcd_kernel": S4, "approx_kernel": S4, "approx_stream_kernel": S4, "gcut_kernel": S4, "approx_matvec_kernel": S4,
