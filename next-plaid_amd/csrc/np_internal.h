@@ -228,6 +228,7 @@ struct DeviceIndex {
   Tuning tune;
   // zeroth filter level, run / skip policy (s3_gain = 1): batches left to skip, and the parameters the count belongs to
   mutable std::atomic<int> gain_skip{0};
+  mutable std::atomic<int> gain_run{0};    // 1: the last report of these parameters said the level pays (no guard between batches)
   mutable std::atomic<uint64_t> gain_key{0};
   CodeArr codes() const { return CodeArr{d_codes, code_wide}; }
   CodeArr ucodes() const { return CodeArr{d_ucodes, code_wide}; }

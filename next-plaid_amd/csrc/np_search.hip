@@ -586,6 +586,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
                    subset_len < 0 && ix->n_docs > 0 && cs->n_sel > 0 && B > 0 &&
                    (int64_t)std::max(prm.n_ivf_probe, 32) * maxLq <= 16384;   // probed cells per query: the scaled gains of all of
                                                                                // them must fit a 15-bit accumulator (gain_prep_kernel)
+  const bool gain_possible = gain_path;   // the level's buffers are reserved whenever it MAY run: a first run in the middle of a
+                                          // service's life must not stall every stream on a dozen hipMalloc calls
   if (gain_path && ix->tune.s3_gain == 1) {
     // Run / skip policy.  The level costs about the same whatever it prunes -- one sweep of the probed lists (to depth 32; with a
     // threshold also the cells it removes), a level byte per document and query written and read twice -- and what it buys is the
@@ -597,8 +599,10 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     // decision.
     const uint64_t key = ((uint64_t)(uint32_t)prm.n_ivf_probe << 40) ^ ((uint64_t)(uint32_t)cs->n_sel << 16) ^ (uint64_t)(uint32_t)LQP ^
                          ((uint64_t)(prm.has_threshold ? 1u : 0u) << 63);
-    if (ix->gain_key.exchange(key, std::memory_order_relaxed) != key)
+    if (ix->gain_key.exchange(key, std::memory_order_relaxed) != key) {
+      ix->gain_run.store(0, std::memory_order_relaxed);
       ix->gain_skip.store(prm.has_threshold ? 63 : 0, std::memory_order_relaxed);
+    }
     if (w.h_gain) {
       const unsigned long long v = __atomic_exchange_n(&w.h_gain[0], 0ull, __ATOMIC_ACQUIRE);
       const double raw = (double)(v >> 32), kept = (double)(v & 0xFFFFFFFFull), swept = (double)w.h_gain[1];
@@ -606,8 +610,14 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       const double benefit_ms = (raw - kept) * 1e-7 * std::max(1.0, block_b / 192.0);   // 8 ms per 130 M candidates at K = 2^16
       const double cost_ms = 0.8 * ((double)ix->n_docs / 1e7) * ((double)B / 64.0) + swept * 3e-9;   // passes + ~330 M entries per ms
       // (a report of a batch with other parameters says nothing about these)
-      if (raw > 0 && w.h_gain_key == key && benefit_ms < cost_ms)
-        ix->gain_skip.store(benefit_ms > 0.7 * cost_ms ? 31 : 255, std::memory_order_relaxed);
+      if (raw > 0 && w.h_gain_key == key) {
+        if (benefit_ms < cost_ms) {
+          ix->gain_run.store(0, std::memory_order_relaxed);
+          ix->gain_skip.store(benefit_ms > 0.7 * cost_ms ? 31 : 255, std::memory_order_relaxed);
+        } else {
+          ix->gain_run.store(1, std::memory_order_relaxed);
+        }
+      }
     } else if (hipHostMalloc((void**)&w.h_gain, 64, hipHostMallocDefault) == hipSuccess) {
       w.h_gain[0] = w.h_gain[1] = 0;
     } else {
@@ -619,12 +629,15 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
       gain_path = false;
     } else {
       w.h_gain_key = key;
+      // a trial run: the other contexts wait for its report instead of each paying for one
+      if (!ix->gain_run.load(std::memory_order_relaxed)) ix->gain_skip.store(3, std::memory_order_relaxed);
     }
   }
   // the level probes on its own to depth 32 where the search stops earlier: the bound's floor falls with the depth (np_kernels.h)
   // ... and with a threshold it sweeps the cells the threshold removes too (bound-only): its own probe, without the threshold
   const int gain_depth = std::max(32, prm.n_ivf_probe);
-  const bool gain_deep = gain_path && (prm.n_ivf_probe < gain_depth || prm.has_threshold) && ix->K > gain_depth;
+  const bool deep_wanted = (prm.n_ivf_probe < gain_depth || prm.has_threshold) && ix->K > gain_depth;
+  const bool gain_deep = gain_path && deep_wanted;
   if (gain_path && prm.has_threshold && !gain_deep) gain_path = false;
   const int s0_target = ix->tune.s3_gain_mult * cs->n_sel;
   // S0 takes whole histogram bins: the marginal bin may hold a few whole posting lists (documents in ONE probed cell share a bound)
@@ -634,14 +647,14 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   // u32 words of w.gsmall: [0, 4B) base / shift / floor bin / 0, then B each: n_raw, thr0, cut0, n_s0, n_emit, n_direct, round_of0, order0, cursor0,
   // n_hi, n_hi_emit, n_marg, lcut; 4 words round_tab0; 6 words = 3 x u64 batch report; then (8-byte aligned) cand_base0 i64 [B]
   const size_t gs_words = (size_t)17 * B + 4 + 8, gs_bytes = (gs_words + (gs_words & 1)) * 4 + (size_t)B * 8;
-  if (gain_path) {
+  if (gain_possible) {
     NP_TRY(w.gain.reserve((size_t)B * KP * 2));
     NP_TRY(w.gsmall.reserve(gs_bytes));
     NP_TRY(w.ghist.reserve((size_t)B * (256 + NP_UB_BINS) * 4));   // levels of all candidates; exact lower bounds of S0
     NP_TRY(w.s0_meta.reserve((size_t)B * s0cap * 16));
     NP_TRY(w.s0_u.reserve((size_t)B * s0cap * 2));
     NP_TRY(w.gacc.reserve((size_t)B * ix->n_ranges * NP_GAIN_RANGE));   // one level byte per document and query
-    if (gain_deep) NP_TRY(w.gdeep.reserve(((size_t)B * G + (size_t)B * LQP + (size_t)B + (size_t)B * G + (size_t)B * KP) * 4));
+    if (deep_wanted) NP_TRY(w.gdeep.reserve(((size_t)B * G + (size_t)B * LQP + (size_t)B + (size_t)B * G + (size_t)B * KP) * 4));
   }
   NP_TRY(w.sel_keys.reserve((size_t)B * nsel1 * 8));
   NP_TRY(w.sel_doc.reserve((size_t)B * nsel1 * 4));
