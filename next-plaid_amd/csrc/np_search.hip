@@ -595,13 +595,14 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
     // posting entries swept) of each batch in pinned words; a context reads the words of ITS previous batch here -- never waited
     // for: a batch still in flight simply has not reported -- and when the removed candidates would not have paid for the level,
     // the handle skips it for 31 batches (255 when it was not even close) and then tries again.  With a threshold the level starts
-    // skipped (the metric corpus: it does not pay) and is tried for the first time after 63 batches.  Results do not depend on the
-    // decision.
+    // skipped (the metric corpus: it does not pay) and is tried for the first time after 511 batches -- a trial costs a short-lived
+    // process more than the level's ~1.3 ms (the first launch of its kernels loads their code: ~40 ms measured inside a 300-batch
+    // bench), a service never notices.  Results do not depend on the decision.
     const uint64_t key = ((uint64_t)(uint32_t)prm.n_ivf_probe << 40) ^ ((uint64_t)(uint32_t)cs->n_sel << 16) ^ (uint64_t)(uint32_t)LQP ^
                          ((uint64_t)(prm.has_threshold ? 1u : 0u) << 63);
     if (ix->gain_key.exchange(key, std::memory_order_relaxed) != key) {
       ix->gain_run.store(0, std::memory_order_relaxed);
-      ix->gain_skip.store(prm.has_threshold ? 63 : 0, std::memory_order_relaxed);
+      ix->gain_skip.store(prm.has_threshold ? 511 : 0, std::memory_order_relaxed);
     }
     if (w.h_gain) {
       const unsigned long long v = __atomic_exchange_n(&w.h_gain[0], 0ull, __ATOMIC_ACQUIRE);

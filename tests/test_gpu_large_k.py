@@ -84,6 +84,7 @@ def test_production_path_selects_the_oracles_set(big):
     path] -> selection -> MaxSim) with top_k = n_sel returns the whole selected set: it must be the oracle's, scores within
     the stated f32 tolerance; and the filter must actually have pruned."""
     name, spec, hx, ox, qs, src, cbs = big
+    hx.tune("s3_gain", 2)      # pinned on: the default's run / skip rule may decide differently for calls whose counters are compared
     for nfs, nprobe, thr in ((1024, 32, 0.4), (2048, 8, None)):
         k = nfs // 4
         p = P(n_full_scores=nfs, top_k=k, n_ivf_probe=nprobe, centroid_score_threshold=thr, centroid_batch_size=cbs)
@@ -122,6 +123,7 @@ def test_production_path_selects_the_oracles_set(big):
     for i, (g, o) in enumerate(zip(got, ref)):
         assert_ranking_close(g.passage_ids, g.scores, o.passage_ids, o.scores, RTOL_F32, f"{name} default q{i}")
         assert g.passage_ids[0] == src[i]
+    hx.tune("s3_gain", 1)
 
 
 def test_split_bf16_centroid_scores_opt_in(big):

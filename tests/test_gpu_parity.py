@@ -360,6 +360,8 @@ def test_s4_two_level_filter_preserves_selection(mid, tuned):
             assert rows[100] < rows[0], rows        # the hot level gathers fewer table rows than the exact bound alone
     hx.tune("s4_planes", 1)
     # the floored exact level really skips table rows (n_cand_codes counts the rows requested) and keeps the results
+    # (the zeroth level pinned off: its run / skip rule may decide differently for the two calls whose row counts are compared)
+    hx.tune("s3_gain", 0)
     hx.tune("s4_hot", 100)
     p2 = P(n_full_scores=512, top_k=128, n_ivf_probe=32, centroid_score_threshold=None)
     hx.tune("s4_warm", 1000)

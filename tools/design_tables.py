@@ -20,7 +20,7 @@ GROUPS = {
     f"{R}_bench_shard_sizes.jsonl": ["shard_5m", "shard_2500k", "shard_1250k", "shard_1250k_rccl"],
     f"{R}_bench_variants_10m.jsonl": ["prec0", "prec1", "prec3", "single_level_10m"],
     f"{R}_bench_regimes.jsonl": ["api_default", "tcs_none", "dist05", "dist08", "lq48_10m", "nfs8192_10m", "colgrep_10m", "k19_10m",
-                                 "k19_split_10m", "k19_rest", "k19_rest_lq48_nfs8192", "c3_np32", "c4_k18_12500k", "k20_2500k"],
+                                 "k19_split_10m", "k19_rest", "k19_rest_lq48_nfs8192", "c3_np32", "c4_k18_12500k", "k20_2500k", "dist05_gain", "dist08_gain"],
 }
 SINGLES = {f"{R}_bench_default_10m.json": "default_10m", f"{R}_bench_1m.json": "1m", f"{R}_bench_c4_shard_12500k.json": "c4_shard_12500k",
            f"{R}_bench_disk_1m.json": "disk1m"}
@@ -139,7 +139,9 @@ def tables():
         return "—" if not pv else f"{pv['topk_ids_identical']}/{pv['queries']}"
 
     dist = ["| distinct codes per token (`--rand256`) | candidates / query | table rows / batch | queries/s | S3 ms | S4 ms | CPU oracle q/s | top-10 = oracle |", "|---|---:|---:|---:|---:|---:|---:|---:|"]
-    for lab, d in (("0.23 (51, the default corpus)", d10), ("0.50 (121)", reg.get("dist05")), ("0.80 (200)", reg.get("dist08"))):
+    for lab, d in (("0.23 (51, the default corpus)", d10), ("0.50 (121)", reg.get("dist05")),
+                   ("0.50 with the zeroth level on (`NP_S3_GAIN=2`: where the run / skip rule arrives after its first trial)", reg.get("dist05_gain")),
+                   ("0.80 (200)", reg.get("dist08")), ("0.80 with the zeroth level on", reg.get("dist08_gain"))):
         if not d:
             continue
         s = d["stages"]
