@@ -215,8 +215,8 @@ int np_hip_index_write_dir(const char* index_dir, const np_index_arrays* arrays,
  * "s4_qm" 0/1, "s4_pnbx" 8..512, "s4_warm" 0..1000 (per-mille of centroids whose rows the exact filter level still gathers
  * for the S2 lists; 1000 = every row; 0 = the default: by query length and mean distinct-code count), "s4_hot_auto" >= 0 (candidates
  * per query up to which "s4_hot" applies as given; beyond it the share falls with the count^(-1/3); 0 = always as given),
- * "ub_ncut" 1..512, "s3_bisect" 0/1, "s3_gain" 0/1/2 (zeroth filter level in S3, only without a centroid_score_threshold: 0 = off -- read at open too: its range
- * table is not built --, 2 = whenever it applies, 1 = the default: 2 with a run / skip policy fed by the previous batches' pruning),
+ * "ub_ncut" 1..512, "s3_bisect" 0/1, "s3_gain" 0/1/2 (zeroth filter level in S3: 0 = off -- read at open too: its range table is not built --, 2 = whenever it
+ * applies, 1 = the default: 2 with a run / skip policy fed by the previous batches' pruning; with a centroid_score_threshold it starts skipped),
  * "s3_gain_mult" 1..16, "s3_gain_direct" 0..64, "s1_split" 0/1 (the only knob that changes values: see INTEGRATION.md),
  * "s3_slices" 0/1, "ub_nt" 0..2, "ub_steal" >= 1, "ub_nbx" 8..256, "ub_direct" 0..16, "ub_static" 0/1, "hot_static" 0/1, "s6_xcd" 0/1, "s6_tiles" 0/1, "s6_lds" 0..2, "gemm_cpw" 1/2, "exact_rowmax" 0/1.
  * Results are identical for every setting except "s1_split"; not synchronised with concurrent searches.  Unknown name:
