@@ -535,6 +535,16 @@ __global__ void __launch_bounds__(256) ivf_split_kernel(const uint32_t* __restri
   split[i] = a;
 }
 
+// the planner's candidate bound (np_internal.h ivf_top_prefix), from the host copy of the list offsets
+static void set_ivf_bound(DeviceIndex* ix, const int64_t* ioff) {
+  const int64_t K = ix->K;
+  std::vector<int64_t> len((size_t)K);
+  for (int64_t c = 0; c < K; ++c) len[(size_t)c] = ioff[c + 1] - ioff[c];
+  std::sort(len.begin(), len.end(), std::greater<int64_t>());
+  ix->ivf_top_prefix.assign((size_t)K + 1, 0);
+  for (int64_t c = 0; c < K; ++c) ix->ivf_top_prefix[(size_t)c + 1] = ix->ivf_top_prefix[(size_t)c] + len[(size_t)c];
+}
+
 static int build_ivf_split(DeviceIndex* ix) {
   ix->d_ivf_split = nullptr;
   ix->n_ranges = 0;
@@ -1132,6 +1142,7 @@ int build_device_index(const HostIndex& h, const np_open_opts* opts_in, DeviceIn
     if (!ivf.empty()) NP_HIP(hipMemcpy(ix->d_ivf, ivf.data(), ivf.size() * 4, hipMemcpyHostToDevice));
     NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
     NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
+    set_ivf_bound(ix, ioff.data());
   }
   trace.mark("posting lists");
   NP_TRY(sort_tokens(ix));
@@ -1366,6 +1377,7 @@ static int build_ivf_from_ucodes(DeviceIndex* ix, const int64_t* d_uoff) {
   }
   NP_TRY(dev_alloc(&ix->d_ivf_offsets, ioff.size(), &ix->device_bytes));
   NP_HIP(hipMemcpy(ix->d_ivf_offsets, ioff.data(), ioff.size() * 8, hipMemcpyHostToDevice));
+  set_ivf_bound(ix, ioff.data());
   NP_HIP(hipDeviceSynchronize());
   ix->ivf_sorted = true;   // (code, document) pairs radix-sorted, ranges ascending: every list ascends
   return NP_OK;

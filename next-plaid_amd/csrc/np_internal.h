@@ -216,6 +216,10 @@ struct DeviceIndex {
   uint32_t* d_ivf_split = nullptr;   // [K][n_ranges + 1] (derived, ascending lists only): entries of list c with id < 32768 r -- the
                                   // zeroth filter level's blocks read their range's part of a posting list without a bisection
   int n_ranges = 0;               // ceil(n_docs / 32768)
+  // ivf_top_prefix[i] = entries of the i longest posting lists together (host side, i <= K): a query that probes c cells cannot
+  // have more candidates than ivf_top_prefix[c] (search.rs:427-452 unions the probed cells' lists), which is what the workspace
+  // planner sizes the candidate pool and the number of pool rounds for -- n_docs per query only when the lists do not say less
+  std::vector<int64_t> ivf_top_prefix;
   size_t device_bytes = 0;
   np_open_opts opts{};
   // per-context scratch budget the planner uses.  A caller-given workspace_bytes is kept as it is; the default (what the device

@@ -4117,174 +4117,220 @@ __global__ void __launch_bounds__(64 * WPB) approx_hotp_kernel(
 // ---------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// one wave per listed document; lanes (q = lane & 31, half = lane >> 5): half h takes the document's distinct codes
-// h, h+2, ...; 32 query tokens at a time
+// Approximate scores of the listed documents in unrolled_dot's arithmetic, as a register-blocked product on the vector ALUs.
+//
+// Work unit: a wave takes NP_MV_DOCS consecutive listed documents and walks the concatenation of their distinct-code lists
+// 16 x NP_MV_PQ (document, code) pairs at a time.  A QUAD of lanes owns NP_MV_PQ pairs and splits unrolled_dot's eight partial
+// sums between its lanes: lane kp = lane & 3 keeps (p[2kp], p[2kp+1]) of each of the quad's pairs, i.e. it multiplies
+// x[8i + 2kp + {0,1}] by y[8i + 2kp + {0,1}] for i = 0, 1, ... in order -- one v_pk_mul_f32 and one v_pk_add_f32 per (pair, i),
+// multiply THEN add, no FMA, exactly numeric_util::unrolled_dot's chains.  The lane's quarter of the quad's centroid rows sits in
+// registers for the whole chunk (NP_MV_PQ x DIM / 4 floats); the query token's quarter row is DIM/4 floats read from LDS (DIM/16
+// ds_read_b128 per token, a token ahead of its use).  The fold ((p0+p4) + (p1+p5)) + (p2+p6) + (p3+p7), added to 0 one pair at a
+// time, crosses the quad with four DPP operands per pair.  Nothing else touches LDS on the arithmetic path.
+//
+// Why this shape -- kernel time per batch of 64 queries, K = 2^19, t_cs None, nprobe 8, ~1 030 listed documents x ~72 distinct
+// codes per query (profiles/r06_ab_runs.md):
+//   round 5: one document per wave, lanes = tokens x two codes, the centroid row read from LDS by every lane     1.42 ms
+//   one lane per pair, the query row in SGPRs (scalar loads): 64 queries x 16 KB thrash the scalar cache         2.70 ms
+//   one lane per pair, the query row broadcast from LDS to every lane (512 B per lane and token)                 1.99 ms
+//   one lane per pair, a quad-replicated query row, v_mul_f32_dpp quad broadcasts                                1.54 ms
+//   the partial sums split over the quad (this kernel), 4 pairs per quad, 8 documents per wave (2 waves/SIMD)    1.43 ms
+//   ... the same with unpacked v_mul_f32 / v_add_f32: packed f32 is not the slower form here                     1.76 ms
+//   2 pairs per quad (161 VGPRs, 3 waves/SIMD) 1.31 ms; 1 pair per quad 1.49 ms; 2 pairs, 4 documents per wave   1.20 ms
+// The arithmetic alone (DIM packed multiplies + DIM packed adds per 16 x NP_MV_PQ pairs and token) is ~0.6 ms of that, the row
+// gather (2.4 GB of 512-byte rows out of a 268 MB table) ~0.4 ms when nothing else runs; a wave does them one after the other, so
+// occupancy -- registers -- decides how much of the gather hides.
+// The per-token maxima over a document's codes are taken over a 32-token tile of sums in LDS (`if s > max`, search.rs:286-291 --
+// the maximum's VALUE does not depend on the order the codes are visited in), and lane d adds document d's maxima in token order
+// (search.rs:294-297), continuing from the previous 32-token tile's sum for longer queries.
 // TAIL: the index files' dim (ldim <= DIM, rows zero-padded) is not a multiple of 8 -- unrolled_dot adds the last ldim % 8
-// products one by one AFTER the eight partial sums, so the padded row cannot simply run through the 8-wide loop.
+// products one by one AFTER the eight partial sums.  That (rare) geometry takes the plain form: one lane per pair, the query
+// row through scalar loads.
+#ifndef NP_MV_DOCS
+#define NP_MV_DOCS 4
+#endif
+#ifndef NP_MV_PQ
+#define NP_MV_PQ 2
+#endif
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
 template <int DIM, bool TAIL>
-__global__ void __launch_bounds__(256) approx_matvec_kernel(const float* __restrict__ qrows, const int32_t* __restrict__ qoff,
-                                                            const float* __restrict__ centroids,
-                                                            const uint4* __restrict__ meta, const int32_t* __restrict__ n_list,
-                                                            RoundPlan rp, int round, CodeArr codes,
-                                                            float* __restrict__ approx, int ldim) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
+approx_matvec_kernel(const float* __restrict__ qrows, const int32_t* __restrict__ qoff, const float* __restrict__ centroids,
+                     const uint4* __restrict__ meta, const int32_t* __restrict__ n_list, RoundPlan rp, int round, CodeArr codes,
+                     float* __restrict__ approx, int ldim) {
 #pragma clang fp contract(off)
-  constexpr int QS = DIM + 4;   // LDS row stride (floats): conflict-free b128 reads across 32 rows
-  __shared__ float sQ[32 * QS];
-  __shared__ float sC[4][2][DIM];
-  __shared__ float sM[4][64];
+  constexpr int D = NP_MV_DOCS;
+  constexpr int PQ = TAIL ? 4 : NP_MV_PQ;   // pairs of a quad
+  constexpr int CH = 16 * PQ;               // pairs of a chunk
+  constexpr int SS = CH + 4;                // row stride of the tile of sums (floats; 16-byte rows)
+  constexpr int XK = DIM / 4 + 4;           // a k-part's quarter row (+16 B: the four parts start on distinct banks)
+  constexpr int XT = 4 * XK;                // a token
+  __shared__ __attribute__((aligned(16))) float sS[4][32 * SS];
+  __shared__ float sM[4][D][33];
+  __shared__ __attribute__((aligned(16))) float sX[TAIL ? 4 : 32 * XT];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (rp.round_of[b] != round) return;
   const int n = n_list[b];
   const int64_t pbase = rp.cand_base[b];
   const int q0 = qoff[b], Lq = qoff[b + 1] - q0;
-  const int ql = lane & 31, half = lane >> 5;
-  const int ndoc_iter = (n + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
-  if constexpr (!TAIL) {
-    if (Lq <= 32) {
-      // One query tile (the usual case): the lane's query row lives in REGISTERS for the whole block -- the kernel is bound by
-      // LDS bandwidth (per (token, code) pair a lane read its 512-byte query row AND the 512-byte centroid row from LDS: four
-      // SIMDs ask the CU's one LDS for 4 x 512 cycles of reads per 512 cycles of packed-f32 VALU work), and the query row is
-      // the half that never changes.  Same arithmetic, same order: eight partial sums, multiply then add.
-      for (int w = tid; w < 32 * (DIM / 4); w += 256) {
-        const int r = w / (DIM / 4), c4 = w - r * (DIM / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < Lq) v = *reinterpret_cast<const float4*>(qrows + (int64_t)(q0 + r) * DIM + 4 * c4);
-        *reinterpret_cast<float4*>(&sQ[r * QS + 4 * c4]) = v;
+  const int ngroups = (n + D - 1) / D;
+  const int kfull = TAIL ? (ldim & ~7) : DIM;
+  const int ql = lane & 31, half = lane >> 5, kp = lane & 3;
+  for (int qt = 0; qt < Lq; qt += 32) {              // block-uniform (barriers inside)
+    const int nq = min(32, Lq - qt);
+    if constexpr (!TAIL) {
+      __syncthreads();
+      for (int w = tid; w < 32 * DIM; w += 256) {    // x[t][k] -> part (k % 8) / 2, slot 2 (k / 8) + (k & 1)
+        const int t = w / DIM, k = w - t * DIM;
+        sX[t * XT + ((k & 7) >> 1) * XK + 2 * (k >> 3) + (k & 1)] = t < nq ? qrows[(int64_t)(q0 + qt + t) * DIM + k] : 0.f;
       }
       __syncthreads();
-      float4 xr[DIM / 4];
+    }
+    for (int g = (int)blockIdx.x * 4 + wave; g < ngroups; g += (int)gridDim.x * 4) {
+      const int i0 = g * D;
+      const bool dl = lane < D && i0 + lane < n;
+      const uint4 m = meta[pbase + (dl ? i0 + lane : 0)];
+      const int nd = dl ? (int)m.y : 0;
+      const uint32_t cl_lo = m.z, cl_hi = m.w & 0xFFu;
+      int incl = nd;                          // lanes 0..D-1: where document `lane`'s codes start in the group's pair sequence
 #pragma unroll
-      for (int k4 = 0; k4 < DIM / 4; ++k4) xr[k4] = *reinterpret_cast<const float4*>(&sQ[ql * QS + 4 * k4]);
-      for (int it = 0; it < ndoc_iter; ++it) {
-        const int i = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
-        const bool live = i < n;
-        const uint4 m = meta[pbase + (live ? i : 0)];
-        const int nd = live ? (int)m.y : 0;
-        const int64_t cl = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
-        float mx = NP_NEG_INF;
-        // The step's centroid row is one global round trip behind its code: a step that fetched code -> row -> LDS -> compute in
-        // turn was a chain of ~1.5 us per pair of codes (34 steps per document).  The document's codes are read 64 at a time into
-        // a register per lane (a step's code comes by ds_bpermute), and the NEXT step's rows are requested before this step's
-        // arithmetic.
-        for (int c0 = 0; c0 < nd; c0 += 64) {
-          const int ncs = min(64, nd - c0);
-          const uint32_t cr0 = c0 + lane < nd ? codes[cl + c0 + lane] : 0u;
-          auto row_piece = [&](int jj) {   // this lane's 16 bytes of the row of code jj of the chunk (clamped: a duplicate of the last)
-            const uint32_t c = (uint32_t)__shfl((int)cr0, min(jj, ncs - 1));
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ql < DIM / 4) v = reinterpret_cast<const float4*>(centroids + (int64_t)c * DIM)[ql];
-            return v;
-          };
-          float4 nxt = row_piece(half);
-          for (int j0 = 0; j0 < ncs; j0 += 2) {
-            const int j = j0 + half;
-            const float4 cur = nxt;
-            if (j0 + 2 < ncs) nxt = row_piece(j0 + 2 + half);
-            if (ql < DIM / 4) *reinterpret_cast<float4*>(&sC[wave][half][4 * ql]) = cur;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+      for (int o = 1; o < D; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      const int excl = incl - nd;
+      int st[D + 1];                          // wave-uniform
+#pragma unroll
+      for (int k = 0; k < D; ++k) st[k] = __builtin_amdgcn_readlane(excl, k);
+      st[D] = __builtin_amdgcn_readlane(incl, D - 1);
+      const int total = st[D];
+      for (int w = lane; w < D * 33; w += 64) (&sM[wave][0][0])[w] = NP_NEG_INF;
+      for (int c0 = 0; c0 < total; c0 += CH) {
+        const int p = min(c0 + lane, total - 1);        // lanes past the end repeat the last pair (their sums are never read)
+        int d = 0;
+#pragma unroll
+        for (int k = 1; k < D; ++k) d += (p >= st[k]) ? 1 : 0;
+        const int j = p - __shfl(excl, d);
+        const int64_t cl = (int64_t)(uint32_t)__shfl((int)cl_lo, d) | ((int64_t)(uint32_t)__shfl((int)cl_hi, d) << 32);
+        const uint32_t code = codes[cl + j];
+        if constexpr (TAIL) {
+          const float4* src = reinterpret_cast<const float4*>(centroids + (int64_t)code * DIM);
+          float4 cr[DIM / 4];
+#pragma unroll
+          for (int k4 = 0; k4 < DIM / 4; ++k4) cr[k4] = src[k4];
+          for (int qq = 0; qq < nq; ++qq) {
+            const float* xq = qrows + (int64_t)(q0 + qt + qq) * DIM;      // wave-uniform: scalar loads
             f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, p45 = {0.f, 0.f}, p67 = {0.f, 0.f};
-            const float* yc = &sC[wave][half][0];
 #pragma unroll
             for (int k = 0; k < DIM; k += 8) {
-              const float4 x0 = xr[k / 4], x1 = xr[k / 4 + 1];
-              const float4 y0 = *reinterpret_cast<const float4*>(yc + k), y1 = *reinterpret_cast<const float4*>(yc + k + 4);
-              p01 = p01 + (f32x2){x0.x, x0.y} * (f32x2){y0.x, y0.y};
-              p23 = p23 + (f32x2){x0.z, x0.w} * (f32x2){y0.z, y0.w};
-              p45 = p45 + (f32x2){x1.x, x1.y} * (f32x2){y1.x, y1.y};
-              p67 = p67 + (f32x2){x1.z, x1.w} * (f32x2){y1.z, y1.w};
+              if (k < kfull) {
+                const float4 y0 = cr[k / 4], y1 = cr[k / 4 + 1];
+                p01 = p01 + (f32x2){xq[k], xq[k + 1]} * (f32x2){y0.x, y0.y};
+                p23 = p23 + (f32x2){xq[k + 2], xq[k + 3]} * (f32x2){y0.z, y0.w};
+                p45 = p45 + (f32x2){xq[k + 4], xq[k + 5]} * (f32x2){y1.x, y1.y};
+                p67 = p67 + (f32x2){xq[k + 6], xq[k + 7]} * (f32x2){y1.z, y1.w};
+              }
             }
             float sum = 0.f;
             sum = sum + (p01.x + p45.x);
             sum = sum + (p01.y + p45.y);
             sum = sum + (p23.x + p67.x);
             sum = sum + (p23.y + p67.y);
-            if (j < ncs && sum > mx) mx = sum;          // search.rs:286-291 (codes in list order: chunks ascend)
-            __builtin_amdgcn_wave_barrier();            // sC is rewritten by the next step
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+              const float4 y = cr[k / 4];
+              const float yk = (k & 3) == 0 ? y.x : (k & 3) == 1 ? y.y : (k & 3) == 2 ? y.z : y.w;
+              if (k >= kfull && k < ldim) sum = sum + xq[k] * yk;
+            }
+            sS[wave][qq * SS + lane] = sum;
+          }
+        } else {
+          // the quad's PQ pairs: this lane's quarter (k-part kp) of their centroid rows
+          f32x2 yr[PQ][DIM / 8];
+#pragma unroll
+          for (int c = 0; c < PQ; ++c) {
+            const uint32_t cq = (uint32_t)__shfl((int)code, (lane >> 2) * PQ + c);
+            const float* r = centroids + (int64_t)cq * DIM + 2 * kp;
+#pragma unroll
+            for (int i = 0; i < DIM / 8; ++i) yr[c][i] = *reinterpret_cast<const f32x2*>(r + 8 * i);
+          }
+          const float* xb = &sX[kp * XK];
+          float4 x[DIM / 16];
+#pragma unroll
+          for (int jj = 0; jj < DIM / 16; ++jj) x[jj] = *reinterpret_cast<const float4*>(xb + 4 * jj);
+          for (int qq = 0; qq < nq; ++qq) {
+            const float* xnext = xb + min(qq + 1, nq - 1) * XT;
+            f32x2 pp[PQ];
+#pragma unroll
+            for (int c = 0; c < PQ; ++c) pp[c] = (f32x2){0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < DIM / 16; ++jj) {
+              const float4 xa = x[jj];
+              const f32x2 xe = {xa.x, xa.y}, xo = {xa.z, xa.w};      // i = 2 jj, 2 jj + 1
+#pragma unroll
+              for (int c = 0; c < PQ; ++c) pp[c] = pp[c] + xe * yr[c][2 * jj];
+#pragma unroll
+              for (int c = 0; c < PQ; ++c) pp[c] = pp[c] + xo * yr[c][2 * jj + 1];
+              x[jj] = *reinterpret_cast<const float4*>(xnext + 4 * jj);      // the next token's piece, a token ahead of its use
+            }
+            // lane kp holds (p[2kp], p[2kp+1]): kp 0 and 1 fold with kp 2 and 3, then kp 0 takes kp 1's two terms
+            float sums[PQ];
+#pragma unroll
+            for (int c = 0; c < PQ; ++c) {
+              const float a = pp[c].x + quad_perm<0x4E>(pp[c].x);      // kp 0: p0 + p4   kp 1: p2 + p6
+              const float e = pp[c].y + quad_perm<0x4E>(pp[c].y);      // kp 0: p1 + p5   kp 1: p3 + p7
+              float sum = 0.f;
+              sum = sum + a;
+              sum = sum + e;
+              sum = sum + quad_perm<0xB1>(a);
+              sum = sum + quad_perm<0xB1>(e);
+              sums[c] = sum;
+            }
+            if (kp == 0) {
+              float* dst = &sS[wave][qq * SS + (lane >> 2) * PQ];
+              if constexpr (PQ == 4) *reinterpret_cast<float4*>(dst) = make_float4(sums[0], sums[1], sums[2], sums[3]);
+              else if constexpr (PQ == 2) *reinterpret_cast<float2*>(dst) = make_float2(sums[0], sums[1]);
+              else dst[0] = sums[0];
+            }
           }
         }
-        sM[wave][lane] = mx;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-          float score = 0.f;
-          for (int qq = 0; qq < Lq; ++qq) {
-            const float a0 = sM[wave][qq], a1 = sM[wave][32 + qq];
-            const float mm = (a1 > a0) ? a1 : a0;
-            if (mm > NP_NEG_INF) score = score + mm;
+        // per-token maxima of the documents this chunk touches: lanes = (token, even / odd pairs of the segment)
+        const int cend = min(c0 + CH, total);
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const int s0 = max(st[dd], c0) - c0, s1 = min(st[dd + 1], cend) - c0;
+          if (s1 <= s0) continue;
+          float mm = NP_NEG_INF;
+          for (int e = s0 + half; e < s1; e += 2) {
+            const float v = sS[wave][ql * SS + e];
+            if (v > mm) mm = v;
           }
-          if (live) approx[pbase + i] = score;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      return;
-    }
-  }
-  for (int it = 0; it < ndoc_iter; ++it) {           // block-uniform trip count (barriers inside)
-    const int i = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
-    const bool live = i < n;
-    const uint4 m = meta[pbase + (live ? i : 0)];
-    const int nd = live ? (int)m.y : 0;
-    const int64_t cl = (int64_t)m.z | ((int64_t)(m.w & 0xFF) << 32);
-    float score = 0.f;
-    for (int qt = 0; qt < Lq; qt += 32) {
-      __syncthreads();
-      for (int w = tid; w < 32 * (DIM / 4); w += 256) {
-        const int r = w / (DIM / 4), c4 = w - r * (DIM / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qt + r < Lq) v = *reinterpret_cast<const float4*>(qrows + (int64_t)(q0 + qt + r) * DIM + 4 * c4);
-        *reinterpret_cast<float4*>(&sQ[r * QS + 4 * c4]) = v;
-      }
-      __syncthreads();
-      float mx = NP_NEG_INF;
-      for (int j0 = 0; j0 < nd; j0 += 2) {
-        const int j = j0 + half;
-        // the two centroid rows of this step, one per half-wave, through LDS
-        {
-          const uint32_t c = codes[cl + max(min(j, nd - 1), 0)];
-          const float4* src = reinterpret_cast<const float4*>(centroids + (int64_t)c * DIM);
-          if (ql < DIM / 4) *reinterpret_cast<float4*>(&sC[wave][half][4 * ql]) = src[ql];
+          const float other = __shfl_xor(mm, 32);
+          if (other > mm) mm = other;
+          if (half == 0 && ql < nq) {
+            const float cur = sM[wave][dd][ql];
+            if (mm > cur) sM[wave][dd][ql] = mm;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, p45 = {0.f, 0.f}, p67 = {0.f, 0.f};
-        const float* xq = &sQ[ql * QS];
-        const float* yc = &sC[wave][half][0];
-        const int kfull = TAIL ? (ldim & ~7) : DIM;
-#pragma unroll 4
-        for (int k = 0; k < kfull; k += 8) {
-          const float4 x0 = *reinterpret_cast<const float4*>(xq + k), x1 = *reinterpret_cast<const float4*>(xq + k + 4);
-          const float4 y0 = *reinterpret_cast<const float4*>(yc + k), y1 = *reinterpret_cast<const float4*>(yc + k + 4);
-          p01 = p01 + (f32x2){x0.x, x0.y} * (f32x2){y0.x, y0.y};
-          p23 = p23 + (f32x2){x0.z, x0.w} * (f32x2){y0.z, y0.w};
-          p45 = p45 + (f32x2){x1.x, x1.y} * (f32x2){y1.x, y1.y};
-          p67 = p67 + (f32x2){x1.z, x1.w} * (f32x2){y1.z, y1.w};
-        }
-        float sum = 0.f;
-        sum = sum + (p01.x + p45.x);
-        sum = sum + (p01.y + p45.y);
-        sum = sum + (p23.x + p67.x);
-        sum = sum + (p23.y + p67.y);
-        if constexpr (TAIL)
-          for (int k = kfull; k < ldim; ++k) sum = sum + xq[k] * yc[k];
-        if (j < nd && sum > mx) mx = sum;          // search.rs:286-291: `if centroid_score > max_score`
-        __builtin_amdgcn_wave_barrier();            // sC is rewritten by the next step
+        __builtin_amdgcn_wave_barrier();                // sS is rewritten by the next chunk
       }
-      // the two halves saw disjoint codes: combine with the same '>' rule, then the q-ordered sum (search.rs:294-297)
-      sM[wave][lane] = mx;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) {
-        const int nq = min(32, Lq - qt);
+      if (dl) {
+        float score = qt ? approx[pbase + i0 + lane] : 0.f;      // the q-ordered sum continues over the token tiles
         for (int qq = 0; qq < nq; ++qq) {
-          const float a0 = sM[wave][qq], a1 = sM[wave][32 + qq];
-          const float mm = (a1 > a0) ? a1 : a0;
+          const float mm = sM[wave][lane][qq];
           if (mm > NP_NEG_INF) score = score + mm;
         }
+        approx[pbase + i0 + lane] = score;
       }
-      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                  // sM is reset by the next group
     }
-    if (live && lane == 0) approx[pbase + i] = score;
   }
 }
 

@@ -220,7 +220,9 @@ static int64_t per_query_bytes(const DeviceIndex* ix, int LQP, int n_sel, int to
          + (int64_t)std::max(n_sel, 1) * 16 + (int64_t)std::max(top_k, 1) * 20 + 64;
 }
 
-static WsPlan plan_workspace(const DeviceIndex* ix, int B, int LQP, const np_search_params* prm) {
+// `probed_cells`: the most cells one query of the batch can take candidates from (n_ivf_probe x its tokens), 0 = unknown (a
+// subset scales n_ivf_probe on the device, search.rs:350-382): the pool and its rounds are then planned for n_docs per query.
+static WsPlan plan_workspace(const DeviceIndex* ix, int B, int LQP, const np_search_params* prm, int64_t probed_cells = 0) {
   WsPlan w;
   const int64_t budget = ix->ws_budget.load(std::memory_order_relaxed);
   const int64_t pq = std::max<int64_t>(per_query_bytes(ix, LQP, n_sel_of(prm), prm->top_k), 1);
@@ -230,12 +232,15 @@ static WsPlan plan_workspace(const DeviceIndex* ix, int B, int LQP, const np_sea
   // if every query's worst case fits next to the scratch, take it (no rounds at all)
   while (S > 1 && S * pq + 2 * nd * NP_POOL_ENTRY > budget) --S;
   w.S = (int)S;
-  const int64_t worst = S * nd;
+  int64_t worst_q = nd;      // candidates of one query at most: the probed cells' lists, were they the longest of the index
+  if (probed_cells > 0 && !ix->ivf_top_prefix.empty())
+    worst_q = std::max<int64_t>(1, std::min(nd, ix->ivf_top_prefix[(size_t)std::min<int64_t>(probed_cells, ix->K)]));
+  const int64_t worst = S * worst_q;
   int64_t pool = (budget - S * pq) / NP_POOL_ENTRY;
-  pool = std::min(worst, std::max(pool, std::min<int64_t>(2, S) * nd));
+  pool = std::min(worst, std::max(pool, std::min<int64_t>(2, S) * worst_q));
   w.pool = std::max<int64_t>(pool, 1);
-  // first-fit packing in query order: every closed round holds more than pool - n_docs entries
-  w.max_rounds = (worst <= w.pool) ? 1 : (int)std::min<int64_t>(S, worst / (w.pool - nd + 1) + 1);
+  // first-fit packing in query order: every closed round holds more than pool - worst_q entries
+  w.max_rounds = (worst <= w.pool) ? 1 : (int)std::min<int64_t>(S, worst / (w.pool - worst_q + 1) + 1);
   return w;
 }
 
@@ -392,7 +397,7 @@ static void launch_approx(hipStream_t st, const DeviceIndex* ix, Workspace& w, c
 // Batched path (search.rs:259-272): approximate scores of the listed documents in the reference's mat-vec arithmetic
 static void launch_matvec(hipStream_t st, const DeviceIndex* ix, Workspace& w, const float* d_q, const int32_t* d_qoff, int B,
                           const uint4* meta, const int32_t* n, const RoundPlan& rp, int round) {
-  const dim3 grid(64, (unsigned)B);
+  const dim3 grid(512 / NP_MV_DOCS, (unsigned)B);      // a wave per NP_MV_DOCS documents: one pass over ~n_sel listed documents
 #define NP_MATVEC(D)                                                                                                   \
   do {                                                                                                                 \
     if (ix->ldim & 7)                                                                                                  \
@@ -472,7 +477,8 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
   const int64_t KP = ix->KP, G = KP / 32, NW = (ix->n_docs + 31) / 32;
   const int nchunks = (int)((NW + NP_CHUNK_WORDS - 1) / NP_CHUNK_WORDS);
   const int nsel1 = std::max(cs->n_sel, 1), topk1 = std::max(prm.top_k, 1);
-  WsPlan plan = plan_workspace(ix, B, LQP, &prm);
+  const int64_t probed_cells = subset_len < 0 ? (int64_t)std::max(prm.n_ivf_probe, 1) * maxLq : 0;
+  WsPlan plan = plan_workspace(ix, B, LQP, &prm, probed_cells);
   if (ix->ws_auto) {
     // The default budget was what the device had free at open.  Before a pool GROWS, and whenever the budget stands below
     // its value at open, look at what is free now: the budget covers this context's scratch AND pool, so what this context
@@ -502,7 +508,7 @@ static int phase_a_once(const DeviceIndex* ix, CallState* cs, const float* d_q, 
           // race re-plans from whatever the winner stored)
           int64_t seen = budget;
           (void)ix->ws_budget.compare_exchange_strong(seen, nb, std::memory_order_relaxed);
-          plan = plan_workspace(ix, B, LQP, &prm);
+          plan = plan_workspace(ix, B, LQP, &prm, probed_cells);
         }
       }
     }

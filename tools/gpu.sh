@@ -61,9 +61,11 @@ for job in "$@"; do
     pmc) shift 2
       mkdir -p $O/pmc_$name
       i=0
-      for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
-                 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-                 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+      sets=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
+            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS")
+      [ -n "$PMC_SQ_ONLY" ] && sets=("${sets[@]:4}")      # PMC_SQ_ONLY=1: the two SQ passes only (what is a kernel waiting for)
+      for set in "${sets[@]}"; do
         i=$((i+1))
         ( cd /tmp && export TMPDIR=/tmp && timeout $T rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$name/p$i -o p -- \
             python $REPO/bench.py --steps 3 --warmup 1 --cpu-queries 0 --parity-queries 0 "$@" > /dev/null 2> $O/pmc_$name/p$i.err )
