@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) prep_queries_kernel(const float* __restri
 // The k loop feeds k = 2s + (lane>>5) in ascending s, so each output is the k-ordered FMA chain.
 // ---------------------------------------------------------------------------------------------
 template <int DIM, int CPW>   // CPW = 32-centroid A fragments per wave
-__global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPW == 1 ? 3 : 1))) qc_gemm_kernel(const float* __restrict__ C, int64_t K, int64_t KP,
                                                       const float* __restrict__ Qt, int B, int LQP,
                                                       float* __restrict__ QCT, uint32_t* __restrict__ gmax,
                                                       uint8_t* __restrict__ QCU, int RB /* u8 row bytes: power of two >= LQP */,
@@ -218,8 +218,12 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
   // one per 25-30 cycles while the sibling wave's back-to-back f32 MFMA chain holds the SIMD -- per SIMD the kernel is
   // MFMA time plus epilogue time; placing element r of tile t-1 after MFMA 4r+3 of tile t (the wave's own MFMA shadow) did
   // not change that (0.48 ms).
+  // Round 6: the f32 tile goes through LDS in two halves of 16 centroid rows (one more wave barrier per fragment) and the kernel is
+  // compiled for three waves per SIMD: at DIM = 128 it stood at 172 registers and 54 KB of LDS per workgroup -- both just past
+  // what three workgroups per CU allow (168 / 53.3 KB).  With a third wave to run its MFMA chain while two are in their
+  // epilogues: S1 0.370 -> 0.366 ms at K = 2^16, 2.95 - 3.05 -> 2.77 ms at K = 2^19 (63 % of the f32 MFMA peak).
   constexpr int TS = 36;   // f32 tile row stride in words: 16-B aligned rows, halves land on different banks
-  __shared__ __attribute__((aligned(16))) float sT[4][32 * TS];
+  __shared__ __attribute__((aligned(16))) float sT[4][16 * TS];   // half a tile (16 centroid rows) at a time
   __shared__ __attribute__((aligned(16))) uint8_t sU[4][32 * 32];
   auto epilogue = [&](const f32x16 (&acc)[CPW], int tile) {
     // (Round 5, measured and removed: s_setprio 2 for the epilogue -- VALU issue between the waves of a SIMD is arbitrated by
@@ -234,7 +238,6 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
       float vsum = 0.f, vmax = acc[f][0];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sT[wave][mfma_row(r, kk) * TS + li] = acc[f][r];
         vsum += acc[f][r];
         vmax = fmaxf(vmax, acc[f][r]);
       }
@@ -263,14 +266,20 @@ __global__ void __launch_bounds__(256) qc_gemm_kernel(const float* __restrict__ 
           sU[wave][mfma_row(r, kk) * 32 + li] = (uint8_t)u;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();   // the wave's own LDS writes are visible to its other lanes
       float* outb = QCT + ((int64_t)b * KP + c0 + 32 * f) * LQP + qt * 32 + 4 * c4;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = 8 * g + 4 * h + rr;
-        const float4 v = *reinterpret_cast<const float4*>(&sT[wave][row * TS + 4 * c4]);
-        *reinterpret_cast<float4*>(outb + (int64_t)row * LQP) = v;
+      for (int hp = 0; hp < 2; ++hp) {   // rows 0..15 (registers 0..7), then rows 16..31, through the same half tile
+#pragma unroll
+        for (int r = 8 * hp; r < 8 * hp + 8; ++r) sT[wave][(mfma_row(r, kk) - 16 * hp) * TS + li] = acc[f][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the wave's own LDS writes are visible to its other lanes
+#pragma unroll
+        for (int g = 2 * hp; g < 2 * hp + 2; ++g) {
+          const int row = 8 * g + 4 * h + rr;
+          const float4 v = *reinterpret_cast<const float4*>(&sT[wave][(row - 16 * hp) * TS + 4 * c4]);
+          *reinterpret_cast<float4*>(outb + (int64_t)row * LQP) = v;
+        }
+        __builtin_amdgcn_wave_barrier();   // the second half / the next fragment overwrites sT
       }
       if (QCU) {
         const int row = lane >> 1, half = lane & 1;   // two lanes per 32-B row piece
